@@ -1,0 +1,203 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (CPU, this container only).
+
+    python tests/golden/make_golden.py            # needs /root/reference
+
+Imports /root/reference/model.py and train_IEMOCAP.py unmodified, loads the
+formula weights of tests/golden/formula.py into the reference's own modules and
+records inputs-independent expected outputs.  The fixtures are data (inputs are
+regenerated from formulas; expected outputs/gradients/losses are stored).  The
+reference never travels: only these .npz files and this script are committed.
+
+Dropout: eval mode, or train mode with every dropout probability set to 0 on the
+reference module instances (attribute assignment on objects; no reference code is
+changed), because torch's CPU dropout stream cannot be reproduced elsewhere.
+"""
+import os
+import sys
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, "/root/reference")
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import formula as F_  # noqa: E402
+import model as ref  # noqa: E402  (the reference)
+
+torch.set_num_threads(8)
+
+GEN = {"acoustic": "AcousticGenerator", "visual": "VisualGenerator", "text": "TextGenerator"}
+DISC = {"acoustic": "AcousticDiscriminator", "visual": "VisualDiscriminator", "text": "TextDiscriminator"}
+DIN = {"acoustic": 100, "visual": 512, "text": 100}
+
+SELECTED = [
+    "transformer_encoder.layers.0.self_attn.in_proj_weight",
+    "transformer_encoder.layers.0.self_attn.in_proj_bias",
+    "transformer_encoder.layers.3.self_attn.out_proj.weight",
+    "transformer_encoder.layers.3.self_attn.out_proj.bias",
+    "transformer_encoder.layers.7.linear1.weight",
+    "transformer_encoder.layers.7.linear1.bias",
+    "transformer_encoder.layers.4.linear2.weight",
+    "transformer_encoder.layers.4.linear2.bias",
+    "transformer_encoder.layers.2.norm1.weight",
+    "transformer_encoder.layers.2.norm1.bias",
+    "transformer_encoder.layers.5.norm2.weight",
+    "transformer_encoder.layers.5.norm2.bias",
+    "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias",
+    "object.weight", "object.bias",
+]
+
+
+def build(cls_name):
+    m = getattr(ref, cls_name)(100, dropout=0.2)
+    sd = F_.formula_state_dict(m.state_dict())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    return m
+
+
+def zero_dropout(m):
+    for sub in m.modules():
+        if isinstance(sub, nn.Dropout):
+            sub.p = 0.0
+        if isinstance(sub, nn.MultiheadAttention):
+            sub.dropout = 0.0
+
+
+def put(d, prefix, t):
+    for k, v in F_.summarize(t.detach().cpu().numpy() if torch.is_tensor(t) else t).items():
+        d[prefix + "/" + k] = v
+
+
+def module_cases():
+    out = {}
+    for cls_name, din in (("AcousticGenerator", 100), ("TextGenerator", 100), ("VisualGenerator", 512),
+                          ("AcousticDiscriminator", 100), ("TextDiscriminator", 100),
+                          ("VisualDiscriminator", 512), ("VisualDiscriminator", 100)):
+        m = build(cls_name).eval()
+        for (S, B) in ((7, 2), (110, 3)):
+            tag = "%s.%d.%dx%d" % (cls_name, din, S, B)
+            x = torch.from_numpy(F_.formula_input(tag, S, B, din, pad_from=max(1, S - 3))).requires_grad_(True)
+            for p in m.parameters():
+                p.grad = None
+            y = m(x)
+            g = torch.from_numpy(F_.formula_input("grad." + tag, S, B, y.shape[-1])) - 0.5
+            (y * g).sum().backward()
+            put(out, tag + "/out", y)
+            put(out, tag + "/dx", x.grad)
+            sd = dict(m.named_parameters())
+            for k in SELECTED:
+                if k in sd and sd[k].grad is not None:
+                    put(out, tag + "/grad/" + k, sd[k].grad)
+            # the template layer never receives a gradient (model.py:1210-1213)
+            out[tag + "/template_grad_is_none"] = np.array(
+                all(p.grad is None for k, p in sd.items() if k.startswith("encoder_layer.")))
+            print("module", tag, tuple(y.shape), float(y.abs().mean()))
+    return out
+
+
+def gan_steps():
+    """Two full 12-sub-step iterations via the reference's own train_disc/train_gen, dropout p=0."""
+    import train_IEMOCAP as T
+    out = {}
+    S, B = 7, 2
+    gens = {k: build(v) for k, v in GEN.items()}
+    discs = {k: build(v) for k, v in DISC.items()}
+    for m in list(gens.values()) + list(discs.values()):
+        zero_dropout(m)
+    lr, b1, b2 = 1e-4, 0.5, 0.6  # the actual call, train_IEMOCAP.py:603-606
+    A = torch.optim.Adam
+    opt = {("G", "acoustic"): A(gens["acoustic"].parameters(), lr=lr, betas=(b1, b2)),
+           ("D", "acoustic"): A(discs["acoustic"].parameters(), lr=lr / 2, betas=(b1, b2)),
+           ("G", "visual"): A(gens["visual"].parameters(), lr=lr, betas=(b1, b2)),
+           ("D", "visual"): A(discs["visual"].parameters(), lr=lr / 2, betas=(b1, b2)),
+           ("G", "text"): A(gens["text"].parameters(), lr=lr * 1.1, betas=(b1, b2)),
+           ("D", "text"): A(discs["text"].parameters(), lr=lr / 2, betas=(b1, b2))}
+    bce = nn.BCELoss()
+    batch = {k: torch.from_numpy(F_.formula_input("gan." + k, S, B, DIN[k], pad_from=5)) for k in DIN}
+    valid = torch.ones(S, B, 1)
+    fake = torch.zeros(S, B, 1)
+    sched = [("D", "visual", "acoustic"), ("G", "acoustic", "visual"), ("D", "visual", "text"),
+             ("G", "text", "visual"), ("D", "text", "acoustic"), ("G", "acoustic", "text"),
+             ("D", "acoustic", "text"), ("G", "text", "acoustic"), ("D", "text", "visual"),
+             ("G", "visual", "text"), ("D", "acoustic", "visual"), ("G", "visual", "acoustic")]
+    losses = []
+    seen = set()
+    for it in range(2):
+        for kind, who, partner in sched:  # order of train_IEMOCAP.py:355-382
+            if kind == "D":
+                v = T.train_disc(discs[who], batch[who], gens[partner], batch[partner], opt[("D", who)], bce, valid, fake)
+            else:
+                v = T.train_gen(gens[who], batch[who], discs[partner], opt[("G", who)], bce, valid, fake)
+            losses.append(float(v))
+            print("gan it%d %s %s|%s loss %.7f" % (it, kind, who, partner, float(v)))
+            if (kind, who) not in seen:
+                # parameter delta right after this module's FIRST Adam step (t = 1).  Later states are
+                # not fixtures: Adam's first steps are sign-like (delta = -lr*g/(|g|+eps)), so fp32
+                # rounding noise on ~0 gradients flips +-lr updates and trajectories separate
+                # chaotically (an fp64 restatement drifts from this fp32 run just as much).
+                seen.add((kind, who))
+                sd = dict((discs if kind == "D" else gens)[who].named_parameters())
+                for k in SELECTED:
+                    if k in sd:
+                        w0 = F_.formula_tensor(k, tuple(sd[k].shape))
+                        put(out, "gan/%s_%s/delta1/%s" % (kind, who, k), sd[k].detach().numpy() - w0)
+    out["gan/losses"] = np.array(losses, dtype=np.float64)
+    return out
+
+
+def misc():
+    out = {}
+    out["pe/100"] = ref.PositionalEncoding(100).pe.numpy()[:, 0, :]
+    out["pe/512"] = ref.PositionalEncoding(512).pe.numpy()[:, 0, :]
+    # BCE edge cases (call site train_IEMOCAP.py:300)
+    p = torch.tensor([0.0, 1.0, 1e-45, 1.0 - 1e-7, 0.5, 0.25, 1e-30, 0.9999999], dtype=torch.float32)
+    for tgt in (0.0, 1.0):
+        y = torch.full_like(p, tgt)
+        out["bce/target%d" % int(tgt)] = np.float64(nn.BCELoss()(p, y).item())
+        out["bce/target%d_elem" % int(tgt)] = nn.BCELoss(reduction="none")(p, y).numpy()
+    out["bce/probs"] = p.numpy()
+    # Adam (call sites train_IEMOCAP.py:292-297, :661)
+    for tag, kw in (("gan", dict(lr=1e-4, betas=(0.5, 0.6))), ("phase2", dict(lr=1e-4, weight_decay=0.008))):
+        w = torch.from_numpy(F_.formula_tensor("adam.w", (37, 11))).clone().requires_grad_(True)
+        o = torch.optim.Adam([w], **kw)
+        for step in range(3):
+            w.grad = torch.from_numpy(F_.formula_tensor("adam.g%d" % step, (37, 11))).clone()
+            o.step()
+            out["adam/%s/step%d" % (tag, step)] = w.detach().numpy().copy()
+    # phase 2: GAN_FFN forward + MaskedNLLLoss (model.py:1434-1462, :62-81; train_IEMOCAP.py:151-156,653)
+    S, B = 7, 2
+    gens = {k: build(v).eval() for k, v in GEN.items()}
+    net = ref.GAN_FFN(gens["acoustic"], gens["visual"], gens["text"], n_classes=6, dropout=0.2).eval()
+    with torch.no_grad():
+        net.fc.weight.copy_(torch.from_numpy(F_.formula_tensor("phase2.fc.weight", (6, 100))))
+        net.fc.bias.copy_(torch.from_numpy(F_.formula_tensor("phase2.fc.bias", (6,))))
+    batch = {k: torch.from_numpy(F_.formula_input("gan." + k, S, B, DIN[k], pad_from=5)) for k in DIN}
+    lp, _, _, _ = net(batch["acoustic"], batch["visual"], batch["text"])
+    umask = torch.tensor([[1, 1, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 0, 0]], dtype=torch.float32)
+    label = torch.tensor([[0, 1, 2, 3, 4, 5, 0], [5, 4, 3, 2, 1, 0, 0]], dtype=torch.long)
+    wts = torch.FloatTensor([1.2, 0.60072, 0.38066, 0.94019, 0.67924, 0.34332])
+    lp_ = lp.transpose(0, 1).contiguous().view(-1, lp.size()[2])
+    out["phase2/log_prob"] = lp.detach().numpy()
+    loss_w = ref.MaskedNLLLoss(wts)(lp_, label.view(-1), umask)
+    out["phase2/loss_weighted"] = np.float64(loss_w.item())
+    out["phase2/loss_unweighted"] = np.float64(ref.MaskedNLLLoss()(lp_, label.view(-1), umask).item())
+    loss_w.backward()
+    out["phase2/grad_fc_weight"] = net.fc.weight.grad.numpy()
+    put(out, "phase2/grad_text_fc2_weight", gens["text"].fc2.weight.grad)
+    put(out, "phase2/grad_visual_l0_inproj", gens["visual"].transformer_encoder.layers[0].self_attn.in_proj_weight.grad)
+    out["phase2/umask"] = umask.numpy()
+    out["phase2/label"] = label.numpy()
+    return out
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    np.savez_compressed(os.path.join(HERE, "misc.npz"), **misc())
+    np.savez_compressed(os.path.join(HERE, "modules.npz"), **module_cases())
+    np.savez_compressed(os.path.join(HERE, "gan_steps.npz"), **gan_steps())
+    print("golden fixtures written to", HERE)
