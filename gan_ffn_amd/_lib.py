@@ -1,0 +1,94 @@
+"""ctypes binding of libganffn.so (the C ABI in include/ganffn.h).
+
+The HIP library is the product path: if it is missing or a call fails, this module
+raises — there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libganffn.so")
+
+
+class EncCfg(C.Structure):
+    _fields_ = [("S", C.c_int32), ("B", C.c_int32), ("E", C.c_int32), ("H", C.c_int32), ("F", C.c_int32),
+                ("L", C.c_int32), ("p_pe", C.c_float), ("p_enc", C.c_float), ("ln_eps", C.c_float),
+                ("train", C.c_int32)]
+
+
+class HeadCfg(C.Structure):
+    _fields_ = [("T", C.c_int32), ("E", C.c_int32), ("D1", C.c_int32), ("D2", C.c_int32), ("kind", C.c_int32),
+                ("p", C.c_float), ("train", C.c_int32)]
+
+
+_P = C.c_void_p
+_I, _L, _F, _U32, _U64 = C.c_int, C.c_int64, C.c_float, C.c_uint32, C.c_uint64
+_PE, _PH = C.POINTER(EncCfg), C.POINTER(HeadCfg)
+
+# name -> (restype, argtypes); must cover every symbol include/ganffn.h declares
+SIGNATURES = {
+    "ganffn_version": (_I, []),
+    "ganffn_last_error": (C.c_char_p, []),
+    "ganffn_layer_param_count": (_L, [_I, _I]),
+    "ganffn_layer_param_offsets": (_I, [_I, _I, C.POINTER(C.c_int64)]),
+    "ganffn_encoder_saved_floats": (_L, [_PE]),
+    "ganffn_encoder_workspace_floats": (_L, [_PE]),
+    "ganffn_head_saved_floats": (_L, [_PH]),
+    "ganffn_head_workspace_floats": (_L, [_PH]),
+    "ganffn_rng_advance": (_I, [_P, _U64, _P]),
+    "ganffn_pe_table": (_I, [_P, _I, _I, _P]),
+    "ganffn_encoder_fwd": (_I, [_PE, _P, _P, _P, _P, _P, _P, _P, _U64, _P]),
+    "ganffn_encoder_bwd": (_I, [_PE, _I, _I, _P, _P, _P, _P, _P, _P, _U64, _P]),
+    "ganffn_head_fwd": (_I, [_PH, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _P]),
+    "ganffn_head_bwd": (_I, [_PH, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _P]),
+    "ganffn_linear_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "ganffn_linear_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ganffn_bce_fwd": (_I, [_P, _F, _I, _F, _P, _I, _P]),
+    "ganffn_bce_bwd": (_I, [_P, _F, _I, _F, _P, _P]),
+    "ganffn_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P]),
+    "ganffn_add3": (_I, [_P, _P, _P, _P, _L, _P]),
+    "ganffn_logsoftmax_nll": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ganffn_gemm_nt": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "ganffn_gemm_nn": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ganffn_gemm_tn_acc": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "ganffn_attention_fwd": (_I, [_P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),
+    "ganffn_attention_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),
+    "ganffn_add_dropout_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U32, _P, _U64, _P]),
+    "ganffn_add_dropout_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U32, _P, _U64, _P]),
+    "ganffn_dropout": (_I, [_P, _P, _I, _I, _F, _U32, _P, _U64, _P]),
+}
+
+_lib = None
+
+
+class GanffnError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libganffn.so and bind every entry point.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GanffnError(
+            "libganffn.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C gan_ffn_amd/csrc`. There is no CPU fallback for the GAN-FFN hot path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().ganffn_last_error()
+        raise GanffnError("%s failed (rc=%d): %s" % (what or "libganffn call", rc, msg.decode() if msg else "?"))
+
+
+def call(name, *args):
+    """call an int-returning entry point and raise on a non-zero code"""
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,415 @@
+// api.hip — C ABI of libganffn.so (declared in include/ganffn.h): argument checking and the launch
+// sequences of the encoder stack, the heads and the plain linears.  No allocation, no synchronisation.
+#include "common.h"
+
+#include <string.h>
+
+namespace ganffn {
+
+static thread_local char g_err[512] = "";
+char* err_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// from elementwise.hip
+int launch_gelu_bwd_drop(const float* d, const float* u, float* out, int R, int C, float p, uint32_t site,
+                         const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+int launch_disc_tail_fwd(const float* a2, const float* w3, const float* b3, float* prob, int T, int D2, float p,
+                         const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+int launch_disc_tail_bwd(const float* dprob, const float* prob, const float* a2, const float* u2, const float* w3,
+                         float* d_pre2, float* gw3, float* gb3, int T, int D2, float p, const uint64_t* rng, uint64_t add,
+                         int train, hipStream_t st);
+int launch_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int T, int K, int N, hipStream_t st);
+int launch_small_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* gw, float* gb, int T, int K,
+                            int N, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
+// parameter slab layout of one encoder layer
+// ------------------------------------------------------------------------------------------
+struct LayerOff {
+    int64_t in_w, in_b, out_w, out_b, w1, b1, w2, b2, n1w, n1b, n2w, n2b, total;
+};
+static LayerOff layer_off(int E, int F) {
+    LayerOff o;
+    int64_t p = 0;
+    auto take = [&](int64_t n) { int64_t r = p; p += (n + 3) & ~int64_t(3); return r; };
+    o.in_w = take((int64_t)3 * E * E);
+    o.in_b = take(3 * E);
+    o.out_w = take((int64_t)E * E);
+    o.out_b = take(E);
+    o.w1 = take((int64_t)F * E);
+    o.b1 = take(F);
+    o.w2 = take((int64_t)E * F);
+    o.b2 = take(E);
+    o.n1w = take(E);
+    o.n1b = take(E);
+    o.n2w = take(E);
+    o.n2b = take(E);
+    o.total = p;
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------
+// saved-for-backward layout of one encoder stack
+//   X[0..L]      (L+1) * T*E     X[0] = PE output, X[l+1] = output of layer l
+//   per layer:   qkv 3TE | attn_o TE | x1 TE | xhat1 TE | xhat2 TE | h TF | rstd1 T4 | rstd2 T4
+// ------------------------------------------------------------------------------------------
+struct SavedOff {
+    int64_t X, layers, per_layer, qkv, attn_o, x1, xhat1, xhat2, h, rstd1, rstd2, total;
+};
+static SavedOff saved_off(const ganffn_enc_cfg* c) {
+    SavedOff s;
+    const int64_t T = (int64_t)c->S * c->B, TE = T * c->E, TF = T * c->F, T4 = (T + 3) & ~int64_t(3);
+    s.X = 0;
+    s.layers = (int64_t)(c->L + 1) * TE;
+    int64_t p = 0;
+    s.qkv = p; p += 3 * TE;
+    s.attn_o = p; p += TE;
+    s.x1 = p; p += TE;
+    s.xhat1 = p; p += TE;
+    s.xhat2 = p; p += TE;
+    s.h = p; p += TF;
+    s.rstd1 = p; p += T4;
+    s.rstd2 = p; p += T4;
+    s.per_layer = p;
+    s.total = s.layers + (int64_t)c->L * s.per_layer;
+    return s;
+}
+
+static int check_cfg(const ganffn_enc_cfg* c) {
+    GF_CHECK_ARG(c, "null cfg");
+    GF_CHECK_ARG(c->S >= 1 && c->S <= 110, "S=%d out of range [1,110] (PositionalEncoding max_len, model.py:1179)", c->S);
+    GF_CHECK_ARG(c->B >= 1, "B=%d", c->B);
+    GF_CHECK_ARG(c->E >= 4 && (c->E & 3) == 0 && c->E <= 512, "E=%d must be a multiple of 4 and <= 512", c->E);
+    GF_CHECK_ARG(c->H >= 1 && c->E % c->H == 0, "E=%d not divisible by H=%d", c->E, c->H);
+    GF_CHECK_ARG(c->F >= 4 && (c->F & 3) == 0, "F=%d must be a multiple of 4", c->F);
+    GF_CHECK_ARG(c->L >= 1 && c->L <= 64, "L=%d", c->L);
+    GF_CHECK_ARG(c->p_pe >= 0.f && c->p_pe < 1.f && c->p_enc >= 0.f && c->p_enc < 1.f, "dropout p out of [0,1)");
+    return 0;
+}
+
+static int64_t enc_ws_floats(const ganffn_enc_cfg* c) {
+    const int64_t T = (int64_t)c->S * c->B, TE = T * c->E, TF = T * c->F;
+    const int64_t bwd = TF + 8 * TE;                               // dh | dz dy tmp d_attn d_qkv(3)
+    const SavedOff s = saved_off(c);
+    const int64_t fwd_nosave = 2 * TE + s.per_layer + TE;          // X ping-pong + one layer's saved set + tmp
+    return (bwd > fwd_nosave ? bwd : fwd_nosave) + 64;
+}
+
+}  // namespace ganffn
+
+using namespace ganffn;
+
+extern "C" int ganffn_version(void) { return GANFFN_VERSION; }
+extern "C" const char* ganffn_last_error(void) { return err_buf(); }
+
+extern "C" int64_t ganffn_layer_param_count(int E, int F) { return layer_off(E, F).total; }
+extern "C" int ganffn_layer_param_offsets(int E, int F, int64_t* o) {
+    GF_CHECK_ARG(o, "null offsets");
+    const LayerOff l = layer_off(E, F);
+    const int64_t v[12] = {l.in_w, l.in_b, l.out_w, l.out_b, l.w1, l.b1, l.w2, l.b2, l.n1w, l.n1b, l.n2w, l.n2b};
+    memcpy(o, v, sizeof(v));
+    return 0;
+}
+
+extern "C" int64_t ganffn_encoder_saved_floats(const ganffn_enc_cfg* c) {
+    if (check_cfg(c) != 0) return -1;
+    return saved_off(c).total;
+}
+extern "C" int64_t ganffn_encoder_workspace_floats(const ganffn_enc_cfg* c) {
+    if (check_cfg(c) != 0) return -1;
+    return enc_ws_floats(c);
+}
+
+// ------------------------------------------------------------------------------------------
+// encoder stack forward
+// ------------------------------------------------------------------------------------------
+extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, const float* pe, const float* params,
+                                  float* out, float* saved, float* workspace, const uint64_t* rng, uint64_t add,
+                                  void* stream) {
+    GF_TRY(check_cfg(c));
+    GF_CHECK_ARG(x_in && pe && params && out && workspace, "encoder_fwd: null pointer");
+    GF_CHECK_ARG(aligned16(x_in) && aligned16(params) && aligned16(out) && aligned16(workspace) && (!saved || aligned16(saved)),
+                 "encoder_fwd: buffers must be 16-byte aligned");
+    const bool drop = c->train && (c->p_pe > 0.f || c->p_enc > 0.f);
+    GF_CHECK_ARG(!drop || rng, "encoder_fwd: rng required in train mode");
+    hipStream_t st = (hipStream_t)stream;
+    const int S = c->S, B = c->B, E = c->E, H = c->H, F = c->F, L = c->L, T = S * B;
+    const int64_t TE = (int64_t)T * E;
+    const LayerOff lo = layer_off(E, F);
+    const SavedOff so = saved_off(c);
+    const int train = c->train;
+
+    float* tmp;      // [T x E] GEMM output before residual+LN
+    float* Xcur;
+    if (saved) {
+        tmp = workspace;
+        Xcur = saved + so.X;
+    } else {
+        tmp = workspace + 2 * TE + so.per_layer;
+        Xcur = workspace;
+    }
+    GF_TRY(launch_pe_dropout(x_in, pe, Xcur, S, B, E, c->p_pe, rng, add, train, st));
+
+    for (int l = 0; l < L; ++l) {
+        const float* P = params + (int64_t)l * lo.total;
+        float* sv = saved ? saved + so.layers + (int64_t)l * so.per_layer : workspace + 2 * TE;
+        float* Xnext = saved ? saved + so.X + (int64_t)(l + 1) * TE : workspace + ((l & 1) ? 0 : TE);
+        if (l == L - 1) Xnext = out;
+        const uint32_t site = SITE_LAYER0 + 4 * l;
+        EpiArgs ea;
+        // qkv = X W_in^T + b_in
+        ea.bias = P + lo.in_b;
+        GF_TRY(launch_gemm_nt(Xcur, E, P + lo.in_w, E, sv + so.qkv, 3 * E, T, 3 * E, E, EPI_NONE, ea, st));
+        // attention core
+        GF_TRY(launch_attention_fwd(sv + so.qkv, sv + so.attn_o, S, B, E, H, c->p_enc, site + 0, rng, add, train, st));
+        // out-proj, residual + dropout + LN1
+        ea.bias = P + lo.out_b;
+        GF_TRY(launch_gemm_nt(sv + so.attn_o, E, P + lo.out_w, E, tmp, E, T, E, E, EPI_NONE, ea, st));
+        GF_TRY(launch_add_drop_ln_fwd(Xcur, tmp, P + lo.n1w, P + lo.n1b, sv + so.x1, sv + so.xhat1, sv + so.rstd1, T, E,
+                                      c->ln_eps, c->p_enc, site + 1, rng, add, train, st));
+        // FFN: h = drop(relu(x1 W1^T + b1)); y = h W2^T + b2
+        EpiArgs e1;
+        e1.bias = P + lo.b1; e1.p = c->p_enc; e1.site = site + 2; e1.rng = rng; e1.rng_add = add; e1.train = train;
+        GF_TRY(launch_gemm_nt(sv + so.x1, E, P + lo.w1, E, sv + so.h, F, T, F, E, EPI_RELU_DROP, e1, st));
+        ea.bias = P + lo.b2;
+        GF_TRY(launch_gemm_nt(sv + so.h, F, P + lo.w2, F, tmp, E, T, E, F, EPI_NONE, ea, st));
+        GF_TRY(launch_add_drop_ln_fwd(sv + so.x1, tmp, P + lo.n2w, P + lo.n2b, Xnext, sv + so.xhat2, sv + so.rstd2, T, E,
+                                      c->ln_eps, c->p_enc, site + 3, rng, add, train, st));
+        if (saved && l == L - 1) {
+            // keep X[L] in the saved set too (not needed by backward, but keeps the layout uniform) — skip the copy:
+            // nothing reads X[L].
+        }
+        Xcur = Xnext;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// encoder stack backward over layers [lo_l, hi_l)
+// ------------------------------------------------------------------------------------------
+extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int layer_hi, float* dx, const float* params,
+                                  float* grads, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
+                                  void* stream) {
+    GF_TRY(check_cfg(c));
+    GF_CHECK_ARG(dx && params && saved && workspace, "encoder_bwd: null pointer");
+    GF_CHECK_ARG(0 <= layer_lo && layer_lo < layer_hi && layer_hi <= c->L, "encoder_bwd: bad layer range [%d,%d)", layer_lo, layer_hi);
+    GF_CHECK_ARG(aligned16(dx) && aligned16(params) && aligned16(saved) && aligned16(workspace) && (!grads || aligned16(grads)),
+                 "encoder_bwd: buffers must be 16-byte aligned");
+    const bool drop = c->train && (c->p_pe > 0.f || c->p_enc > 0.f);
+    GF_CHECK_ARG(!drop || rng, "encoder_bwd: rng required in train mode");
+    hipStream_t st = (hipStream_t)stream;
+    const int S = c->S, B = c->B, E = c->E, H = c->H, F = c->F, T = S * B;
+    const int64_t TE = (int64_t)T * E, TF = (int64_t)T * F;
+    const LayerOff lo = layer_off(E, F);
+    const SavedOff so = saved_off(c);
+    const int train = c->train;
+    const float pdrop = (train ? c->p_enc : 0.f);
+
+    float* dh = workspace;            // [T x F]
+    float* dz = dh + TF;              // [T x E] LN input gradient (residual branch)
+    float* dy = dz + TE;              // [T x E] gradient of the sub-layer output (after dropout bwd)
+    float* tmp = dy + TE;             // [T x E]
+    float* d_attn = tmp + TE;         // [T x E]
+    float* d_qkv = d_attn + TE;       // [T x 3E]
+
+    for (int l = layer_hi - 1; l >= layer_lo; --l) {
+        const float* P = params + (int64_t)l * lo.total;
+        float* G = grads ? grads + (int64_t)l * lo.total : nullptr;
+        const float* sv = saved + so.layers + (int64_t)l * so.per_layer;
+        const float* Xl = saved + so.X + (int64_t)l * TE;
+        const uint32_t site = SITE_LAYER0 + 4 * l;
+        EpiArgs none;
+        // LN2 backward: dx = dL/dX[l+1] -> dz (to x1), dy (to FFN output)
+        GF_TRY(launch_add_drop_ln_bwd(dx, sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz, dy, G ? G + lo.n2w : nullptr,
+                                      G ? G + lo.n2b : nullptr, T, E, c->p_enc, site + 3, rng, add, train, st));
+        // linear2 wgrad: gW2[E,F] += dy^T h ; gb2 += colsum(dy)
+        if (G) GF_TRY(launch_gemm_tn_acc(dy, E, sv + so.h, F, G + lo.w2, F, G + lo.b2, E, F, T, st));
+        // dh = (dy W2) * [h > 0] / (1-p)
+        EpiArgs em;
+        em.aux_in = sv + so.h;
+        em.mscale = (pdrop > 0.f) ? 1.0f / (1.0f - pdrop) : 1.0f;
+        GF_TRY(launch_gemm_nn(dy, E, P + lo.w2, F, dh, F, T, F, E, EPI_MASK_POS, em, st));
+        // linear1 wgrad: gW1[F,E] += dh^T x1 ; gb1 += colsum(dh)
+        if (G) GF_TRY(launch_gemm_tn_acc(dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T, st));
+        // d x1 = dh W1 + dz
+        GF_TRY(launch_gemm_nn(dh, F, P + lo.w1, E, tmp, E, T, E, F, EPI_NONE, none, st));
+        GF_TRY(launch_add_inplace(tmp, dz, TE, st));
+        // LN1 backward
+        GF_TRY(launch_add_drop_ln_bwd(tmp, sv + so.xhat1, sv + so.rstd1, P + lo.n1w, dz, dy, G ? G + lo.n1w : nullptr,
+                                      G ? G + lo.n1b : nullptr, T, E, c->p_enc, site + 1, rng, add, train, st));
+        // out-proj wgrad + dgrad
+        if (G) GF_TRY(launch_gemm_tn_acc(dy, E, sv + so.attn_o, E, G + lo.out_w, E, G + lo.out_b, E, E, T, st));
+        GF_TRY(launch_gemm_nn(dy, E, P + lo.out_w, E, d_attn, E, T, E, E, EPI_NONE, none, st));
+        // attention core backward
+        GF_TRY(launch_attention_bwd(sv + so.qkv, d_attn, d_qkv, S, B, E, H, c->p_enc, site + 0, rng, add, train, st));
+        // in-proj wgrad + dgrad; dX[l] = d_qkv W_in + dz
+        if (G) GF_TRY(launch_gemm_tn_acc(d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T, st));
+        GF_TRY(launch_gemm_nn(d_qkv, 3 * E, P + lo.in_w, E, dx, E, T, E, 3 * E, EPI_NONE, none, st));
+        GF_TRY(launch_add_inplace(dx, dz, TE, st));
+    }
+    if (layer_lo == 0) GF_TRY(launch_dropout_bwd_inplace(dx, T, E, c->p_pe, SITE_PE, rng, add, train, st));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// heads
+// saved layout: gen : t0 [T,E] | u1 [T,D1] | a1 [T,D1] | u2 [T,D2]
+//               disc: g0 [T,E] | u1 [T,D1] | a1 [T,D1] | u2 [T,D2] | a2 [T,D2] | prob [T4]
+// ------------------------------------------------------------------------------------------
+static int check_head(const ganffn_head_cfg* c) {
+    GF_CHECK_ARG(c, "null head cfg");
+    GF_CHECK_ARG(c->T >= 1 && c->E >= 4 && (c->E & 3) == 0, "head: bad T=%d E=%d", c->T, c->E);
+    GF_CHECK_ARG(c->D1 >= 4 && (c->D1 & 3) == 0 && c->D2 >= 4 && (c->D2 & 3) == 0, "head: D1=%d D2=%d must be multiples of 4", c->D1, c->D2);
+    GF_CHECK_ARG(c->kind == 0 || c->kind == 1, "head: kind=%d", c->kind);
+    GF_CHECK_ARG(c->kind == 0 || c->D2 <= 32, "disc head: D2=%d > 32", c->D2);
+    GF_CHECK_ARG(c->p >= 0.f && c->p < 1.f, "head: p out of [0,1)");
+    return 0;
+}
+extern "C" int64_t ganffn_head_saved_floats(const ganffn_head_cfg* c) {
+    if (check_head(c) != 0) return -1;
+    const int64_t T = c->T, T4 = (T + 3) & ~int64_t(3);
+    int64_t n = T * c->E + 2 * T * c->D1 + T * c->D2;
+    if (c->kind == 1) n += T * c->D2 + T4;
+    return n;
+}
+extern "C" int64_t ganffn_head_workspace_floats(const ganffn_head_cfg* c) {
+    if (check_head(c) != 0) return -1;
+    const int64_t T = c->T;
+    return T * c->D1 + T * c->D2 + T * c->E + 64;  // d_pre1 | d_pre2 | spare
+}
+
+extern "C" int ganffn_head_fwd(const ganffn_head_cfg* c, const float* x, const float* w1, const float* b1, const float* w2,
+                               const float* b2, const float* w3, const float* b3, float* out, float* saved, float* workspace,
+                               const uint64_t* rng, uint64_t add, void* stream) {
+    GF_TRY(check_head(c));
+    GF_CHECK_ARG(x && w1 && b1 && w2 && b2 && out && saved, "head_fwd: null pointer");
+    GF_CHECK_ARG(c->kind == 0 || (w3 && b3), "head_fwd: disc needs fc3");
+    GF_CHECK_ARG(!(c->train && c->p > 0.f) || rng, "head_fwd: rng required in train mode");
+    hipStream_t st = (hipStream_t)stream;
+    const int T = c->T, E = c->E, D1 = c->D1, D2 = c->D2, train = c->train;
+    float* s0 = saved;                      // t0 / g0
+    float* u1 = s0 + (int64_t)T * E;
+    float* a1 = u1 + (int64_t)T * D1;
+    float* u2 = a1 + (int64_t)T * D1;
+    EpiArgs e;
+    e.p = c->p; e.rng = rng; e.rng_add = add; e.train = train;
+    if (c->kind == 0) {
+        GF_TRY(launch_gelu_drop_fwd(x, s0, T, E, c->p, SITE_HEAD0, rng, add, train, st));
+        e.bias = b1; e.site = SITE_HEAD1; e.aux_out = u1;
+        GF_TRY(launch_gemm_nt(s0, E, w1, E, a1, D1, T, D1, E, EPI_DROP_GELU, e, st));
+        e.bias = b2; e.site = SITE_HEAD2; e.aux_out = u2;
+        GF_TRY(launch_gemm_nt(a1, D1, w2, D1, out, D2, T, D2, D1, EPI_DROP_GELU, e, st));
+    } else {
+        float* a2 = u2 + (int64_t)T * D2;
+        float* prob = a2 + (int64_t)T * D2;
+        GF_TRY(launch_gelu_drop_fwd(x, s0, T, E, 0.f, SITE_HEAD0, rng, add, 0, st));  // gelu only (model.py:1322)
+        e.bias = b1; e.site = SITE_HEAD1; e.aux_out = u1;
+        GF_TRY(launch_gemm_nt(s0, E, w1, E, a1, D1, T, D1, E, EPI_DROP_GELU, e, st));
+        e.bias = b2; e.site = SITE_HEAD2; e.aux_out = u2;
+        GF_TRY(launch_gemm_nt(a1, D1, w2, D1, a2, D2, T, D2, D1, EPI_DROP_GELU, e, st));
+        GF_TRY(launch_disc_tail_fwd(a2, w3, b3, prob, T, D2, c->p, rng, add, train, st));
+        hipError_t er = hipMemcpyAsync(out, prob, (size_t)T * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (er != hipSuccess) return fail((int)er, "head_fwd: memcpy failed");
+    }
+    (void)workspace;
+    return 0;
+}
+
+extern "C" int ganffn_head_bwd(const ganffn_head_cfg* c, const float* d_out, const float* x, const float* w1, const float* w2,
+                               const float* w3, float* gw1, float* gb1, float* gw2, float* gb2, float* gw3, float* gb3,
+                               float* dx, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
+                               void* stream) {
+    GF_TRY(check_head(c));
+    GF_CHECK_ARG(d_out && x && w1 && w2 && dx && saved && workspace, "head_bwd: null pointer");
+    GF_CHECK_ARG(c->kind == 0 || w3, "head_bwd: disc needs fc3");
+    GF_CHECK_ARG(!(c->train && c->p > 0.f) || rng, "head_bwd: rng required in train mode");
+    hipStream_t st = (hipStream_t)stream;
+    const int T = c->T, E = c->E, D1 = c->D1, D2 = c->D2, train = c->train;
+    const float* s0 = saved;
+    const float* u1 = s0 + (int64_t)T * E;
+    const float* a1 = u1 + (int64_t)T * D1;
+    const float* u2 = a1 + (int64_t)T * D1;
+    float* d_pre1 = workspace;                       // [T x D1]
+    float* d_pre2 = d_pre1 + (int64_t)T * D1;        // [T x D2]
+    if (c->kind == 0) {
+        // d_pre2 = d_out * gelu'(u2) * m2
+        GF_TRY(launch_gelu_bwd_drop(d_out, u2, d_pre2, T, D2, c->p, SITE_HEAD2, rng, add, train, st));
+    } else {
+        const float* a2 = u2 + (int64_t)T * D2;
+        const float* prob = a2 + (int64_t)T * D2;
+        GF_TRY(launch_disc_tail_bwd(d_out, prob, a2, u2, w3, d_pre2, gw3, gb3, T, D2, c->p, rng, add, train, st));
+    }
+    if (gw2) GF_TRY(launch_gemm_tn_acc(d_pre2, D2, a1, D1, gw2, D1, gb2, D2, D1, T, st));
+    EpiArgs e;
+    e.p = c->p; e.rng = rng; e.rng_add = add; e.train = train;
+    e.aux_in = u1; e.site = SITE_HEAD1;
+    GF_TRY(launch_gemm_nn(d_pre2, D2, w2, D1, d_pre1, D1, T, D1, D2, EPI_GELU_BWD_DROP, e, st));
+    if (gw1) GF_TRY(launch_gemm_tn_acc(d_pre1, D1, s0, E, gw1, E, gb1, D1, E, T, st));
+    e.aux_in = x;
+    if (c->kind == 0) {
+        e.site = SITE_HEAD0;
+        GF_TRY(launch_gemm_nn(d_pre1, D1, w1, E, dx, E, T, E, D1, EPI_GELU_BWD_DROP, e, st));
+    } else {
+        GF_TRY(launch_gemm_nn(d_pre1, D1, w1, E, dx, E, T, E, D1, EPI_GELU_BWD, e, st));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// plain linear
+// ------------------------------------------------------------------------------------------
+static bool mfma_ok(int K, int N) { return (K & 3) == 0 && (N & 3) == 0; }
+
+extern "C" int ganffn_linear_fwd(const float* x, const float* w, const float* b, float* y, int T, int K, int N, void* stream) {
+    GF_CHECK_ARG(x && w && y && T > 0 && K > 0 && N > 0, "linear_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if ((K & 3) == 0 && aligned16(x) && aligned16(w)) {
+        EpiArgs e;
+        e.bias = b;
+        return launch_gemm_nt(x, K, w, K, y, N, T, N, K, EPI_NONE, e, st);
+    }
+    return launch_small_linear_fwd(x, w, b, y, T, K, N, st);
+}
+
+extern "C" int ganffn_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* gw, float* gb, int T,
+                                 int K, int N, void* stream) {
+    GF_CHECK_ARG(dy && x && w && T > 0 && K > 0 && N > 0, "linear_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (mfma_ok(K, N) && aligned16(dy) && aligned16(x) && aligned16(w)) {
+        EpiArgs e;
+        if (dx) GF_TRY(launch_gemm_nn(dy, N, w, K, dx, K, T, K, N, EPI_NONE, e, st));
+        if (gw) GF_TRY(launch_gemm_tn_acc(dy, N, x, K, gw, K, gb, N, K, T, st));
+        return 0;
+    }
+    return launch_small_linear_bwd(dy, x, w, dx, gw, gb, T, K, N, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// building blocks for unit tests
+// ------------------------------------------------------------------------------------------
+extern "C" int ganffn_gemm_nt(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, void* stream) {
+    EpiArgs e;
+    e.bias = bias;
+    return launch_gemm_nt(A, K, W, K, C, N, M, N, K, EPI_NONE, e, (hipStream_t)stream);
+}
+extern "C" int ganffn_gemm_nn(const float* A, const float* Bm, float* C, int M, int N, int K, void* stream) {
+    EpiArgs e;
+    return launch_gemm_nn(A, K, Bm, N, C, N, M, N, K, EPI_NONE, e, (hipStream_t)stream);
+}
+extern "C" int ganffn_gemm_tn_acc(const float* At, const float* Bm, float* C, float* colsum, int M, int N, int K, void* stream) {
+    return launch_gemm_tn_acc(At, M, Bm, N, C, N, colsum, M, N, K, (hipStream_t)stream);
+}
+extern "C" int ganffn_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p, uint32_t site,
+                                    const uint64_t* rng, uint64_t add, void* stream) {
+    return launch_attention_fwd(qkv, o, S, B, E, H, p, site, rng, add, 1, (hipStream_t)stream);
+}
+extern "C" int ganffn_attention_bwd(const float* qkv, const float* d_o, float* d_qkv, int S, int B, int E, int H, float p,
+                                    uint32_t site, const uint64_t* rng, uint64_t add, void* stream) {
+    return launch_attention_bwd(qkv, d_o, d_qkv, S, B, E, H, p, site, rng, add, 1, (hipStream_t)stream);
+}

@@ -1,0 +1,203 @@
+// common.h — shared device/host helpers for libganffn (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/ganffn.h"
+
+namespace ganffn {
+
+// ---------------------------------------------------------------------------------------
+// error reporting (thread-local message, int return codes; no exceptions across the ABI)
+// ---------------------------------------------------------------------------------------
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+#define GF_CHECK_ARG(cond, ...)                         \
+    do {                                                \
+        if (!(cond)) return ::ganffn::fail(-1, __VA_ARGS__); \
+    } while (0)
+
+#define GF_LAUNCH_CHECK()                                                              \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess)                                                         \
+            return ::ganffn::fail((int)e__, "%s:%d launch failed: %s", __FILE__, __LINE__, \
+                                  hipGetErrorString(e__));                             \
+    } while (0)
+
+#define GF_TRY(expr)              \
+    do {                          \
+        int r__ = (expr);         \
+        if (r__ != 0) return r__; \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---------------------------------------------------------------------------------------
+// dropout sites (mirror of oracle/ganffn_oracle.py SITE_*)
+// ---------------------------------------------------------------------------------------
+enum : uint32_t {
+    SITE_PE = 0,
+    SITE_HEAD0 = 1,
+    SITE_HEAD1 = 2,
+    SITE_HEAD2 = 3,
+    SITE_HEAD3 = 4,
+    SITE_LAYER0 = 16,  // + 4*layer + {0 attn-prob, 1 post-attn, 2 ffn-mid, 3 post-ffn}
+};
+
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 (contract: oracle/philox.py)
+// ---------------------------------------------------------------------------------------
+struct DropCtx {
+    uint32_t k0, k1;   // seed lo/hi
+    uint32_t o0, o1;   // offset lo/hi
+    uint32_t site;
+    uint32_t thr;      // drop iff word < thr
+    float scale;       // 1/(1-p)
+    int on;
+};
+
+__host__ __device__ inline uint32_t drop_threshold(float p) {
+    if (p <= 0.f) return 0u;
+    double t = (double)p * 4294967296.0;
+    if (t >= 4294967295.0) return 0xFFFFFFFFu;
+    return (uint32_t)t;  // floor
+}
+
+__device__ __forceinline__ DropCtx make_drop(const uint64_t* rng, uint64_t add, uint32_t site, float p, int on) {
+    DropCtx d;
+    d.on = on && (p > 0.f);
+    d.site = site;
+    d.thr = drop_threshold(p);
+    d.scale = d.on ? 1.0f / (1.0f - p) : 1.0f;
+    uint64_t seed = 0, off = 0;
+    if (d.on) {
+        seed = rng[0];
+        off = rng[1] + add;
+    }
+    d.k0 = (uint32_t)seed;
+    d.k1 = (uint32_t)(seed >> 32);
+    d.o0 = (uint32_t)off;
+    d.o1 = (uint32_t)(off >> 32);
+    return d;
+}
+
+__device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                        uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// keep-multipliers (0 or 1/(1-p)) for the 4 consecutive rows 4*rg .. 4*rg+3 of column c in a [R x C] tensor
+__device__ __forceinline__ void drop_mult4(const DropCtx& d, uint32_t rowgroup, uint32_t C, uint32_t c, float (&m)[4]) {
+    if (!d.on) {
+        m[0] = m[1] = m[2] = m[3] = 1.f;
+        return;
+    }
+    uint32_t w[4];
+    philox4(rowgroup * C + c, d.site, d.o0, d.o1, d.k0, d.k1, w);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = (w[i] >= d.thr) ? d.scale : 0.f;
+}
+
+// single element (row r, col c) — used by row-wise kernels; 4x the Philox work of drop_mult4
+__device__ __forceinline__ float drop_mult1(const DropCtx& d, uint32_t r, uint32_t C, uint32_t c) {
+    if (!d.on) return 1.f;
+    uint32_t w[4];
+    philox4((r >> 2) * C + c, d.site, d.o0, d.o1, d.k0, d.k1, w);
+    const uint32_t x = (r & 3) == 0 ? w[0] : (r & 3) == 1 ? w[1] : (r & 3) == 2 ? w[2] : w[3];
+    return (x >= d.thr) ? d.scale : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------
+// math
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) {  // nn.GELU() exact (erf) form
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// internal launchers shared between translation units
+// ---------------------------------------------------------------------------------------
+enum Epilogue : int {
+    EPI_NONE = 0,          // C = acc (+bias)
+    EPI_RELU_DROP = 1,     // C = drop(relu(acc+bias))                       (FFN linear1)
+    EPI_DROP_GELU = 2,     // aux = drop(acc+bias); C = gelu(aux)            (head fc1/fc2)
+    EPI_MASK_POS = 3,      // C = acc * (aux > 0 ? mscale : 0)               (FFN dgrad through relu+dropout)
+    EPI_GELU_BWD_DROP = 4, // C = drop_bwd(acc) * gelu'(aux)  i.e. d(pre-dropout) of u=drop(v), a=gelu(u) chain
+    EPI_GELU_BWD = 5,      // C = acc * gelu'(aux)
+    EPI_GELU_BWD_DROP0 = 6 // C = acc * dropmult * gelu'(aux): aux = pre-gelu x, out=drop(gelu(x)) (gen head site 0)
+};
+
+struct EpiArgs {
+    const float* bias = nullptr;  // [N]
+    float* aux_out = nullptr;     // [M x N] (EPI_DROP_GELU)
+    const float* aux_in = nullptr;// [M x N]
+    float mscale = 1.f;           // EPI_MASK_POS
+    float p = 0.f;                // dropout prob
+    uint32_t site = 0;
+    const uint64_t* rng = nullptr;
+    uint64_t rng_add = 0;
+    int train = 0;
+};
+
+// C[MxN] = A[MxK] * W[NxK]^T (NT)
+int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                   int epi, const EpiArgs& ea, hipStream_t st);
+// C[MxN] = A[MxK] * B[KxN] (NN)
+int launch_gemm_nn(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
+                   int epi, const EpiArgs& ea, hipStream_t st);
+// C[MxN] += At[KxM]^T * B[KxN]  (TN, split-K, atomic accumulate); colsum[M] += sum_k At[k][m]
+int launch_gemm_tn_acc(const float* At, int lda, const float* Bm, int ldb, float* C, int ldc, float* colsum,
+                       int M, int N, int K, hipStream_t st);
+
+int launch_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p, uint32_t site,
+                         const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+int launch_attention_bwd(const float* qkv, const float* d_o, float* d_qkv, int S, int B, int E, int H, float p,
+                         uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+
+int launch_pe_dropout(const float* x, const float* pe, float* out, int S, int B, int E, float p,
+                      const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+int launch_dropout_bwd_inplace(float* dx, int R, int C, float p, uint32_t site, const uint64_t* rng, uint64_t add,
+                               int train, hipStream_t st);
+int launch_dropout(const float* x, float* out, int R, int C, float p, uint32_t site, const uint64_t* rng,
+                   uint64_t add, int train, hipStream_t st);
+int launch_add_drop_ln_fwd(const float* x, const float* y, const float* w, const float* b, float* out, float* xhat,
+                           float* rstd, int T, int E, float eps, float p, uint32_t site, const uint64_t* rng,
+                           uint64_t add, int train, hipStream_t st);
+int launch_add_drop_ln_bwd(const float* d_out, const float* xhat, const float* rstd, const float* w, float* dz,
+                           float* dy, float* gw, float* gb, int T, int E, float p, uint32_t site,
+                           const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+int launch_add_inplace(float* a, const float* b, int64_t n, hipStream_t st);
+int launch_gelu_drop_fwd(const float* x, float* out, int R, int C, float p, uint32_t site, const uint64_t* rng,
+                         uint64_t add, int train, hipStream_t st);
+
+}  // namespace ganffn

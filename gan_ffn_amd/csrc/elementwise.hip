@@ -1,0 +1,656 @@
+// elementwise.hip — HBM-bound row/elementwise kernels of the GAN-FFN step: PositionalEncoding add,
+// dropout, residual+dropout+LayerNorm (fwd/bwd), GELU chains, discriminator tail, BCE, Adam,
+// log-softmax + masked NLL.  All fp32.  Dropout follows the Philox contract (4 consecutive rows of one
+// column share one Philox call), so row-wise kernels process rows in groups of 4.
+#include "common.h"
+
+namespace ganffn {
+
+// ------------------------------------------------------------------------------------------
+// A1: out = dropout_p(x + pe[s])        /root/reference/model.py:1196-1197
+// one thread per (row group of 4, column)
+// ------------------------------------------------------------------------------------------
+__global__ void pe_dropout_kernel(const float* __restrict__ x, const float* __restrict__ pe, float* __restrict__ out,
+                                  int T, int B, int E, float p, const uint64_t* __restrict__ rng, uint64_t add,
+                                  int train) {
+    const int G = (T + 3) >> 2;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)G * E) return;
+    const int rg = (int)(idx / E), c = (int)(idx - (long)rg * E);
+    const DropCtx dc = make_drop(rng, add, SITE_PE, p, train);
+    float mult[4];
+    drop_mult4(dc, (uint32_t)rg, (uint32_t)E, (uint32_t)c, mult);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int t = rg * 4 + q;
+        if (t < T) {
+            const int s = t / B;
+            out[(size_t)t * E + c] = (x[(size_t)t * E + c] + pe[(size_t)s * E + c]) * mult[q];
+        }
+    }
+}
+
+// generic: out = f(x) * mult, f = identity (MODE 0) or gelu (MODE 1);  MODE 2: out = d * gelu'(u) * mult
+template <int MODE>
+__global__ void drop_kernel(const float* __restrict__ x, const float* __restrict__ u, float* __restrict__ out, int R,
+                            int C, float p, uint32_t site, const uint64_t* __restrict__ rng, uint64_t add, int train) {
+    const int G = (R + 3) >> 2;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)G * C) return;
+    const int rg = (int)(idx / C), c = (int)(idx - (long)rg * C);
+    const DropCtx dc = make_drop(rng, add, site, p, train);
+    float mult[4];
+    drop_mult4(dc, (uint32_t)rg, (uint32_t)C, (uint32_t)c, mult);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int t = rg * 4 + q;
+        if (t < R) {
+            const size_t o = (size_t)t * C + c;
+            float v = x[o];
+            if (MODE == 1) v = gelu_f(v);
+            if (MODE == 2) v = v * gelu_grad_f(u[o]);
+            out[o] = v * mult[q];
+        }
+    }
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 x = reinterpret_cast<float4*>(a)[i];
+    const float4 y = reinterpret_cast<const float4*>(b)[i];
+    x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+    reinterpret_cast<float4*>(a)[i] = x;
+}
+
+__global__ void add3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                            float* __restrict__ o, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] + b[i] + c[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// z = x + dropout(y); xhat = (z - mean) * rstd; out = xhat * w + b        (norm1 / norm2, post-LN)
+// one wave per group of 4 rows; lane covers columns lane, lane+64, ...  (E <= 64*MAXC)
+// ------------------------------------------------------------------------------------------
+constexpr int LN_MAXC = 8;  // E <= 512
+
+__global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ w, const float* __restrict__ b,
+                                                              float* __restrict__ out, float* __restrict__ xhat,
+                                                              float* __restrict__ rstd, int T, int E, float eps, float p,
+                                                              uint32_t site, const uint64_t* __restrict__ rng,
+                                                              uint64_t add, int train) {
+    const int lane = threadIdx.x & 63;
+    const int rg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rg * 4 >= T) return;
+    const DropCtx dc = make_drop(rng, add, site, p, train);
+    float z[LN_MAXC][4];
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) {
+        const int c = lane + 64 * k;
+        if (c < E) {
+            float mult[4];
+            drop_mult4(dc, (uint32_t)rg, (uint32_t)E, (uint32_t)c, mult);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = rg * 4 + q;
+                float v = 0.f;
+                if (t < T) v = x[(size_t)t * E + c] + y[(size_t)t * E + c] * mult[q];
+                z[k][q] = v;
+                sum[q] += v;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z[k][q] = 0.f;
+        }
+    }
+    const float invE = 1.0f / (float)E;
+    float mean[4], rs[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mean[q] = wave_sum(sum[q]) * invE;
+    float var[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) {
+        const int c = lane + 64 * k;
+        if (c < E) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float d = z[k][q] - mean[q];
+                var[q] += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rs[q] = rsqrtf(wave_sum(var[q]) * invE + eps);
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) {
+        const int c = lane + 64 * k;
+        if (c < E) {
+            const float ww = w[c], bb = b[c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = rg * 4 + q;
+                if (t < T) {
+                    const float xh = (z[k][q] - mean[q]) * rs[q];
+                    if (xhat) xhat[(size_t)t * E + c] = xh;
+                    out[(size_t)t * E + c] = xh * ww + bb;
+                }
+            }
+        }
+    }
+    if (rstd && lane < 4 && rg * 4 + lane < T) rstd[rg * 4 + lane] = rs[lane];
+}
+
+// backward: g = d_out * w; dz = rstd * (g - mean(g) - xhat * mean(g * xhat)); dy = dz * dropmult
+// gw += sum_t d_out * xhat, gb += sum_t d_out   (per-block partial sums in registers -> LDS -> atomics)
+__global__ __launch_bounds__(256) void add_drop_ln_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ xhat,
+                                                              const float* __restrict__ rstd, const float* __restrict__ w,
+                                                              float* __restrict__ dz, float* __restrict__ dy,
+                                                              float* __restrict__ gw, float* __restrict__ gb, int T, int E,
+                                                              float p, uint32_t site, const uint64_t* __restrict__ rng,
+                                                              uint64_t add, int train) {
+    __shared__ float red[2][4][64 * LN_MAXC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const DropCtx dc = make_drop(rng, add, site, p, train);
+    const int G = (T + 3) >> 2;
+    const float invE = 1.0f / (float)E;
+    float aw[LN_MAXC], ab[LN_MAXC], wreg[LN_MAXC];
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) {
+        aw[k] = 0.f; ab[k] = 0.f;
+        const int c = lane + 64 * k;
+        wreg[k] = (c < E) ? w[c] : 0.f;
+    }
+    for (int rg = blockIdx.x * 4 + wv; rg < G; rg += gridDim.x * 4) {
+        float g[LN_MAXC][4], xh[LN_MAXC][4];
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < LN_MAXC; ++k) {
+            const int c = lane + 64 * k;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = rg * 4 + q;
+                float d = 0.f, h = 0.f;
+                if (c < E && t < T) {
+                    d = d_out[(size_t)t * E + c];
+                    h = xhat[(size_t)t * E + c];
+                }
+                aw[k] += d * h;
+                ab[k] += d;
+                g[k][q] = d * wreg[k];
+                xh[k][q] = h;
+                s1[q] += g[k][q];
+                s2[q] += g[k][q] * h;
+            }
+        }
+        float c1[4], c2[4], rs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            c1[q] = wave_sum(s1[q]) * invE;
+            c2[q] = wave_sum(s2[q]) * invE;
+            const int t = rg * 4 + q;
+            rs[q] = (t < T) ? rstd[t] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < LN_MAXC; ++k) {
+            const int c = lane + 64 * k;
+            if (c < E) {
+                float mult[4] = {1.f, 1.f, 1.f, 1.f};
+                if (dy) drop_mult4(dc, (uint32_t)rg, (uint32_t)E, (uint32_t)c, mult);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int t = rg * 4 + q;
+                    if (t < T) {
+                        const float v = rs[q] * (g[k][q] - c1[q] - xh[k][q] * c2[q]);
+                        dz[(size_t)t * E + c] = v;
+                        if (dy) dy[(size_t)t * E + c] = v * mult[q];
+                    }
+                }
+            }
+        }
+    }
+    if (gw == nullptr) return;
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) {
+        red[0][wv][lane + 64 * k] = aw[k];
+        red[1][wv][lane + 64 * k] = ab[k];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < E; c += 256) {
+        const float sw = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        atomicAdd(gw + c, sw);
+        atomicAdd(gb + c, sb);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// discriminator tail: u3 = drop(a2 . w3 + b3); prob = sigmoid(u3)      model.py:1326
+// and its backward fused with the fc2 activation backward:
+//   d_u3 = dprob * prob*(1-prob); d_pre3 = d_u3 * m3; d_a2 = d_pre3 * w3; d_pre2 = d_a2 * gelu'(u2) * m2
+// one thread per token; D2 <= 32
+// ------------------------------------------------------------------------------------------
+__global__ void disc_tail_fwd_kernel(const float* __restrict__ a2, const float* __restrict__ w3, const float* __restrict__ b3,
+                                     float* __restrict__ prob, int T, int D2, float p, const uint64_t* __restrict__ rng,
+                                     uint64_t add, int train) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const DropCtx dc = make_drop(rng, add, SITE_HEAD3, p, train);
+    float acc = b3[0];
+    for (int k = 0; k < D2; ++k) acc += a2[(size_t)t * D2 + k] * w3[k];
+    acc *= drop_mult1(dc, (uint32_t)t, 1u, 0u);
+    prob[t] = 1.0f / (1.0f + expf(-acc));
+}
+
+__global__ __launch_bounds__(256) void disc_tail_bwd_kernel(const float* __restrict__ dprob, const float* __restrict__ prob,
+                                                            const float* __restrict__ a2, const float* __restrict__ u2,
+                                                            const float* __restrict__ w3, float* __restrict__ d_pre2,
+                                                            float* __restrict__ gw3, float* __restrict__ gb3, int T, int D2,
+                                                            float p, const uint64_t* __restrict__ rng, uint64_t add,
+                                                            int train) {
+    __shared__ float red[4][33];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const DropCtx d3 = make_drop(rng, add, SITE_HEAD3, p, train);
+    const DropCtx d2 = make_drop(rng, add, SITE_HEAD2, p, train);
+    float dpre3 = 0.f;
+    if (t < T) {
+        const float pr = prob[t];
+        dpre3 = dprob[t] * pr * (1.0f - pr) * drop_mult1(d3, (uint32_t)t, 1u, 0u);
+    }
+    for (int k = 0; k < D2; ++k) {
+        float a = 0.f;
+        if (t < T) {
+            const size_t o = (size_t)t * D2 + k;
+            a = a2[o];
+            d_pre2[o] = dpre3 * w3[k] * gelu_grad_f(u2[o]) * drop_mult1(d2, (uint32_t)t, (uint32_t)D2, (uint32_t)k);
+        }
+        if (gw3) {
+            const float s = wave_sum(dpre3 * a);
+            if (lane == 0) red[wv][k] = s;
+        }
+    }
+    if (gw3) {
+        const float s = wave_sum(dpre3);
+        if (lane == 0) red[wv][32] = s;
+        __syncthreads();
+        if (threadIdx.x < D2) atomicAdd(gw3 + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (threadIdx.x == 32) atomicAdd(gb3, red[0][32] + red[1][32] + red[2][32] + red[3][32]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// A10: BCELoss(mean)     torch.nn.BCELoss semantics (log clamped at -100)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ prob, float target, int n, float scale,
+                                                      float* __restrict__ loss) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float p = prob[i];
+        const float lp = fmaxf(logf(p), -100.f);
+        const float l1p = fmaxf(logf(1.0f - p), -100.f);
+        s -= target * lp + (1.0f - target) * l1p;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * scale / (float)n);
+}
+
+__global__ void bce_bwd_kernel(const float* __restrict__ prob, float target, int n, float scale, float* __restrict__ dprob) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float p = prob[i];
+    dprob[i] = scale / (float)n * (p - target) / fmaxf(p * (1.0f - p), 1e-12f);
+}
+
+// ------------------------------------------------------------------------------------------
+// A10: Adam, flat slab.  t = *step + 1 (the counter is bumped by adam_step_inc afterwards)
+// ------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            const int32_t* __restrict__ step, long n, float lr, float b1, float b2, float eps, float wd,
+                            float gscale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float t = (float)(*step + 1);
+    const float bc1 = 1.0f - powf(b1, t);
+    const float bc2 = 1.0f - powf(b2, t);
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+}
+__global__ void adam_step_inc(int32_t* step) { *step += 1; }
+
+__global__ void rng_advance_kernel(uint64_t* rng, uint64_t delta) { rng[1] += delta; }
+
+// ------------------------------------------------------------------------------------------
+// A1: PE table, fp32 exactly as the reference computes it (model.py:1182-1188):
+//   div[i] = exp((2i) * (-ln(1e4)/E)) in fp32;  pe[p, 2i] = sin(p*div[i]); pe[p, 2i+1] = cos(p*div[i])
+// ------------------------------------------------------------------------------------------
+__global__ void pe_table_kernel(float* __restrict__ pe, int max_len, int E) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= max_len * (E / 2)) return;
+    const int pos = idx / (E / 2), i = idx % (E / 2);
+    const float c = (float)(-9.210340371976184 / (double)E);  // -ln(1e4)/E rounded to fp32 like python float -> tensor mul
+    const float div = expf((float)(2 * i) * c);
+    const float a = (float)pos * div;
+    pe[(size_t)pos * E + 2 * i] = sinf(a);
+    pe[(size_t)pos * E + 2 * i + 1] = cosf(a);
+}
+
+// ------------------------------------------------------------------------------------------
+// A11: log_softmax over C classes + masked weighted NLL   (model.py:1448-1449, :74-81)
+// acc2[0] += sum w[y] m lp[y] ; acc2[1] += sum w[y] m   then a finishing kernel divides
+// ------------------------------------------------------------------------------------------
+__global__ void logsoftmax_nll_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                      const float* __restrict__ umask, const float* __restrict__ cw,
+                                      float* __restrict__ logp, float* __restrict__ acc2, int S, int B, int C) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;  // token t = s*B + b
+    float num = 0.f, den = 0.f;
+    if (t < S * B) {
+        const int s = t / B, b = t - s * B;
+        const float* x = logits + (size_t)t * C;
+        float m = x[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) sum += expf(x[c] - m);
+        const float lse = m + logf(sum);
+        for (int c = 0; c < C; ++c) logp[(size_t)t * C + c] = x[c] - lse;
+        if (labels) {
+            const int y = (int)labels[(size_t)b * S + s];
+            const float mk = umask[(size_t)b * S + s];
+            const float wy = cw ? cw[y] : 1.f;
+            num = wy * mk * (x[y] - lse);
+            den = wy * mk;
+        }
+    }
+    if (labels) {
+        num = wave_sum(num);
+        den = wave_sum(den);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(acc2, num);
+            atomicAdd(acc2 + 1, den);
+        }
+    }
+}
+__global__ void nll_finish_kernel(const float* __restrict__ acc2, float* __restrict__ loss) { loss[0] = -acc2[0] / acc2[1]; }
+// dlogits[t,c] = -(w[y] m / den) * (1[c==y] - softmax[t,c])
+__global__ void nll_bwd_kernel(const float* __restrict__ logp, const int64_t* __restrict__ labels,
+                               const float* __restrict__ umask, const float* __restrict__ cw, const float* __restrict__ acc2,
+                               float* __restrict__ dlogits, int S, int B, int C) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S * B) return;
+    const int s = t / B, b = t - s * B;
+    const int y = (int)labels[(size_t)b * S + s];
+    const float coef = (cw ? cw[y] : 1.f) * umask[(size_t)b * S + s] / acc2[1];
+    for (int c = 0; c < C; ++c) {
+        const float sm = expf(logp[(size_t)t * C + c]);
+        dlogits[(size_t)t * C + c] = -coef * ((c == y ? 1.f : 0.f) - sm);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// naive linear for shapes the MFMA GEMM does not take (N or K not a multiple of 4: fc 100->6)
+// ------------------------------------------------------------------------------------------
+__global__ void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                        float* __restrict__ y, int T, int K, int N) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)T * N) return;
+    const int t = (int)(idx / N), n = (int)(idx - (long)t * N);
+    float acc = b ? b[n] : 0.f;
+    for (int k = 0; k < K; ++k) acc += x[(size_t)t * K + k] * w[(size_t)n * K + k];
+    y[idx] = acc;
+}
+__global__ void small_linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                       int T, int K, int N) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)T * K) return;
+    const int t = (int)(idx / K), k = (int)(idx - (long)t * K);
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc += dy[(size_t)t * N + n] * w[(size_t)n * K + k];
+    dx[idx] = acc;
+}
+// gw[n,k] += sum_t dy[t,n] x[t,k]; gb[n] += sum_t dy[t,n]; one block per n, threads over k, loop over t
+__global__ void small_linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ gw,
+                                       float* __restrict__ gb, int T, int K, int N) {
+    const int n = blockIdx.x;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) acc += dy[(size_t)t * N + n] * x[(size_t)t * K + k];
+        gw[(size_t)n * K + k] += acc;
+    }
+    if (gb && threadIdx.x == 0) {
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) acc += dy[(size_t)t * N + n];
+        gb[n] += acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static inline int nblk(long n, int bs) { return (int)((n + bs - 1) / bs); }
+
+int launch_pe_dropout(const float* x, const float* pe, float* out, int S, int B, int E, float p,
+                      const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
+    const int T = S * B;
+    const long n = (long)((T + 3) / 4) * E;
+    hipLaunchKernelGGL(pe_dropout_kernel, dim3(nblk(n, 256)), dim3(256), 0, st, x, pe, out, T, B, E, p, rng, add, train);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_dropout(const float* x, float* out, int R, int C, float p, uint32_t site, const uint64_t* rng,
+                   uint64_t add, int train, hipStream_t st) {
+    const long n = (long)((R + 3) / 4) * C;
+    hipLaunchKernelGGL(drop_kernel<0>, dim3(nblk(n, 256)), dim3(256), 0, st, x, (const float*)nullptr, out, R, C, p, site, rng, add, train);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+int launch_dropout_bwd_inplace(float* dx, int R, int C, float p, uint32_t site, const uint64_t* rng, uint64_t add,
+                               int train, hipStream_t st) {
+    if (!(train && p > 0.f)) return 0;
+    return launch_dropout(dx, dx, R, C, p, site, rng, add, train, st);
+}
+int launch_gelu_drop_fwd(const float* x, float* out, int R, int C, float p, uint32_t site, const uint64_t* rng,
+                         uint64_t add, int train, hipStream_t st) {
+    const long n = (long)((R + 3) / 4) * C;
+    hipLaunchKernelGGL(drop_kernel<1>, dim3(nblk(n, 256)), dim3(256), 0, st, x, (const float*)nullptr, out, R, C, p, site, rng, add, train);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+int launch_gelu_bwd_drop(const float* d, const float* u, float* out, int R, int C, float p, uint32_t site,
+                         const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
+    const long n = (long)((R + 3) / 4) * C;
+    hipLaunchKernelGGL(drop_kernel<2>, dim3(nblk(n, 256)), dim3(256), 0, st, d, u, out, R, C, p, site, rng, add, train);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_add_inplace(float* a, const float* b, int64_t n, hipStream_t st) {
+    GF_CHECK_ARG((n & 3) == 0 && aligned16(a) && aligned16(b), "add_inplace: n %% 4 and 16-byte alignment required");
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(nblk(n / 4, 256)), dim3(256), 0, st, a, b, (long)(n / 4));
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_add_drop_ln_fwd(const float* x, const float* y, const float* w, const float* b, float* out, float* xhat,
+                           float* rstd, int T, int E, float eps, float p, uint32_t site, const uint64_t* rng,
+                           uint64_t add, int train, hipStream_t st) {
+    GF_CHECK_ARG(E <= 64 * LN_MAXC, "layernorm: E=%d > %d", E, 64 * LN_MAXC);
+    const int G = (T + 3) / 4;
+    hipLaunchKernelGGL(add_drop_ln_fwd_kernel, dim3((G + 3) / 4), dim3(256), 0, st, x, y, w, b, out, xhat, rstd, T, E, eps, p,
+                       site, rng, add, train);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_add_drop_ln_bwd(const float* d_out, const float* xhat, const float* rstd, const float* w, float* dz,
+                           float* dy, float* gw, float* gb, int T, int E, float p, uint32_t site,
+                           const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
+    GF_CHECK_ARG(E <= 64 * LN_MAXC, "layernorm: E=%d > %d", E, 64 * LN_MAXC);
+    const int G = (T + 3) / 4;
+    int blocks = (G + 3) / 4;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(add_drop_ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, d_out, xhat, rstd, w, dz, dy, gw, gb, T, E, p,
+                       site, rng, add, train);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_disc_tail_fwd(const float* a2, const float* w3, const float* b3, float* prob, int T, int D2, float p,
+                         const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
+    hipLaunchKernelGGL(disc_tail_fwd_kernel, dim3(nblk(T, 256)), dim3(256), 0, st, a2, w3, b3, prob, T, D2, p, rng, add, train);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+int launch_disc_tail_bwd(const float* dprob, const float* prob, const float* a2, const float* u2, const float* w3,
+                         float* d_pre2, float* gw3, float* gb3, int T, int D2, float p, const uint64_t* rng, uint64_t add,
+                         int train, hipStream_t st) {
+    GF_CHECK_ARG(D2 <= 32, "disc tail: D2=%d > 32", D2);
+    hipLaunchKernelGGL(disc_tail_bwd_kernel, dim3(nblk(T, 256)), dim3(256), 0, st, dprob, prob, a2, u2, w3, d_pre2, gw3, gb3, T,
+                       D2, p, rng, add, train);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int T, int K, int N, hipStream_t st) {
+    hipLaunchKernelGGL(small_linear_fwd_kernel, dim3(nblk((long)T * N, 256)), dim3(256), 0, st, x, w, b, y, T, K, N);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+int launch_small_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* gw, float* gb, int T, int K,
+                            int N, hipStream_t st) {
+    if (dx) {
+        hipLaunchKernelGGL(small_linear_dx_kernel, dim3(nblk((long)T * K, 256)), dim3(256), 0, st, dy, w, dx, T, K, N);
+        GF_LAUNCH_CHECK();
+    }
+    if (gw) {
+        hipLaunchKernelGGL(small_linear_dw_kernel, dim3(N), dim3(128), 0, st, dy, x, gw, gb, T, K, N);
+        GF_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace ganffn
+
+// ==========================================================================================
+// C ABI entry points that are pure elementwise work
+// ==========================================================================================
+using namespace ganffn;
+
+extern "C" int ganffn_rng_advance(uint64_t* rng, uint64_t delta, void* stream) {
+    GF_CHECK_ARG(rng, "rng_advance: null rng");
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng, delta);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ganffn_pe_table(float* pe, int max_len, int E, void* stream) {
+    GF_CHECK_ARG(pe && max_len > 0 && E > 0 && (E & 1) == 0, "pe_table: E must be even (model.py:1187-1188)");
+    const int n = max_len * (E / 2);
+    hipLaunchKernelGGL(pe_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pe, max_len, E);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ganffn_bce_fwd(const float* prob, float target, int n, float scale, float* loss_out, int accumulate,
+                              void* stream) {
+    GF_CHECK_ARG(prob && loss_out && n > 0, "bce_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(loss_out, 0, sizeof(float), st);
+        if (e != hipSuccess) return fail((int)e, "bce_fwd: memset failed: %s", hipGetErrorString(e));
+    }
+    int blocks = (n + 255) / 256;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(blocks), dim3(256), 0, st, prob, target, n, scale, loss_out);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ganffn_bce_bwd(const float* prob, float target, int n, float scale, float* dprob, void* stream) {
+    GF_CHECK_ARG(prob && dprob && n > 0, "bce_bwd: bad arguments");
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, prob, target, n, scale, dprob);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ganffn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t* step,
+                                int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                float grad_scale, void* stream) {
+    GF_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && step && n > 0, "adam_step: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq,
+                       (const int32_t*)step, (long)n, lr, beta1, beta2, eps, weight_decay, grad_scale);
+    GF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(adam_step_inc, dim3(1), dim3(1), 0, st, step);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ganffn_add3(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream) {
+    GF_CHECK_ARG(a && b && c && out && n > 0, "add3: bad arguments");
+    hipLaunchKernelGGL(add3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, out, (long)n);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ganffn_logsoftmax_nll(const float* logits, const int64_t* labels, const float* umask, const float* class_w,
+                                     float* log_prob, float* loss_out, float* dlogits, float* workspace2, int S, int B, int C,
+                                     void* stream) {
+    GF_CHECK_ARG(logits && log_prob && S > 0 && B > 0 && C > 0, "logsoftmax_nll: bad arguments");
+    GF_CHECK_ARG(!labels || (umask && loss_out && workspace2), "logsoftmax_nll: labels need umask, loss_out, workspace2");
+    hipStream_t st = (hipStream_t)stream;
+    const int T = S * B;
+    if (labels) {
+        hipError_t e = hipMemsetAsync(workspace2, 0, 2 * sizeof(float), st);
+        if (e != hipSuccess) return fail((int)e, "logsoftmax_nll: memset failed");
+    }
+    hipLaunchKernelGGL(logsoftmax_nll_kernel, dim3((T + 255) / 256), dim3(256), 0, st, logits, labels, umask, class_w, log_prob,
+                       workspace2, S, B, C);
+    GF_LAUNCH_CHECK();
+    if (labels) {
+        hipLaunchKernelGGL(nll_finish_kernel, dim3(1), dim3(1), 0, st, (const float*)workspace2, loss_out);
+        GF_LAUNCH_CHECK();
+        if (dlogits) {
+            hipLaunchKernelGGL(nll_bwd_kernel, dim3((T + 255) / 256), dim3(256), 0, st, (const float*)log_prob, labels, umask,
+                               class_w, (const float*)workspace2, dlogits, S, B, C);
+            GF_LAUNCH_CHECK();
+        }
+    }
+    return 0;
+}
+
+extern "C" int ganffn_dropout(const float* x, float* out, int R, int C, float p, uint32_t site, const uint64_t* rng,
+                              uint64_t rng_offset_add, void* stream) {
+    GF_CHECK_ARG(x && out && R > 0 && C > 0, "dropout: bad arguments");
+    GF_CHECK_ARG(p <= 0.f || rng, "dropout: rng required");
+    return launch_dropout(x, out, R, C, p, site, rng, rng_offset_add, 1, (hipStream_t)stream);
+}
+
+extern "C" int ganffn_add_dropout_layernorm_fwd(const float* x, const float* y, const float* w, const float* b, float* out,
+                                                float* xhat, float* rstd, int T, int E, float eps, float p, uint32_t site,
+                                                const uint64_t* rng, uint64_t rng_offset_add, void* stream) {
+    GF_CHECK_ARG(x && y && w && b && out && T > 0 && E > 0, "add_dropout_layernorm_fwd: bad arguments");
+    GF_CHECK_ARG(p <= 0.f || rng, "add_dropout_layernorm_fwd: rng required");
+    return launch_add_drop_ln_fwd(x, y, w, b, out, xhat, rstd, T, E, eps, p, site, rng, rng_offset_add, 1, (hipStream_t)stream);
+}
+
+extern "C" int ganffn_add_dropout_layernorm_bwd(const float* d_out, const float* xhat, const float* rstd, const float* w,
+                                                float* dz, float* dy, float* gw, float* gb, int T, int E, float p,
+                                                uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, void* stream) {
+    GF_CHECK_ARG(d_out && xhat && rstd && w && dz && T > 0 && E > 0, "add_dropout_layernorm_bwd: bad arguments");
+    GF_CHECK_ARG(p <= 0.f || rng, "add_dropout_layernorm_bwd: rng required");
+    return launch_add_drop_ln_bwd(d_out, xhat, rstd, w, dz, dy, gw, gb, T, E, p, site, rng, rng_offset_add, 1,
+                                  (hipStream_t)stream);
+}

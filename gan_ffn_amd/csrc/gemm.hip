@@ -1,0 +1,337 @@
+// gemm.hip — fp32 MFMA GEMMs for gfx950 (v_mfma_f32_32x32x2_f32), LDS-tiled, with fused epilogues.
+//
+// Three operand forms cover forward, dgrad and wgrad of every nn.Linear on the hot path
+// (torch nn.Linear / MultiheadAttention in/out-proj / TransformerEncoderLayer linear1/2, call sites
+// /root/reference/model.py:1210-1216,1244-1249,1307-1313):
+//   NT  C[MxN]  = A[MxK] * W[NxK]^T          forward  (A, W both K-contiguous)
+//   NN  C[MxN]  = A[MxK] * B[KxN]            dgrad    (B N-contiguous)
+//   TN  C[MxN] += At[KxM]^T * B[KxN]         wgrad    (both K-major), split-K + fp32 atomics
+//
+// Numerics: v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain in k order (no reduced precision).
+//
+// Tiling: 256 threads = 4 waves (2 x 2); block tile BM x BN in {64, 128}^2, BK = 16; each wave owns
+// (BM/2) x (BN/2) = TM x TN tiles of 32x32 (16 accumulator VGPRs each).  LDS images:
+//   K-contiguous operand: [rows][20] floats — row stride 20 (= 4 * odd) makes the ds_read_b128
+//     fragment reads (lane (r,h) -> row r, k = kk + 4h .. 4h+3) bank-conflict-free;
+//   K-major operand:      [16][cols + 4] — lanes read consecutive columns with ds_read_b32.
+// The k index inside an 8-wide group is permuted identically for A and B (MFMA j of the group takes
+// k = kk + 4h + j on lane half h), which is all an MFMA needs.
+// Global->LDS staging is register-staged and double-buffered: the loads of tile t+1 are issued before
+// the MFMAs of tile t and written to the other LDS buffer after them; one barrier per K tile.
+#include "common.h"
+
+namespace ganffn {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+constexpr int LDK = 20;  // K-contiguous LDS row stride (floats)
+
+enum { MODE_NT = 0, MODE_NN = 1, MODE_TN = 2 };
+
+struct GemmArgs {
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    float* colsum;
+    int M, N, K;
+    int kchunk;  // TN split-K chunk (multiple of BK); others: K
+    EpiArgs ea;
+};
+
+template <int ROWS>  // K-contiguous operand tile: ROWS x 16 floats -> regs (ROWS*4/256 float4 per thread)
+struct KcTile {
+    static constexpr int NV = ROWS * 4 / 256;
+    float4 v[NV];
+    __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int kend, int tid) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * 256;
+            const int row = i >> 2, kc = (i & 3) << 2;
+            const int gr = row0 + row, gk = k0 + kc;
+            if (gr < nrows && gk < kend)
+                v[j] = *reinterpret_cast<const float4*>(P + (size_t)gr * ld + gk);
+            else
+                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * 256;
+            const int row = i >> 2, kc = (i & 3) << 2;
+            *reinterpret_cast<float4*>(S + row * LDK + kc) = v[j];
+        }
+    }
+};
+
+template <int COLS>  // K-major operand tile: 16 x COLS floats
+struct KmTile {
+    static constexpr int NV = COLS * 4 / 256;
+    static constexpr int LD = COLS + 4;
+    float4 v[NV];
+    __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int col0, int ncols, int k0, int kend, int tid) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * 256;
+            const int kr = i / (COLS / 4), c4 = (i % (COLS / 4)) << 2;
+            const int gk = k0 + kr, gc = col0 + c4;
+            if (gk < kend && gc < ncols)
+                v[j] = *reinterpret_cast<const float4*>(P + (size_t)gk * ld + gc);
+            else
+                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * 256;
+            const int kr = i / (COLS / 4), c4 = (i % (COLS / 4)) << 2;
+            *reinterpret_cast<float4*>(S + kr * LD + c4) = v[j];
+        }
+    }
+};
+
+template <int MODE, int BM, int BN>
+struct Smem {
+    static constexpr int A_FLOATS = (MODE == MODE_TN) ? BK * (BM + 4) : BM * LDK;
+    static constexpr int B_FLOATS = (MODE == MODE_NT) ? BN * LDK : BK * (BN + 4);
+    static constexpr int STAGE = A_FLOATS + B_FLOATS;
+    static constexpr int TOTAL = 2 * STAGE;
+};
+
+template <int MODE, int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
+    constexpr int TM = WM / 32, TN = WN / 32;
+    using SM = Smem<MODE, BM, BN>;
+    __shared__ __attribute__((aligned(16))) float smem[SM::TOTAL];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = (MODE == MODE_TN) ? blockIdx.z * g.kchunk : 0;
+    const int kend = (MODE == MODE_TN) ? min(g.K, kbeg + g.kchunk) : g.K;
+    const int nt = (kend - kbeg + BK - 1) / BK;
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    KcTile<BM> ta_kc;
+    KmTile<BM> ta_km;
+    KcTile<BN> tb_kc;
+    KmTile<BN> tb_km;
+
+    auto gload = [&](int t) {
+        const int k0 = kbeg + t * BK;
+        if (MODE == MODE_TN) ta_km.load(g.A, g.lda, m0, g.M, k0, kend, tid);
+        else ta_kc.load(g.A, g.lda, m0, g.M, k0, kend, tid);
+        if (MODE == MODE_NT) tb_kc.load(g.B, g.ldb, n0, g.N, k0, kend, tid);
+        else tb_km.load(g.B, g.ldb, n0, g.N, k0, kend, tid);
+    };
+    auto sstore = [&](int buf) {
+        float* sa = smem + buf * SM::STAGE;
+        float* sb = sa + SM::A_FLOATS;
+        if (MODE == MODE_TN) ta_km.store(sa, tid); else ta_kc.store(sa, tid);
+        if (MODE == MODE_NT) tb_kc.store(sb, tid); else tb_km.store(sb, tid);
+    };
+
+    float colsum_acc = 0.f;  // TN: thread tid < BM sums column (m0+tid) of At over k
+
+    if (nt > 0) {
+        gload(0);
+        sstore(0);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) gload(t + 1);
+        const float* sa = smem + buf * SM::STAGE;
+        const float* sb = sa + SM::A_FLOATS;
+        const int kvalid = min(BK, kend - (kbeg + t * BK));
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 8) {
+            if (kk < kvalid) {
+                float af[TM][4], bf[TN][4];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    if (MODE == MODE_TN) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) af[a][j] = sa[(kk + 4 * h + j) * (BM + 4) + wm * WM + a * 32 + r];
+                    } else {
+                        const float4 q = *reinterpret_cast<const float4*>(sa + (wm * WM + a * 32 + r) * LDK + kk + 4 * h);
+                        af[a][0] = q.x; af[a][1] = q.y; af[a][2] = q.z; af[a][3] = q.w;
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    if (MODE == MODE_NT) {
+                        const float4 q = *reinterpret_cast<const float4*>(sb + (wn * WN + b * 32 + r) * LDK + kk + 4 * h);
+                        bf[b][0] = q.x; bf[b][1] = q.y; bf[b][2] = q.z; bf[b][3] = q.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bf[b][j] = sb[(kk + 4 * h + j) * (BN + 4) + wn * WN + b * 32 + r];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (MODE == MODE_TN) {
+            if (g.colsum != nullptr && blockIdx.x == 0 && tid < BM) {
+#pragma unroll
+                for (int k = 0; k < BK; ++k) colsum_acc += sa[k * (BM + 4) + tid];  // zero-filled beyond kend
+            }
+        }
+        if (t + 1 < nt) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    if (MODE == MODE_TN) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int col = n0 + wn * WN + b * 32 + r;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = m0 + wm * WM + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (row < g.M && col < g.N) atomicAdd(g.C + (size_t)row * g.ldc + col, acc[a][b][i]);
+                }
+            }
+        if (g.colsum != nullptr && blockIdx.x == 0 && tid < BM && (m0 + tid) < g.M)
+            atomicAdd(g.colsum + m0 + tid, colsum_acc);
+        return;
+    }
+
+    DropCtx dc;
+    if (EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU || EPI == EPI_GELU_BWD_DROP)
+        dc = make_drop(g.ea.rng, g.ea.rng_add, g.ea.site, g.ea.p, g.ea.train);
+
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = n0 + wn * WN + b * 32 + r;
+            const bool colok = col < g.N;
+            float bias = 0.f;
+            if (EPI == EPI_NONE || EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU)
+                if (g.ea.bias != nullptr && colok) bias = g.ea.bias[col];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int rb = m0 + wm * WM + a * 32 + 8 * gq + 4 * h;  // 4 consecutive rows rb..rb+3
+                float mult[4] = {1.f, 1.f, 1.f, 1.f};
+                if (EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU || EPI == EPI_GELU_BWD_DROP)
+                    if (colok && rb < g.M) drop_mult4(dc, (uint32_t)(rb >> 2), (uint32_t)g.N, (uint32_t)col, mult);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = rb + q;
+                    if (row < g.M && colok) {
+                        const size_t off = (size_t)row * g.ldc + col;
+                        float v = acc[a][b][gq * 4 + q];
+                        if (EPI == EPI_NONE) {
+                            v += bias;
+                        } else if (EPI == EPI_RELU_DROP) {
+                            v = fmaxf(v + bias, 0.f) * mult[q];
+                        } else if (EPI == EPI_DROP_GELU) {
+                            const float u = (v + bias) * mult[q];
+                            g.ea.aux_out[off] = u;
+                            v = gelu_f(u);
+                        } else if (EPI == EPI_MASK_POS) {
+                            v = (g.ea.aux_in[off] > 0.f) ? v * g.ea.mscale : 0.f;
+                        } else if (EPI == EPI_GELU_BWD_DROP) {
+                            v = v * mult[q] * gelu_grad_f(g.ea.aux_in[off]);
+                        } else if (EPI == EPI_GELU_BWD) {
+                            v = v * gelu_grad_f(g.ea.aux_in[off]);
+                        }
+                        g.C[off] = v;
+                    }
+                }
+            }
+        }
+}
+
+template <int MODE, int BM, int BN, int EPI>
+static int launch_cfg(const GemmArgs& g, int splits, hipStream_t st) {
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
+    hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, EPI>), grid, dim3(256), 0, st, g);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int MODE, int EPI>
+static int launch_pick(const GemmArgs& g, hipStream_t st) {
+    // big tile only when it still yields >= 2 blocks per CU
+    const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    if (tiles128 >= 512) return launch_cfg<MODE, 128, 128, EPI>(g, 1, st);
+    return launch_cfg<MODE, 64, 64, EPI>(g, 1, st);
+}
+
+static int check_common(const float* A, int lda, const float* B, int ldb, const float* C, int M, int N, int K) {
+    GF_CHECK_ARG(A && B && C, "gemm: null pointer");
+    GF_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    GF_CHECK_ARG((lda & 3) == 0 && (ldb & 3) == 0, "gemm: leading dims must be multiples of 4 (lda=%d ldb=%d)", lda, ldb);
+    GF_CHECK_ARG(aligned16(A) && aligned16(B), "gemm: operands must be 16-byte aligned");
+    return 0;
+}
+
+#define EPI_SWITCH(MODE, g, st)                                                            \
+    switch (epi) {                                                                         \
+        case EPI_NONE: return launch_pick<MODE, EPI_NONE>(g, st);                          \
+        case EPI_RELU_DROP: return launch_pick<MODE, EPI_RELU_DROP>(g, st);                \
+        case EPI_DROP_GELU: return launch_pick<MODE, EPI_DROP_GELU>(g, st);                \
+        case EPI_MASK_POS: return launch_pick<MODE, EPI_MASK_POS>(g, st);                  \
+        case EPI_GELU_BWD_DROP:                                                            \
+        case EPI_GELU_BWD_DROP0: return launch_pick<MODE, EPI_GELU_BWD_DROP>(g, st);       \
+        case EPI_GELU_BWD: return launch_pick<MODE, EPI_GELU_BWD>(g, st);                  \
+        default: return fail(-1, "gemm: unknown epilogue %d", epi);                        \
+    }
+
+int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                   int epi, const EpiArgs& ea, hipStream_t st) {
+    GF_TRY(check_common(A, lda, W, ldw, C, M, N, K));
+    GF_CHECK_ARG((K & 3) == 0, "gemm_nt: K=%d must be a multiple of 4", K);
+    GemmArgs g{A, lda, W, ldw, C, ldc, nullptr, M, N, K, K, ea};
+    EPI_SWITCH(MODE_NT, g, st)
+}
+
+int launch_gemm_nn(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
+                   int epi, const EpiArgs& ea, hipStream_t st) {
+    GF_TRY(check_common(A, lda, Bm, ldb, C, M, N, K));
+    GF_CHECK_ARG((K & 3) == 0 && (N & 3) == 0, "gemm_nn: K=%d and N=%d must be multiples of 4", K, N);
+    GemmArgs g{A, lda, Bm, ldb, C, ldc, nullptr, M, N, K, K, ea};
+    EPI_SWITCH(MODE_NN, g, st)
+}
+
+int launch_gemm_tn_acc(const float* At, int lda, const float* Bm, int ldb, float* C, int ldc, float* colsum,
+                       int M, int N, int K, hipStream_t st) {
+    GF_TRY(check_common(At, lda, Bm, ldb, C, M, N, K));
+    GF_CHECK_ARG((M & 3) == 0 && (N & 3) == 0, "gemm_tn: M=%d and N=%d must be multiples of 4", M, N);
+    EpiArgs ea;
+    GemmArgs g{At, lda, Bm, ldb, C, ldc, colsum, M, N, K, K, ea};
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    long splits = (1536 + tiles - 1) / tiles;            // aim at ~6 blocks per CU
+    const long maxsplits = (K + 63) / 64;                // at least 64 k per block
+    if (splits > maxsplits) splits = maxsplits;
+    if (splits < 1) splits = 1;
+    int kchunk = (int)(((K + splits - 1) / splits + BK - 1) / BK * BK);
+    splits = (K + kchunk - 1) / kchunk;
+    g.kchunk = kchunk;
+    return launch_cfg<MODE_TN, 64, 64, EPI_NONE>(g, (int)splits, st);
+}
+
+}  // namespace ganffn

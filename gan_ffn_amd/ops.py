@@ -1,0 +1,373 @@
+"""Tensor-level wrappers over libganffn.so: raw calls on torch CUDA(ROCm) tensors plus the
+torch.autograd.Functions the nn.Modules in model.py are built from.
+
+torch is plumbing here (device memory, streams, autograd bookkeeping); all arithmetic of the
+hot path runs in the HIP library.  Every wrapper raises if the tensors are not on a GPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import EncCfg, HeadCfg, GanffnError
+
+FF = 2048            # nn.TransformerEncoderLayer default dim_feedforward (reference passes none, model.py:1210)
+ENC_DROPOUT = 0.1    # nn.TransformerEncoderLayer default dropout
+PE_DROPOUT = 0.2     # PositionalEncoding default (model.py:1179)
+LN_EPS = 1e-5
+N_LAYERS = 8         # model.py:1212
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise GanffnError("GAN-FFN ops run only on an MI355X (HIP) device; got a %s tensor. "
+                              "There is no CPU fallback." % t.device)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# RNG state (device-resident {seed, offset}; kernels read it at run time -> graph-replay safe)
+# ----------------------------------------------------------------------------------------------
+class DeviceRng:
+    """Per-device Philox state.  `next_add()` hands out one unique offset per dropout-bearing call."""
+    _states = {}
+
+    def __init__(self, device, seed=3407):  # 3407: the reference's seed, train_IEMOCAP.py:46
+        self.state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+        self.counter = 0
+
+    @classmethod
+    def get(cls, device):
+        key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        if key not in cls._states:
+            cls._states[key] = DeviceRng(torch.device("cuda", key))
+        return cls._states[key]
+
+    def manual_seed(self, seed, offset=0):
+        self.state.copy_(torch.tensor([seed, offset], dtype=torch.int64))
+        self.counter = 0
+
+    def next_add(self, n=1):
+        v = self.counter
+        self.counter += n
+        return v
+
+
+def manual_seed(seed, device=None):
+    DeviceRng.get(device if device is not None else torch.cuda.current_device()).manual_seed(seed)
+
+
+# ----------------------------------------------------------------------------------------------
+# layout helpers
+# ----------------------------------------------------------------------------------------------
+LAYER_KEYS = ["self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+              "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias",
+              "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"]
+
+
+def layer_shapes(E, F=FF):
+    return [(3 * E, E), (3 * E,), (E, E), (E,), (F, E), (F,), (E, F), (E,), (E,), (E,), (E,), (E,)]
+
+
+def layer_layout(E, F=FF):
+    """-> (floats per layer, [12 offsets]) from the library (single source of truth)."""
+    lib = _lib.load()
+    offs = (C.c_int64 * 12)()
+    _lib.check(lib.ganffn_layer_param_offsets(E, F, offs), "ganffn_layer_param_offsets")
+    return int(lib.ganffn_layer_param_count(E, F)), [int(o) for o in offs]
+
+
+def enc_cfg(S, B, E, H, L=N_LAYERS, F=FF, train=False, p_pe=PE_DROPOUT, p_enc=ENC_DROPOUT):
+    return EncCfg(S, B, E, H, F, L, p_pe, p_enc, LN_EPS, 1 if train else 0)
+
+
+def enc_sizes(cfg):
+    lib = _lib.load()
+    s = int(lib.ganffn_encoder_saved_floats(C.byref(cfg)))
+    w = int(lib.ganffn_encoder_workspace_floats(C.byref(cfg)))
+    if s < 0 or w < 0:
+        _lib.check(-1, "ganffn_encoder_*_floats")
+    return s, w
+
+
+def head_sizes(cfg):
+    lib = _lib.load()
+    s = int(lib.ganffn_head_saved_floats(C.byref(cfg)))
+    w = int(lib.ganffn_head_workspace_floats(C.byref(cfg)))
+    if s < 0 or w < 0:
+        _lib.check(-1, "ganffn_head_*_floats")
+    return s, w
+
+
+# ----------------------------------------------------------------------------------------------
+# raw calls (no autograd) — used by the autograd Functions below and by engine.py
+# ----------------------------------------------------------------------------------------------
+def encoder_fwd_raw(cfg, x, pe, slab, out, saved, ws, rng, add):
+    _lib.call("ganffn_encoder_fwd", C.byref(cfg), _ptr(x), _ptr(pe), _ptr(slab), _ptr(out), _ptr(saved), _ptr(ws),
+              _ptr(rng), C.c_uint64(add), _stream())
+
+
+def encoder_bwd_raw(cfg, lo, hi, dx, slab, gslab, saved, ws, rng, add):
+    _lib.call("ganffn_encoder_bwd", C.byref(cfg), lo, hi, _ptr(dx), _ptr(slab), _ptr(gslab), _ptr(saved), _ptr(ws),
+              _ptr(rng), C.c_uint64(add), _stream())
+
+
+def head_fwd_raw(cfg, x, w1, b1, w2, b2, w3, b3, out, saved, ws, rng, add):
+    _lib.call("ganffn_head_fwd", C.byref(cfg), _ptr(x), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3),
+              _ptr(out), _ptr(saved), _ptr(ws), _ptr(rng), C.c_uint64(add), _stream())
+
+
+def head_bwd_raw(cfg, d_out, x, w1, w2, w3, gw1, gb1, gw2, gb2, gw3, gb3, dx, saved, ws, rng, add):
+    _lib.call("ganffn_head_bwd", C.byref(cfg), _ptr(d_out), _ptr(x), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(gw1), _ptr(gb1),
+              _ptr(gw2), _ptr(gb2), _ptr(gw3), _ptr(gb3), _ptr(dx), _ptr(saved), _ptr(ws), _ptr(rng), C.c_uint64(add),
+              _stream())
+
+
+def linear_fwd_raw(x, w, b, y, T, K, N):
+    _lib.call("ganffn_linear_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(y), T, K, N, _stream())
+
+
+def linear_bwd_raw(dy, x, w, dx, gw, gb, T, K, N):
+    _lib.call("ganffn_linear_bwd", _ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(gw), _ptr(gb), T, K, N, _stream())
+
+
+def bce_fwd_raw(prob, target, n, scale, loss, accumulate):
+    _lib.call("ganffn_bce_fwd", _ptr(prob), C.c_float(target), n, C.c_float(scale), _ptr(loss), 1 if accumulate else 0,
+              _stream())
+
+
+def bce_bwd_raw(prob, target, n, scale, dprob):
+    _lib.call("ganffn_bce_bwd", _ptr(prob), C.c_float(target), n, C.c_float(scale), _ptr(dprob), _stream())
+
+
+def adam_step_raw(p, g, m, v, step, n, lr, b1, b2, eps=1e-8, wd=0.0, gscale=1.0):
+    _lib.call("ganffn_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(step), C.c_int64(n), C.c_float(lr),
+              C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(wd), C.c_float(gscale), _stream())
+
+
+def rng_advance_raw(rng, delta):
+    _lib.call("ganffn_rng_advance", _ptr(rng), C.c_uint64(delta), _stream())
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd Functions
+# ----------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b over the last dim (VisualDiscriminator.object, GAN_FFN.fc)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _need_gpu(x, w, b)
+        xc, wc, bc = _f32c(x), _f32c(w), _f32c(b)
+        K, N = wc.shape[1], wc.shape[0]
+        T = xc.numel() // K
+        y = torch.empty(*xc.shape[:-1], N, device=x.device, dtype=torch.float32)
+        linear_fwd_raw(xc, wc, bc, y, T, K, N)
+        ctx.save_for_backward(xc, wc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc = ctx.saved_tensors
+        dy = _f32c(dy)
+        K, N = wc.shape[1], wc.shape[0]
+        T = xc.numel() // K
+        dx = torch.empty_like(xc) if ctx.needs_input_grad[0] else None
+        gw = torch.zeros_like(wc) if ctx.needs_input_grad[1] else None
+        gb = torch.zeros(N, device=dy.device, dtype=torch.float32) if gw is not None else None
+        linear_bwd_raw(dy, xc, wc, dx, gw, gb, T, K, N)
+        return dx, gw, (gb if ctx.needs_input_grad[2] else None)
+
+
+class EncoderFn(torch.autograd.Function):
+    """PositionalEncoding + L encoder layers.  `slab` is the packed parameter block the library reads;
+    `*params` are the nn.Parameter views into it (only there so autograd tracks them)."""
+
+    @staticmethod
+    def forward(ctx, x, pe, slab, meta, *params):
+        _need_gpu(x, slab)
+        E, H, L, train = meta["E"], meta["H"], meta["L"], meta["train"]
+        S, B = x.shape[0], x.shape[1]
+        xc = _f32c(x)
+        cfg = enc_cfg(S, B, E, H, L, train=train, p_pe=meta.get("p_pe", PE_DROPOUT), p_enc=meta.get("p_enc", ENC_DROPOUT))
+        n_saved, n_ws = enc_sizes(cfg)
+        need_grad = any(ctx.needs_input_grad)
+        saved = torch.empty(n_saved, device=x.device, dtype=torch.float32) if need_grad else None
+        ws = torch.empty(n_ws, device=x.device, dtype=torch.float32)
+        out = torch.empty(S, B, E, device=x.device, dtype=torch.float32)
+        rng = DeviceRng.get(x.device)
+        add = rng.next_add() if train else 0
+        encoder_fwd_raw(cfg, xc, pe, slab, out, saved, ws, rng.state, add)
+        ctx.cfg, ctx.add, ctx.rng_state = cfg, add, rng.state
+        ctx.slab, ctx.saved = slab, saved
+        ctx.param_meta = meta
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cfg, meta = ctx.cfg, ctx.param_meta
+        dx = _f32c(dout).clone()
+        n_saved, n_ws = enc_sizes(cfg)
+        ws = torch.empty(n_ws, device=dx.device, dtype=torch.float32)
+        want_w = any(ctx.needs_input_grad[4:])
+        gslab = torch.zeros_like(ctx.slab) if want_w else None
+        encoder_bwd_raw(cfg, 0, cfg.L, dx, ctx.slab, gslab, ctx.saved, ws, ctx.rng_state, ctx.add)
+        grads = [None] * len(meta["views"])
+        if want_w:
+            for i, (off, shape) in enumerate(meta["views"]):
+                n = 1
+                for d in shape:
+                    n *= d
+                grads[i] = gslab[off:off + n].view(shape)
+        return (dx if ctx.needs_input_grad[0] else None, None, None, None, *grads)
+
+
+class HeadFn(torch.autograd.Function):
+    """generator / discriminator head after the encoder stack."""
+
+    @staticmethod
+    def forward(ctx, x, kind, p, train, w1, b1, w2, b2, w3, b3):
+        _need_gpu(x, w1)
+        xc = _f32c(x)
+        S, B, E = xc.shape
+        T = S * B
+        D1, D2 = w1.shape[0], w2.shape[0]
+        cfg = HeadCfg(T, E, D1, D2, kind, p, 1 if train else 0)
+        n_saved, n_ws = head_sizes(cfg)
+        saved = torch.empty(n_saved, device=x.device, dtype=torch.float32)
+        ws = torch.empty(n_ws, device=x.device, dtype=torch.float32)
+        out = torch.empty(S, B, D2 if kind == 0 else 1, device=x.device, dtype=torch.float32)
+        rng = DeviceRng.get(x.device)
+        add = rng.next_add() if train else 0
+        head_fwd_raw(cfg, xc, w1, b1, w2, b2, w3, b3, out, saved, ws, rng.state, add)
+        ctx.cfg, ctx.add, ctx.rng_state, ctx.saved = cfg, add, rng.state, saved
+        ctx.save_for_backward(xc, w1, w2, w3)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, w1, w2, w3 = ctx.saved_tensors
+        cfg = ctx.cfg
+        dout = _f32c(dout)
+        n_saved, n_ws = head_sizes(cfg)
+        ws = torch.empty(n_ws, device=dout.device, dtype=torch.float32)
+        dx = torch.empty_like(xc)
+        z = lambda t: torch.zeros_like(t) if t is not None else None
+        gw1, gw2, gw3 = z(w1), z(w2), z(w3)
+        gb1 = torch.zeros(w1.shape[0], device=dout.device)
+        gb2 = torch.zeros(w2.shape[0], device=dout.device)
+        gb3 = torch.zeros(1, device=dout.device) if w3 is not None else None
+        head_bwd_raw(cfg, dout, xc, w1, w2, w3, gw1, gb1, gw2, gb2, gw3, gb3, dx, ctx.saved, ws, ctx.rng_state, ctx.add)
+        return dx, None, None, None, gw1, gb1, gw2, gb2, gw3, gb3
+
+
+class BCEMeanFn(torch.autograd.Function):
+    """nn.BCELoss() against a constant target (the reference only ever uses all-ones / all-zeros labels,
+    train_IEMOCAP.py:341-346)."""
+
+    @staticmethod
+    def forward(ctx, prob, target):
+        _need_gpu(prob)
+        pc = _f32c(prob)
+        loss = torch.empty(1, device=prob.device, dtype=torch.float32)
+        bce_fwd_raw(pc, float(target), pc.numel(), 1.0, loss, False)
+        ctx.save_for_backward(pc)
+        ctx.target = float(target)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (pc,) = ctx.saved_tensors
+        d = torch.empty_like(pc)
+        bce_bwd_raw(pc, ctx.target, pc.numel(), 1.0, d)
+        return d * dloss, None
+
+
+def bce_mean(prob, target):
+    return BCEMeanFn.apply(prob, target)
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout(p) on a (.., C) tensor with the Philox contract (standalone PositionalEncoding use)."""
+
+    @staticmethod
+    def forward(ctx, x, p, train, site):
+        ctx.active = bool(train) and p > 0.0
+        if not ctx.active:
+            return x
+        _need_gpu(x)
+        xc = _f32c(x)
+        C_ = xc.shape[-1]
+        R = xc.numel() // C_
+        rng = DeviceRng.get(x.device)
+        add = rng.next_add()
+        out = torch.empty_like(xc)
+        _lib.call("ganffn_dropout", _ptr(xc), _ptr(out), R, C_, C.c_float(p), C.c_uint32(site), _ptr(rng.state),
+                  C.c_uint64(add), _stream())
+        ctx.args = (R, C_, p, site, rng.state, add)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.active:
+            return dy, None, None, None
+        R, C_, p, site, state, add = ctx.args
+        dy = _f32c(dy)
+        dx = torch.empty_like(dy)
+        _lib.call("ganffn_dropout", _ptr(dy), _ptr(dx), R, C_, C.c_float(p), C.c_uint32(site), _ptr(state),
+                  C.c_uint64(add), _stream())
+        return dx, None, None, None
+
+
+class Add3Fn(torch.autograd.Function):
+    """fusion = a + b + c   (model.py:1445)"""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        _need_gpu(a, b, c)
+        a, b, c = _f32c(a), _f32c(b), _f32c(c)
+        out = torch.empty_like(a)
+        _lib.call("ganffn_add3", _ptr(a), _ptr(b), _ptr(c), _ptr(out), C.c_int64(a.numel()), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d, d
+
+
+def logsoftmax_nll_raw(logits, labels, umask, class_w, log_prob, loss, dlogits, ws2, S, B, Cn):
+    _lib.call("ganffn_logsoftmax_nll", _ptr(logits), _ptr(labels), _ptr(umask), _ptr(class_w), _ptr(log_prob),
+              _ptr(loss), _ptr(dlogits), _ptr(ws2), S, B, Cn, _stream())
+
+
+class LogSoftmaxFn(torch.autograd.Function):
+    """F.log_softmax(x, 2) on (S, B, C)   (model.py:1449)"""
+
+    @staticmethod
+    def forward(ctx, logits):
+        _need_gpu(logits)
+        x = _f32c(logits)
+        S, B, Cn = x.shape
+        lp = torch.empty_like(x)
+        logsoftmax_nll_raw(x, None, None, None, lp, None, None, None, S, B, Cn)
+        ctx.save_for_backward(lp)
+        return lp
+
+    @staticmethod
+    def backward(ctx, d):
+        (lp,) = ctx.saved_tensors
+        return d - torch.exp(lp) * d.sum(-1, keepdim=True)

@@ -1,0 +1,190 @@
+/*
+ * ganffn.h — C ABI of libganffn.so: the MI355X (gfx950) implementation of GAN-FFN's
+ * tri-modal generator/discriminator training step.
+ *
+ * The reference has no FFI: its seam is the Python nn.Module API of model.py as
+ * consumed by train_IEMOCAP.py.  Every entry point below states the
+ * reference code it replaces (file:line under /root/reference).  The Python side
+ * (gan_ffn_amd/model.py, gan_ffn_amd/engine.py) binds these with ctypes and keeps the
+ * reference's class names, constructor/forward signatures and state_dict layout.
+ *
+ * Conventions
+ *  - All tensors are fp32, row-major, DEVICE pointers (hipMalloc'ed by the caller — in
+ *    practice torch's caching allocator).  Activations are [T x C] with T = S*B tokens,
+ *    token t = s*B + b, i.e. exactly the memory of the reference's (S, B, C) tensors
+ *    (train_IEMOCAP.py:142-147).
+ *  - The caller owns EVERY buffer (inputs, outputs, saved-for-backward, workspace,
+ *    parameter/gradient/optimizer-state slabs).  The library allocates nothing and keeps
+ *    no mutable global state.
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it and the call
+ *    returns without synchronising (so calls are capturable in a hipGraph).
+ *  - Return value: 0 ok; < 0 argument/shape/alignment error (message via
+ *    ganffn_last_error, thread-local); > 0 a hipError_t from a launch.
+ *  - Parameters of one encoder stack live in ONE slab: L consecutive layer blocks of
+ *    ganffn_layer_param_count(E, F) floats, each laid out per ganffn_layer_param_offsets.
+ *    Gradient and Adam-state slabs use the same layout.  gan_ffn_amd/model.py exposes the
+ *    slab through nn.Parameter views named like the reference's state_dict keys
+ *    (transformer_encoder.layers.N.self_attn.in_proj_weight ...).
+ *  - Dropout uses the counter-based Philox4x32-10 contract of oracle/philox.py /
+ *    csrc/philox.h.  `rng` points to TWO device uint64: {seed, offset}; kernels read them
+ *    at run time, so a captured graph replays with fresh masks after ganffn_rng_advance.
+ */
+#ifndef GANFFN_H
+#define GANFFN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GANFFN_VERSION 100 /* 0.1.0 */
+#define GANFFN_MAX_SEQ 112 /* PositionalEncoding(max_len=110), model.py:1179, rounded up to 4 */
+
+/* Encoder-stack configuration: PositionalEncoding + L post-LN nn.TransformerEncoderLayer
+ * (model.py:1178-1197, 1210-1213).  p_* = 0 or train = 0 disables that dropout site. */
+typedef struct ganffn_enc_cfg {
+    int32_t S, B;       /* sequence length (<= 110) and batch (dialogues) */
+    int32_t E, H, F, L; /* d_model, heads, dim_feedforward (2048), layers (8) */
+    float p_pe;         /* PositionalEncoding dropout, 0.2 (model.py:1179) */
+    float p_enc;        /* TransformerEncoderLayer dropout, 0.1 (torch default; model.py:1210) */
+    float ln_eps;       /* 1e-5 */
+    int32_t train;      /* 1: dropout active (module.train()), 0: eval */
+} ganffn_enc_cfg;
+
+/* Head configuration (the layers after the encoder stack).
+ *  kind 0 = generator  : gelu -> drop -> gelu(drop(fc1)) -> gelu(drop(fc2))            model.py:1223-1228
+ *  kind 1 = discriminator: gelu -> gelu(drop(fc1)) -> gelu(drop(fc2)) -> sigmoid(drop(fc3)) model.py:1322-1326 */
+typedef struct ganffn_head_cfg {
+    int32_t T;          /* tokens = S*B */
+    int32_t E;          /* input width (d_model) */
+    int32_t D1, D2;     /* fc1 / fc2 output widths (gen: 512|1024, D_h; disc: 64, 16) */
+    int32_t kind;
+    float p;            /* module dropout (0.2) */
+    int32_t train;
+} ganffn_head_cfg;
+
+/* ---- library info ------------------------------------------------------------------ */
+int ganffn_version(void);
+const char* ganffn_last_error(void);
+
+/* ---- parameter slab layout --------------------------------------------------------- */
+/* floats per encoder layer; offsets[12] in this order:
+ * in_proj_weight[3E,E] in_proj_bias[3E] out_proj.weight[E,E] out_proj.bias[E]
+ * linear1.weight[F,E] linear1.bias[F] linear2.weight[E,F] linear2.bias[E]
+ * norm1.weight[E] norm1.bias[E] norm2.weight[E] norm2.bias[E] */
+int64_t ganffn_layer_param_count(int E, int F);
+int ganffn_layer_param_offsets(int E, int F, int64_t* offsets12);
+
+/* ---- sizes the caller must allocate ------------------------------------------------ */
+int64_t ganffn_encoder_saved_floats(const ganffn_enc_cfg* cfg);     /* saved-for-backward */
+int64_t ganffn_encoder_workspace_floats(const ganffn_enc_cfg* cfg); /* scratch, fwd or bwd */
+int64_t ganffn_head_saved_floats(const ganffn_head_cfg* cfg);
+int64_t ganffn_head_workspace_floats(const ganffn_head_cfg* cfg);
+
+/* ---- RNG state --------------------------------------------------------------------- */
+/* rng[0] = seed, rng[1] = offset (device memory).  offset += delta, on the stream. */
+int ganffn_rng_advance(uint64_t* rng, uint64_t delta, void* stream);
+
+/* ---- A1: PositionalEncoding table (model.py:1182-1188) ----------------------------- */
+/* pe[max_len x E] on device, computed as the reference does (fp32 sin/cos of p*exp(-2i ln1e4/E)). */
+int ganffn_pe_table(float* pe, int max_len, int E, void* stream);
+
+/* ---- A1+A2: encoder stack = PE + L encoder layers (model.py:1196-1197, 1224) -------- */
+/* x_in [T x E]; pe [>=S x E]; params: L layer blocks; out [T x E] (output of the last layer);
+ * saved: ganffn_encoder_saved_floats floats (needed by _bwd; pass NULL for inference-only,
+ * then workspace is used and nothing is kept); rng_offset_add is added to rng[1] for this call. */
+int ganffn_encoder_fwd(const ganffn_enc_cfg* cfg, const float* x_in, const float* pe,
+                       const float* params, float* out, float* saved, float* workspace,
+                       const uint64_t* rng, uint64_t rng_offset_add, void* stream);
+
+/* Backward through layers [layer_lo, layer_hi) in reverse order.  dx [T x E] is in/out: on entry
+ * dL/d(output of layer layer_hi-1), on exit dL/d(input of layer layer_lo); when layer_lo == 0 the
+ * PE dropout backward is applied too, so dx is then dL/d(x_in).  grads (same layout as params)
+ * is ACCUMULATED into (+=) when non-NULL; NULL skips every weight gradient (train_gen's pass
+ * through the frozen discriminator, train_IEMOCAP.py:245-250: those grads are never used).
+ * Splitting the range lets the caller start a layer's gradient all-reduce while earlier layers
+ * are still in backward. */
+int ganffn_encoder_bwd(const ganffn_enc_cfg* cfg, int layer_lo, int layer_hi, float* dx,
+                       const float* params, float* grads, const float* saved, float* workspace,
+                       const uint64_t* rng, uint64_t rng_offset_add, void* stream);
+
+/* ---- A3-A6: heads ------------------------------------------------------------------- */
+/* x [T x E] = encoder output.  w1[D1,E] b1[D1] w2[D2,D1] b2[D2]; disc only: w3[1,D2] b3[1].
+ * out: gen -> fusion [T x D2]; disc -> prob [T x 1]. */
+int ganffn_head_fwd(const ganffn_head_cfg* cfg, const float* x, const float* w1, const float* b1,
+                    const float* w2, const float* b2, const float* w3, const float* b3, float* out,
+                    float* saved, float* workspace, const uint64_t* rng, uint64_t rng_offset_add,
+                    void* stream);
+/* d_out: gen [T x D2], disc [T x 1].  dx [T x E] written.  g* accumulated (+=) when non-NULL. */
+int ganffn_head_bwd(const ganffn_head_cfg* cfg, const float* d_out, const float* x,
+                    const float* w1, const float* w2, const float* w3, float* gw1, float* gb1,
+                    float* gw2, float* gb2, float* gw3, float* gb3, float* dx, const float* saved,
+                    float* workspace, const uint64_t* rng, uint64_t rng_offset_add, void* stream);
+
+/* ---- plain Linear (VisualDiscriminator.object model.py:1355-1356; GAN_FFN.fc model.py:1448) */
+int ganffn_linear_fwd(const float* x, const float* w, const float* b, float* y, int T, int K, int N,
+                      void* stream);
+/* dx may be NULL; gw/gb accumulated when non-NULL */
+int ganffn_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* gw,
+                      float* gb, int T, int K, int N, void* stream);
+
+/* ---- A10: BCELoss(mean) (train_IEMOCAP.py:300,220-223,248) -------------------------- */
+/* loss_out[0] (+)= scale * mean_i( -(y*max(log p,-100) + (1-y)*max(log(1-p),-100)) ), y = target.
+ * accumulate != 0 adds to loss_out (the D loss is (real + fake)/2: two calls with scale 0.5). */
+int ganffn_bce_fwd(const float* prob, float target, int n, float scale, float* loss_out,
+                   int accumulate, void* stream);
+/* dprob[i] = scale/n * (p - y) / max(p*(1-p), 1e-12)   (torch's binary_cross_entropy_backward) */
+int ganffn_bce_bwd(const float* prob, float target, int n, float scale, float* dprob, void* stream);
+
+/* ---- A10: Adam over a flat slab (train_IEMOCAP.py:292-297; phase 2 :661) ------------- */
+/* step: device int32 counter, incremented by this call BEFORE use (t = ++*step).
+ * g = grad + weight_decay*p (L2-coupled, not AdamW).  n floats. */
+int ganffn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                     int32_t* step, int64_t n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, float grad_scale, void* stream);
+
+/* ---- A11: phase 2 (model.py:1441-1449, :74-81) --------------------------------------- */
+/* fusion = a + b + c (elementwise, n floats) */
+int ganffn_add3(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream);
+/* logits [T x C] (token t = s*B+b) -> log_prob [T x C]; loss_out[0] = masked weighted NLL:
+ * -sum_t w[y_t] m_t lp[t,y_t] / sum_t w[y_t] m_t, labels/umask are batch-major [B x S] as the
+ * reference's collate makes them (dataloader.py:55-58); class_w may be NULL (unweighted).
+ * dlogits (may be NULL) receives dL/dlogits. */
+int ganffn_logsoftmax_nll(const float* logits, const int64_t* labels, const float* umask,
+                          const float* class_w, float* log_prob, float* loss_out, float* dlogits,
+                          float* workspace2, int S, int B, int C, void* stream);
+
+/* ---- building blocks exported for unit tests ----------------------------------------- */
+/* C[M x N] = A[M x K] * W[N x K]^T + bias (bias may be NULL) */
+int ganffn_gemm_nt(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
+                   void* stream);
+/* C[M x N] = A[M x K] * B[K x N] */
+int ganffn_gemm_nn(const float* A, const float* Bm, float* C, int M, int N, int K, void* stream);
+/* C[M x N] += At[K x M]^T * B[K x N];  colsum[M] += sum_k At[k][m] when colsum != NULL */
+int ganffn_gemm_tn_acc(const float* At, const float* Bm, float* C, float* colsum, int M, int N, int K,
+                       void* stream);
+/* qkv [T x 3E] -> o [T x E]; site = dropout site id; p = 0 disables dropout */
+int ganffn_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p,
+                         uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, void* stream);
+int ganffn_attention_bwd(const float* qkv, const float* d_o, float* d_qkv, int S, int B, int E, int H,
+                         float p, uint32_t site, const uint64_t* rng, uint64_t rng_offset_add,
+                         void* stream);
+/* z = x + drop(y); xhat = (z-mean)*rstd; out = xhat*w + b   (norm1/norm2 of the encoder layer) */
+int ganffn_add_dropout_layernorm_fwd(const float* x, const float* y, const float* w, const float* b,
+                                     float* out, float* xhat, float* rstd, int T, int E, float eps,
+                                     float p, uint32_t site, const uint64_t* rng,
+                                     uint64_t rng_offset_add, void* stream);
+/* d_out -> dz (residual branch) and dy = drop_bwd(dz); gw/gb accumulated when non-NULL */
+int ganffn_add_dropout_layernorm_bwd(const float* d_out, const float* xhat, const float* rstd,
+                                     const float* w, float* dz, float* dy, float* gw, float* gb, int T,
+                                     int E, float p, uint32_t site, const uint64_t* rng,
+                                     uint64_t rng_offset_add, void* stream);
+/* out = keep ? x/(1-p) : 0 over a [R x C] tensor (Philox contract) — test hook for the mask layout */
+int ganffn_dropout(const float* x, float* out, int R, int C, float p, uint32_t site,
+                   const uint64_t* rng, uint64_t rng_offset_add, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANFFN_H */

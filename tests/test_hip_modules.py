@@ -1,0 +1,124 @@
+"""GPU parity of the nn.Module mirror (gan_ffn_amd.model, all arithmetic in libganffn.so) against
+(1) the golden fixtures generated from the reference itself (eval mode), and
+(2) the oracle with identical Philox dropout masks (train mode)."""
+import numpy as np
+import pytest
+import torch
+
+import formula as F_
+from oracle import ganffn_oracle as O
+from util import NETS, check_summary, formula_sd, golden
+
+pytestmark = pytest.mark.gpu
+
+
+def build(cls_name):
+    from gan_ffn_amd import model
+    m = getattr(model, cls_name)(100, dropout=0.2)
+    sd = formula_sd(cls_name)
+    missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert missing.missing_keys == ["position_encoding.pe"] and not missing.unexpected_keys
+    return m.cuda()
+
+
+@pytest.mark.parametrize("case", [
+    ("AcousticGenerator", 100), ("TextGenerator", 100), ("VisualGenerator", 512),
+    ("AcousticDiscriminator", 100), ("TextDiscriminator", 100),
+    ("VisualDiscriminator", 512), ("VisualDiscriminator", 100)])
+@pytest.mark.parametrize("shape", [(7, 2), (110, 3)])
+def test_module_matches_reference_fixture(case, shape):
+    cls_name, din = case
+    S, B = shape
+    g = golden("modules")
+    tag = "%s.%d.%dx%d" % (cls_name, din, S, B)
+    net = build(cls_name).eval()
+    x = torch.from_numpy(F_.formula_input(tag, S, B, din, pad_from=max(1, S - 3))).cuda().requires_grad_(True)
+    y = net(x)
+    gy = (torch.from_numpy(F_.formula_input("grad." + tag, S, B, y.shape[-1])) - 0.5).cuda()
+    (y * gy).sum().backward()
+    # forward: the 1e-4 bound of BASELINE.json's north_star (fused features / discriminator outputs)
+    check_summary(g, tag + "/out", y, rtol=1e-4, atol=1e-6, what="hip", strict=True)
+    check_summary(g, tag + "/dx", x.grad, rtol=2e-4, atol=1e-7, what="hip")
+    sd = dict(net.named_parameters())
+    n = 0
+    for f in g.files:
+        if f.startswith(tag + "/grad/") and (f.endswith("/full") or f.endswith("/sample")):
+            k = f[len(tag) + 6:].rsplit("/", 1)[0]
+            assert sd[k].grad is not None, k
+            # see tests/test_oracle_golden.py: one relu-kink flip moves summed grads by ~5e-4 of scale
+            check_summary(g, tag + "/grad/" + k, sd[k].grad, rtol=1e-3, atol=1e-7, what="hip")
+            n += 1
+    assert n >= 12
+    assert all(p.grad is None for k, p in sd.items() if k.startswith("encoder_layer."))
+
+
+@pytest.mark.parametrize("cls_name,din,S,B", [("TextGenerator", 100, 23, 3), ("VisualGenerator", 512, 38, 2),
+                                              ("AcousticDiscriminator", 100, 94, 4), ("VisualDiscriminator", 512, 17, 2)])
+def test_train_mode_matches_oracle_with_same_masks(cls_name, din, S, B):
+    """dropout ON: same (seed, offset) -> identical Philox masks in kernel and oracle."""
+    from gan_ffn_amd import ops
+    kind, _, E, H, fcs, has_obj = NETS[cls_name]
+    net = build(cls_name).train()
+    seed = 424242
+    ops.manual_seed(seed)
+    tag = "train.%s" % cls_name
+    x_np = F_.formula_input(tag, S, B, din, pad_from=max(1, S - 4))
+    x = torch.from_numpy(x_np).cuda().requires_grad_(True)
+    y = net(x)                      # consumes rng offsets 0 (encoder) and 1 (head)
+    gy = (torch.from_numpy(F_.formula_input("grad." + tag, S, B, y.shape[-1])) - 0.5)
+    (y * gy.cuda()).sum().backward()
+
+    # oracle with the same offsets: encoder sites read offset 0, head sites offset 1
+    onet = O.OracleNet(kind, formula_sd(cls_name), H, 0.2, torch.float64)
+    xo = torch.from_numpy(x_np).double().requires_grad_(True)
+    xin = xo
+    if has_obj and din == 512:
+        xin = xo @ onet.P["object.weight"].T + onet.P["object.bias"]
+    h = O.encoder_stack(xin, onet.P, H, O.Rng(seed, 0, True))
+    r1 = O.Rng(seed, 1, True)
+    if kind == "gen":
+        t = O._drop(O.gelu(h), 0.2, O.SITE_HEAD0, r1)
+        t = O.gelu(O._drop(t @ onet.P["fc1.weight"].T + onet.P["fc1.bias"], 0.2, O.SITE_HEAD1, r1))
+        yo = O.gelu(O._drop(t @ onet.P["fc2.weight"].T + onet.P["fc2.bias"], 0.2, O.SITE_HEAD2, r1))
+    else:
+        t = O.gelu(h)
+        t = O.gelu(O._drop(t @ onet.P["fc1.weight"].T + onet.P["fc1.bias"], 0.2, O.SITE_HEAD1, r1))
+        t = O.gelu(O._drop(t @ onet.P["fc2.weight"].T + onet.P["fc2.bias"], 0.2, O.SITE_HEAD2, r1))
+        yo = torch.sigmoid(O._drop(t @ onet.P["fc3.weight"].T + onet.P["fc3.bias"], 0.2, O.SITE_HEAD3, r1))
+    (yo * gy.double()).sum().backward()
+
+    from util import _assert_close
+    _assert_close(y.detach().cpu().double().numpy(), yo.detach().numpy(), 1e-4, 1e-6, "train out", 0.0, 1.0)
+    _assert_close(x.grad.cpu().double().numpy(), xo.grad.numpy(), 2e-4, 1e-8, "train dx")
+    sd = dict(net.named_parameters())
+    for k in ("transformer_encoder.layers.0.self_attn.in_proj_weight", "transformer_encoder.layers.7.linear1.weight",
+              "transformer_encoder.layers.4.linear2.bias", "transformer_encoder.layers.2.norm1.weight",
+              "transformer_encoder.layers.5.norm2.bias", "transformer_encoder.layers.3.self_attn.out_proj.weight",
+              "fc1.weight", "fc2.bias"):
+        _assert_close(sd[k].grad.cpu().double().numpy(), onet.P[k].grad.numpy(), 1e-3, 1e-8, "train grad " + k)
+
+
+def test_state_dict_roundtrip_and_pickle(tmp_path):
+    from gan_ffn_amd import model
+    torch.manual_seed(3407)
+    a = model.AcousticDiscriminator(100).cuda().eval()
+    x = torch.rand(9, 2, 100, device="cuda")
+    y0 = a(x)
+    torch.save(a, tmp_path / "d.pt")                 # the reference pickles whole modules (train_IEMOCAP.py:438)
+    b = torch.load(tmp_path / "d.pt", weights_only=False).eval()
+    assert torch.equal(b(x), y0)
+    c = model.AcousticDiscriminator(100)
+    c.load_state_dict(a.state_dict())
+    assert torch.equal(c.cuda().eval()(x), y0)
+    # all 8 layers start identical to the template (nn.TransformerEncoder deep copies, model.py:1211)
+    sd = a.state_dict()
+    for l in range(8):
+        assert torch.equal(sd["transformer_encoder.layers.%d.linear1.weight" % l], sd["encoder_layer.linear1.weight"])
+
+
+def test_cpu_tensor_fails_loudly():
+    from gan_ffn_amd import model
+    from gan_ffn_amd._lib import GanffnError
+    m = model.TextGenerator(100)
+    with pytest.raises(GanffnError):
+        m(torch.zeros(4, 2, 100))

@@ -1,0 +1,227 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (ctypes), against the oracle /
+plain torch fp32 references on the same seeded inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ganffn_oracle as O
+from oracle import philox
+from util import golden
+import formula as F_
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gan_ffn_amd import _lib
+    return _lib
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+GEMM_SHAPES = [(3008, 300, 100), (3008, 2048, 100), (3008, 100, 2048), (282, 1536, 512), (14, 300, 100),
+               (5, 4, 4), (65, 68, 20), (3008, 64, 100), (3008, 16, 64), (330, 100, 512), (6016, 2048, 512)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_nt(lib, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    ref = A.double() @ W.double().T + b.double()
+    Ad, Wd, bd = dev(A), dev(W), dev(b)
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    lib.call("ganffn_gemm_nt", ptr(Ad), ptr(Wd), ptr(bd), ptr(Cd), M, N, K, stream())
+    assert rel_err(Cd, ref) < 2e-6 * max(1, K ** 0.5)
+
+
+@pytest.mark.parametrize("M,N,K", [(3008, 100, 300), (3008, 2048, 100), (3008, 100, 2048), (282, 512, 1536),
+                                   (14, 100, 300), (5, 4, 4), (65, 68, 20), (3008, 64, 16), (3008, 512, 100)])
+def test_gemm_nn(lib, M, N, K):
+    g = torch.Generator().manual_seed(M + N * 5 + K * 11)
+    A, Bm = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+    ref = A.double() @ Bm.double()
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    lib.call("ganffn_gemm_nn", ptr(dev(A)), ptr(dev(Bm)), ptr(Cd), M, N, K, stream())
+    assert rel_err(Cd, ref) < 2e-6 * max(1, K ** 0.5)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 100, 3008), (2048, 100, 3008), (100, 2048, 3008), (1536, 512, 282),
+                                   (100, 100, 14), (4, 4, 5), (68, 20, 65), (16, 64, 3008), (2048, 512, 6016)])
+def test_gemm_tn_acc(lib, M, N, K):
+    g = torch.Generator().manual_seed(M * 13 + N + K)
+    At, Bm = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    C0, s0 = torch.randn(M, N, generator=g), torch.randn(M, generator=g)
+    ref = C0.double() + At.double().T @ Bm.double()
+    refs = s0.double() + At.double().sum(0)
+    Cd, sd = dev(C0.clone()), dev(s0.clone())
+    lib.call("ganffn_gemm_tn_acc", ptr(dev(At)), ptr(dev(Bm)), ptr(Cd), ptr(sd), M, N, K, stream())
+    assert rel_err(Cd, ref) < 3e-6 * max(1, K ** 0.5)
+    assert rel_err(sd, refs) < 3e-6 * max(1, K ** 0.5)
+
+
+@pytest.mark.parametrize("R,Cn,p", [(3008, 2048, 0.1), (13, 100, 0.2), (7, 1, 0.2), (330, 512, 0.5)])
+def test_dropout_mask_matches_philox_contract(lib, R, Cn, p):
+    seed, off, add, site = 0x1234567890ABCDEF, 5, 3, 18
+    rng = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, off], dtype=torch.int64, device="cuda")
+    x = torch.ones(R, Cn, device="cuda")
+    y = torch.empty_like(x)
+    lib.call("ganffn_dropout", ptr(x), ptr(y), R, Cn, C.c_float(p), C.c_uint32(site), ptr(rng), C.c_uint64(add), stream())
+    keep = philox.keep_mask(R, Cn, p, site, seed, off + add)
+    got = y.cpu().numpy()
+    assert ((got != 0) == keep).all()
+    assert np.allclose(got[keep], np.float32(1.0) / (np.float32(1.0) - np.float32(p)), rtol=1e-6)
+
+
+ATTN_CASES = [(7, 2, 100, 10), (110, 3, 100, 10), (94, 4, 512, 8), (33, 2, 100, 10), (1, 1, 100, 10), (64, 2, 512, 8),
+              (32, 1, 100, 10), (96, 2, 100, 10), (97, 1, 512, 8)]
+
+
+@pytest.mark.parametrize("S,B,E,H", ATTN_CASES)
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_fwd_bwd(lib, S, B, E, H, p):
+    g = torch.Generator().manual_seed(S * 131 + B * 17 + E)
+    qkv = torch.randn(S, B, 3 * E, generator=g) * 1.5
+    do = torch.randn(S, B, E, generator=g)
+    seed, off, add, layer = 777, 11, 4, 2
+    site = O.SITE_LAYER0 + 4 * layer
+    # oracle (float64 for a tight reference; same Philox mask)
+    q64 = qkv.double().requires_grad_(True)
+    saved = O.ENC_DROPOUT
+    O.ENC_DROPOUT = p
+    try:
+        o_ref = O.attention(q64, B, H, layer, O.Rng(seed, off + add, train=p > 0))
+    finally:
+        O.ENC_DROPOUT = saved
+    (o_ref * do.double()).sum().backward()
+    rng = torch.tensor([seed, off], dtype=torch.int64, device="cuda")
+    qd, dod = dev(qkv), dev(do)
+    od = torch.full((S, B, E), float("nan"), device="cuda")
+    lib.call("ganffn_attention_fwd", ptr(qd), ptr(od), S, B, E, H, C.c_float(p), C.c_uint32(site), ptr(rng),
+             C.c_uint64(add), stream())
+    assert rel_err(od, o_ref.detach()) < 2e-5
+    dq = torch.full((S, B, 3 * E), float("nan"), device="cuda")
+    lib.call("ganffn_attention_bwd", ptr(qd), ptr(dod), ptr(dq), S, B, E, H, C.c_float(p), C.c_uint32(site), ptr(rng),
+             C.c_uint64(add), stream())
+    assert rel_err(dq, q64.grad) < 5e-5
+
+
+@pytest.mark.parametrize("T,E", [(3008, 100), (3008, 512), (14, 100), (5, 512), (331, 100)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_add_dropout_layernorm(lib, T, E, p):
+    g = torch.Generator().manual_seed(T + E)
+    x, y = torch.randn(T, E, generator=g) * 2 + 0.3, torch.randn(T, E, generator=g)
+    w, b = 1 + 0.1 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    dout = torch.randn(T, E, generator=g)
+    seed, off, add, site = 99, 3, 7, 21
+    keep = torch.from_numpy(philox.keep_mask(T, E, p, site, seed, off + add)).double() / (1 - p)
+    y64 = y.double().requires_grad_(True)
+    x64 = x.double().requires_grad_(True)
+    w64, b64 = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    out_ref = O.layer_norm(x64 + y64 * keep, w64, b64)
+    (out_ref * dout.double()).sum().backward()
+    rng = torch.tensor([seed, off], dtype=torch.int64, device="cuda")
+    out = torch.empty(T, E, device="cuda")
+    xhat = torch.empty(T, E, device="cuda")
+    rstd = torch.empty(T, device="cuda")
+    wd, bd = dev(w), dev(b)
+    lib.call("ganffn_add_dropout_layernorm_fwd", ptr(dev(x)), ptr(dev(y)), ptr(wd), ptr(bd), ptr(out), ptr(xhat), ptr(rstd),
+             T, E, C.c_float(1e-5), C.c_float(p), C.c_uint32(site), ptr(rng), C.c_uint64(add), stream())
+    assert rel_err(out, out_ref.detach()) < 5e-6
+    dz = torch.empty(T, E, device="cuda")
+    dy = torch.empty(T, E, device="cuda")
+    gw = torch.zeros(E, device="cuda")
+    gb = torch.zeros(E, device="cuda")
+    lib.call("ganffn_add_dropout_layernorm_bwd", ptr(dev(dout)), ptr(xhat), ptr(rstd), ptr(wd), ptr(dz), ptr(dy), ptr(gw),
+             ptr(gb), T, E, C.c_float(p), C.c_uint32(site), ptr(rng), C.c_uint64(add), stream())
+    assert rel_err(dz, x64.grad) < 2e-5
+    assert rel_err(dy, y64.grad) < 2e-5
+    assert rel_err(gw, w64.grad) < 2e-5
+    assert rel_err(gb, b64.grad) < 2e-5
+
+
+def test_pe_table(lib):
+    g = golden("misc")
+    for d in (100, 512):
+        pe = torch.empty(110, d, device="cuda")
+        lib.call("ganffn_pe_table", ptr(pe), 110, d, stream())
+        # device sinf/cosf/expf vs torch CPU: argument rounding at |a| ~ 100 gives ~1e-5 absolute
+        assert np.abs(pe.cpu().numpy() - g["pe/%d" % d]).max() < 3e-5
+
+
+def test_bce_edge_cases_and_backward(lib):
+    g = golden("misc")
+    p = torch.from_numpy(g["bce/probs"]).cuda()
+    n = p.numel()
+    for tgt in (0, 1):
+        loss = torch.zeros(1, device="cuda")
+        lib.call("ganffn_bce_fwd", ptr(p), C.c_float(tgt), n, C.c_float(1.0), ptr(loss), 0, stream())
+        ref = float(g["bce/target%d" % tgt])
+        assert abs(float(loss) - ref) <= 1e-5 * abs(ref)
+        # accumulate + scale: (a + b)/2 form used by the D loss
+        lib.call("ganffn_bce_fwd", ptr(p), C.c_float(tgt), n, C.c_float(0.5), ptr(loss), 0, stream())
+        lib.call("ganffn_bce_fwd", ptr(p), C.c_float(tgt), n, C.c_float(0.5), ptr(loss), 1, stream())
+        assert abs(float(loss) - ref) <= 1e-5 * abs(ref)
+    pp = torch.tensor([0.3, 0.9, 0.5, 1e-3, 0.999], requires_grad=True)
+    for tgt in (0.0, 1.0):
+        l = torch.nn.BCELoss()(pp, torch.full_like(pp, tgt))
+        (gr,) = torch.autograd.grad(l, pp)
+        d = torch.empty(5, device="cuda")
+        lib.call("ganffn_bce_bwd", ptr(pp.detach().cuda()), C.c_float(tgt), 5, C.c_float(1.0), ptr(d), stream())
+        assert rel_err(d, gr) < 1e-5
+
+
+def test_adam_matches_reference_fixture(lib):
+    g = golden("misc")
+    for tag, kw in (("gan", dict(lr=1e-4, b1=0.5, b2=0.6, wd=0.0)), ("phase2", dict(lr=1e-4, b1=0.9, b2=0.999, wd=0.008))):
+        w = torch.from_numpy(F_.formula_tensor("adam.w", (37, 11))).cuda().contiguous()
+        m, v = torch.zeros_like(w), torch.zeros_like(w)
+        step = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for s in range(3):
+            gr = torch.from_numpy(F_.formula_tensor("adam.g%d" % s, (37, 11))).cuda().contiguous()
+            lib.call("ganffn_adam_step", ptr(w), ptr(gr), ptr(m), ptr(v), ptr(step), C.c_int64(w.numel()),
+                     C.c_float(kw["lr"]), C.c_float(kw["b1"]), C.c_float(kw["b2"]), C.c_float(1e-8), C.c_float(kw["wd"]),
+                     C.c_float(1.0), stream())
+            ref = g["adam/%s/step%d" % (tag, s)]
+            assert np.abs(w.cpu().numpy() - ref).max() <= 3e-7
+        assert int(step) == 3
+
+
+def test_logsoftmax_nll_matches_reference_fixture(lib):
+    g = golden("misc")
+    lp_ref = torch.from_numpy(g["phase2/log_prob"])          # (S, B, 6)
+    S, B, Cn = lp_ref.shape
+    logits = (lp_ref + 0.37).cuda().contiguous()             # log_softmax is shift-invariant
+    labels = torch.from_numpy(g["phase2/label"]).cuda().contiguous()
+    umask = torch.from_numpy(g["phase2/umask"]).cuda().contiguous()
+    w = torch.tensor(O.CLASS_WEIGHTS, device="cuda")
+    for cw, key in ((w, "phase2/loss_weighted"), (None, "phase2/loss_unweighted")):
+        lp = torch.empty_like(logits)
+        loss = torch.zeros(1, device="cuda")
+        dl = torch.empty_like(logits)
+        ws2 = torch.zeros(2, device="cuda")
+        lib.call("ganffn_logsoftmax_nll", ptr(logits), ptr(labels), ptr(umask), ptr(cw), ptr(lp), ptr(loss), ptr(dl), ptr(ws2),
+                 S, B, Cn, stream())
+        assert np.abs(lp.cpu().numpy() - g["phase2/log_prob"]).max() < 2e-6
+        assert abs(float(loss) - float(g[key])) < 2e-6
+        x = logits.cpu().double().requires_grad_(True)
+        l = O.masked_nll(torch.log_softmax(x, 2), labels.cpu(), umask.cpu().double(), None if cw is None else cw.cpu().double())
+        l.backward()
+        assert rel_err(dl, x.grad) < 1e-5
