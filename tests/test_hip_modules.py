@@ -46,7 +46,7 @@ def test_module_matches_reference_fixture(case, shape):
             k = f[len(tag) + 6:].rsplit("/", 1)[0]
             assert sd[k].grad is not None, k
             # see tests/test_oracle_golden.py: one relu-kink flip moves summed grads by ~5e-4 of scale
-            check_summary(g, tag + "/grad/" + k, sd[k].grad, rtol=1e-3, atol=1e-7, what="hip")
+            check_summary(g, tag + "/grad/" + k, sd[k].grad, rtol=1e-3, atol=1e-7, what="hip", outlier_frac=0.10)
             n += 1
     assert n >= 12
     assert all(p.grad is None for k, p in sd.items() if k.startswith("encoder_layer."))

@@ -59,7 +59,8 @@ def test_gemm_nn(lib, M, N, K):
     A, Bm = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
     ref = A.double() @ Bm.double()
     Cd = torch.full((M, N), float("nan"), device="cuda")
-    lib.call("ganffn_gemm_nn", ptr(dev(A)), ptr(dev(Bm)), ptr(Cd), M, N, K, stream())
+    Ad, Bd = dev(A), dev(Bm)   # keep alive: a temporary would be freed (and its block reused) before the launch
+    lib.call("ganffn_gemm_nn", ptr(Ad), ptr(Bd), ptr(Cd), M, N, K, stream())
     assert rel_err(Cd, ref) < 2e-6 * max(1, K ** 0.5)
 
 
@@ -72,7 +73,8 @@ def test_gemm_tn_acc(lib, M, N, K):
     ref = C0.double() + At.double().T @ Bm.double()
     refs = s0.double() + At.double().sum(0)
     Cd, sd = dev(C0.clone()), dev(s0.clone())
-    lib.call("ganffn_gemm_tn_acc", ptr(dev(At)), ptr(dev(Bm)), ptr(Cd), ptr(sd), M, N, K, stream())
+    Ad, Bd = dev(At), dev(Bm)
+    lib.call("ganffn_gemm_tn_acc", ptr(Ad), ptr(Bd), ptr(Cd), ptr(sd), M, N, K, stream())
     assert rel_err(Cd, ref) < 3e-6 * max(1, K ** 0.5)
     assert rel_err(sd, refs) < 3e-6 * max(1, K ** 0.5)
 
@@ -141,15 +143,15 @@ def test_add_dropout_layernorm(lib, T, E, p):
     out = torch.empty(T, E, device="cuda")
     xhat = torch.empty(T, E, device="cuda")
     rstd = torch.empty(T, device="cuda")
-    wd, bd = dev(w), dev(b)
-    lib.call("ganffn_add_dropout_layernorm_fwd", ptr(dev(x)), ptr(dev(y)), ptr(wd), ptr(bd), ptr(out), ptr(xhat), ptr(rstd),
+    wd, bd, xd, yd, doutd = dev(w), dev(b), dev(x), dev(y), dev(dout)
+    lib.call("ganffn_add_dropout_layernorm_fwd", ptr(xd), ptr(yd), ptr(wd), ptr(bd), ptr(out), ptr(xhat), ptr(rstd),
              T, E, C.c_float(1e-5), C.c_float(p), C.c_uint32(site), ptr(rng), C.c_uint64(add), stream())
     assert rel_err(out, out_ref.detach()) < 5e-6
     dz = torch.empty(T, E, device="cuda")
     dy = torch.empty(T, E, device="cuda")
     gw = torch.zeros(E, device="cuda")
     gb = torch.zeros(E, device="cuda")
-    lib.call("ganffn_add_dropout_layernorm_bwd", ptr(dev(dout)), ptr(xhat), ptr(rstd), ptr(wd), ptr(dz), ptr(dy), ptr(gw),
+    lib.call("ganffn_add_dropout_layernorm_bwd", ptr(doutd), ptr(xhat), ptr(rstd), ptr(wd), ptr(dz), ptr(dy), ptr(gw),
              ptr(gb), T, E, C.c_float(p), C.c_uint32(site), ptr(rng), C.c_uint64(add), stream())
     assert rel_err(dz, x64.grad) < 2e-5
     assert rel_err(dy, y64.grad) < 2e-5
@@ -184,7 +186,8 @@ def test_bce_edge_cases_and_backward(lib):
         l = torch.nn.BCELoss()(pp, torch.full_like(pp, tgt))
         (gr,) = torch.autograd.grad(l, pp)
         d = torch.empty(5, device="cuda")
-        lib.call("ganffn_bce_bwd", ptr(pp.detach().cuda()), C.c_float(tgt), 5, C.c_float(1.0), ptr(d), stream())
+        ppd = pp.detach().cuda()
+        lib.call("ganffn_bce_bwd", ptr(ppd), C.c_float(tgt), 5, C.c_float(1.0), ptr(d), stream())
         assert rel_err(d, gr) < 1e-5
 
 
