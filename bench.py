@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — utterances/sec per GAN train step (BASELINE.json metric) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full batch of train_GAN's inner loop (/root/reference/train_IEMOCAP.py:322-382): the 12
+sub-steps (6x train_disc, 6x train_gen) with train-mode dropout, BCE, backward and Adam, on a synthetic
+IEMOCAP-schema batch of 32 dialogues per GPU padded to S = 94 (BASELINE.json configs[1]).  Weak scaling:
+every rank owns its own 32 dialogues; gradients are all-reduced (RCCL) per sub-step.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK = 157.3e12      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+# algorithmic FLOPs of one iteration per padded token at S = 94: fwd 409.5 + bwd 544.8 MFLOP
+FLOP_PER_TOKEN_ITER = 954.3e6
+
+
+def flops_per_token(S):
+    """reference-equivalent FLOPs per padded token per iteration (fwd + 2x bwd), SURVEY.md §8d formulas."""
+    F = 2048
+
+    def layer(E):
+        return 8 * E * E + 4 * S * E + 4 * E * F
+    G100 = 8 * layer(100) + 2 * (100 * 512 + 512 * 100)
+    G512 = 8 * layer(512) + 2 * (512 * 1024 + 1024 * 100)
+    D = 8 * layer(100) + 2 * (100 * 64 + 64 * 16 + 16)
+    OBJ = 2 * 512 * 100
+    fwd = 18 * D + 8 * G100 + 4 * G512 + 2 * OBJ
+    bwd = 2 * (18 * D + 4 * G100 + 2 * G512 + 2 * OBJ)
+    return fwd + bwd
+
+
+def time_dominant_kernel(S, B, reps=30):
+    """Live HIP-event timing of the dominant kernel on the stream it is launched on (torch's current stream):
+    the FFN linear1 forward GEMM of the batched discriminator pass, M = S*2B tokens, N = 2048, K = 100,
+    with its fused bias + ReLU + Philox-dropout epilogue.  Returns (avg seconds per launch, flops per launch)."""
+    from gan_ffn_amd import _lib, ops
+    M, N, K = S * 2 * B, 2048, 100
+    a = torch.rand(M, K, device="cuda")
+    w = torch.rand(N, K, device="cuda") - 0.5
+    b = torch.rand(N, device="cuda")
+    c = torch.empty(M, N, device="cuda")
+    st = ops._stream()
+
+    def launch():
+        _lib.call("ganffn_gemm_nt", ops._ptr(a), ops._ptr(w), ops._ptr(b), ops._ptr(c), M, N, K, st)
+    for _ in range(5):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps, 2.0 * M * N * K
+
+
+def cpu_baseline(S, B_sample, threads):
+    """Stock-PyTorch CPU execution (oracle/stock_modules.py: nn.TransformerEncoder stacks, train-mode dropout,
+    the reference's sub-step logic) of ONE full 12-sub-step iteration on a bounded sample: B_sample dialogues of
+    the same S.  Returns (utterances/s, seconds, real utterances)."""
+    from gan_ffn_amd import data as D
+    from oracle import stock_modules as SM
+    from oracle.ganffn_oracle import SCHEDULE
+    torch.set_num_threads(threads)
+    torch.manual_seed(3407)
+    gens, discs, opts = SM.build_stock()
+    batch = D.synthetic_batch(B=B_sample, S_max=S, seed=3407, device="cpu")
+    # tiny warm-up (thread pools, allocator): one D sub-step on 2 dialogues
+    wb = {k: batch[k][:, :2].contiguous() for k in ("text", "visual", "acoustic")}
+    SM.stock_gan_iteration(gens, discs, opts, wb, SCHEDULE[:1])
+    t0 = time.perf_counter()
+    SM.stock_gan_iteration(gens, discs, opts, batch, SCHEDULE)
+    dt = time.perf_counter() - t0
+    utts = float(batch["umask"].sum())
+    return utts / dt, dt, utts
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="dialogues per GPU (reference hard-codes 32, train_IEMOCAP.py:603)")
+    ap.add_argument("--seq", type=int, default=94, help="padded dialogue length S (model.py:1437)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; the hot path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        pg = dist.group.WORLD
+
+    from gan_ffn_amd import _lib, engine, ops
+    from gan_ffn_amd import data as D
+    _lib.load()
+
+    gens, discs = engine.build_networks(device=dev, seed=3407)       # random init of the reference architecture
+    if world > 1:
+        import torch.distributed as dist
+        for d in (gens, discs):
+            for m in d.values():
+                dist.broadcast(m.slab, src=0)                        # replicated parameters
+    ops.manual_seed(3407 + 1000 * rank, dev)                          # rank-offset dropout streams
+    batch = D.synthetic_batch(B=args.batch, S_max=args.seq, seed=3407 + rank, device=dev)
+    S, B = batch["text"].shape[:2]
+    use_graph = (not args.no_graph) and world == 1
+    eng = engine.GanEngine(gens, discs, process_group=pg, use_graph=use_graph)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.iteration(batch)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.iteration(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    losses = eng.loss_dict()
+
+    utts = torch.tensor([float(batch["umask"].sum()), dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+        tmax = utts[1:2].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        usum = utts[0:1].clone()
+        dist.all_reduce(usum, op=dist.ReduceOp.SUM)
+        dt, total_utts = float(tmax), float(usum)
+    else:
+        total_utts = float(utts[0])
+    ms_per_step = dt / args.steps * 1e3
+    value = total_utts * args.steps / dt
+
+    if rank == 0:
+        kt, kflop = time_dominant_kernel(S, B)
+        fpt = flops_per_token(S)
+        step_tflops = fpt * S * B * world * args.steps / dt / 1e12
+        out = {
+            "metric": "utterances/sec per GAN train step, IEMOCAP tri-modal",
+            "value": round(value, 2), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "IEMOCAP tri-modal batch=32 fp32 on 1xMI355X, full G+D step "
+                                   "(12 sub-steps: 6 train_disc + 6 train_gen, train-mode dropout, BCE, Adam)",
+                       "dialogues_per_gpu": B, "seq_len": S, "real_utterances_per_gpu_batch": float(batch["umask"].sum()),
+                       "padded_tokens_per_s": round(S * B * world * args.steps / dt, 1),
+                       "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager",
+                       "step_tflops_reference_equivalent": round(step_tflops, 2),
+                       "step_frac_of_fp32_mfma_peak": round(step_tflops * 1e12 / (FP32_MFMA_PEAK * world), 4),
+                       "last_losses": {k: round(v, 4) for k, v in losses.items()}},
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<NT,RELU_DROP> FFN linear1 fwd M=%d N=2048 K=100" % (S * 2 * B),
+                         "achieved": round(kflop / kt / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                         "frac": round(kflop / kt / FP32_MFMA_PEAK, 4), "traffic": None,
+                         "avg_kernel_us": round(kt * 1e6, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except Exception:
+                pass
+            cv, cdt, cutts = cpu_baseline(S, args.cpu_sample_batch, threads)
+            out["cpu_baseline"] = {"value": round(cv, 2), "unit": "utterances/s", "cores": threads, "kind": "port",
+                                   "sample": "1 full 12-sub-step iteration, stock PyTorch CPU nn.TransformerEncoder "
+                                             "stacks (oracle/stock_modules.py), train-mode dropout, %d dialogues "
+                                             "padded to S=%d (%d real utterances), %.1f s" %
+                                             (args.cpu_sample_batch, S, int(cutts), cdt)}
+            out["config"]["gpu_over_cpu"] = round(value / cv, 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

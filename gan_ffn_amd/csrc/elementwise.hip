@@ -284,11 +284,15 @@ __global__ __launch_bounds__(256) void disc_tail_bwd_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------
 // A10: BCELoss(mean)     torch.nn.BCELoss semantics (log clamped at -100)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ prob, float target, int n, float scale,
-                                                      float* __restrict__ loss) {
+// target of element i: (i % period) < split ? target : target_b   (period 0: constant `target`).
+// The batched discriminator pass holds [real | fake] dialogues side by side in the batch axis, so one
+// call with period 2B, split B yields (BCE(real,1) + BCE(fake,0)) / 2 = the D loss (train_IEMOCAP.py:220-223).
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ prob, float target_a, float target_b,
+                                                      int period, int split, int n, float scale, float* __restrict__ loss) {
     __shared__ float red[4];
     float s = 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float target = (period > 0 && (i % period) >= split) ? target_b : target_a;
         const float p = prob[i];
         const float lp = fmaxf(logf(p), -100.f);
         const float l1p = fmaxf(logf(1.0f - p), -100.f);
@@ -300,9 +304,11 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * scale / (float)n);
 }
 
-__global__ void bce_bwd_kernel(const float* __restrict__ prob, float target, int n, float scale, float* __restrict__ dprob) {
+__global__ void bce_bwd_kernel(const float* __restrict__ prob, float target_a, float target_b, int period, int split, int n,
+                               float scale, float* __restrict__ dprob) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const float target = (period > 0 && (i % period) >= split) ? target_b : target_a;
     const float p = prob[i];
     dprob[i] = scale / (float)n * (p - target) / fmaxf(p * (1.0f - p), 1e-12f);
 }
@@ -565,7 +571,15 @@ extern "C" int ganffn_pe_table(float* pe, int max_len, int E, void* stream) {
 
 extern "C" int ganffn_bce_fwd(const float* prob, float target, int n, float scale, float* loss_out, int accumulate,
                               void* stream) {
-    GF_CHECK_ARG(prob && loss_out && n > 0, "bce_fwd: bad arguments");
+    return ganffn_bce2_fwd(prob, target, target, 0, 0, n, scale, loss_out, accumulate, stream);
+}
+extern "C" int ganffn_bce_bwd(const float* prob, float target, int n, float scale, float* dprob, void* stream) {
+    return ganffn_bce2_bwd(prob, target, target, 0, 0, n, scale, dprob, stream);
+}
+
+extern "C" int ganffn_bce2_fwd(const float* prob, float target_a, float target_b, int period, int split, int n, float scale,
+                               float* loss_out, int accumulate, void* stream) {
+    GF_CHECK_ARG(prob && loss_out && n > 0 && period >= 0 && split >= 0, "bce_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) {
         hipError_t e = hipMemsetAsync(loss_out, 0, sizeof(float), st);
@@ -573,14 +587,15 @@ extern "C" int ganffn_bce_fwd(const float* prob, float target, int n, float scal
     }
     int blocks = (n + 255) / 256;
     if (blocks > 64) blocks = 64;
-    hipLaunchKernelGGL(bce_fwd_kernel, dim3(blocks), dim3(256), 0, st, prob, target, n, scale, loss_out);
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(blocks), dim3(256), 0, st, prob, target_a, target_b, period, split, n, scale, loss_out);
     GF_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int ganffn_bce_bwd(const float* prob, float target, int n, float scale, float* dprob, void* stream) {
-    GF_CHECK_ARG(prob && dprob && n > 0, "bce_bwd: bad arguments");
-    hipLaunchKernelGGL(bce_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, prob, target, n, scale, dprob);
+extern "C" int ganffn_bce2_bwd(const float* prob, float target_a, float target_b, int period, int split, int n, float scale,
+                               float* dprob, void* stream) {
+    GF_CHECK_ARG(prob && dprob && n > 0 && period >= 0 && split >= 0, "bce_bwd: bad arguments");
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, prob, target_a, target_b, period, split, n, scale, dprob);
     GF_LAUNCH_CHECK();
     return 0;
 }

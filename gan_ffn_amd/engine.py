@@ -1,0 +1,341 @@
+"""Fast step runner: the counterpart of the reference's train_disc / train_gen / train_GAN
+(/root/reference/train_IEMOCAP.py:200-393), driving libganffn.so directly.
+
+Differences from running the nn.Module mirror under torch autograd — all result-preserving:
+  * no autograd graph: forward/backward are explicit C-ABI calls on preallocated buffers;
+  * train_disc evaluates D(real) and D(fake) as ONE pass over a [real | fake] batch of 2B dialogues
+    (dialogues are independent in every op; loss = ganffn_bce2 = (BCE(real,1)+BCE(fake,0))/2);
+  * the generator forward inside train_disc keeps nothing for backward (the reference builds and
+    discards that graph, train_IEMOCAP.py:218-219);
+  * train_gen skips the frozen discriminator's weight gradients (computed but never used by the
+    reference: zero_grad at train_IEMOCAP.py:216 clears them before D's next step);
+  * losses stay on the device; the host reads all 12 once per iteration instead of 12 syncs
+    (train_IEMOCAP.py:224,249);
+  * gradients, Adam moments and parameters are flat slabs -> one fused Adam launch and, with
+    world_size > 1, a bucketed all-reduce (RCCL) per sub-step;
+  * optionally the whole iteration is captured once into a hipGraph and replayed (launch-bound otherwise).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+from ._lib import HeadCfg
+
+# sub-step schedule of one batch, train_IEMOCAP.py:355-382: (kind, trained net, partner net)
+SCHEDULE = [
+    ("D", "visual", "acoustic"), ("G", "acoustic", "visual"),
+    ("D", "visual", "text"), ("G", "text", "visual"),
+    ("D", "text", "acoustic"), ("G", "acoustic", "text"),
+    ("D", "acoustic", "text"), ("G", "text", "acoustic"),
+    ("D", "text", "visual"), ("G", "visual", "text"),
+    ("D", "acoustic", "visual"), ("G", "visual", "acoustic"),
+]
+LOSS_COLUMNS = ["acoustic_G_loss", "visual_G_loss", "text_G_loss", "visual_D_loss", "text_D_loss",
+                "acoustic_D_loss"]  # train_IEMOCAP.py:308-316
+
+
+class NetState:
+    """One network on the device: parameter slab (shared with the nn.Module), gradient slab, Adam state."""
+
+    def __init__(self, module, lr, betas, weight_decay=0.0):
+        self.m = module
+        self.slab = module.slab
+        assert self.slab.is_cuda, "NetState needs the module on the GPU"
+        total, views, enc = module.slab_layout()
+        self.total, self.views, self.enc_floats = total, views, enc
+        self.grad = torch.zeros_like(self.slab)
+        self.exp_avg = torch.zeros_like(self.slab)
+        self.exp_avg_sq = torch.zeros_like(self.slab)
+        self.step = torch.zeros(1, dtype=torch.int32, device=self.slab.device)
+        self.lr, self.betas, self.wd = lr, betas, weight_decay
+        self.E, self.H, self.L = module.d_model, module.nhead, module.num_layers
+        self.kind = 0 if module.KIND == "gen" else 1
+        named = {}
+        params = module._slab_params()
+        names = {id(p): n for n, p in module.named_parameters()}
+        for p, (off, shape) in zip(params, views):
+            named[names[id(p)]] = (off, shape)
+        self.named = named
+        self.pe = module.position_encoding.pe
+        self.p_head = float(module.dropout.p)
+        self.p_pe = float(module.position_encoding.dropout.p)
+        self.p_enc = float(module.transformer_encoder.enc_dropout)
+        self.D1 = module.fc1.weight.shape[0]
+        self.D2 = module.fc2.weight.shape[0]
+        self.layer_floats = enc // self.L
+        self.obj_floats = (512 * 100 + 100) if module.HAS_OBJECT else 0   # `object` sits right after the layers
+
+    def w(self, name, grad=False):
+        off, shape = self.named[name]
+        n = 1
+        for d in shape:
+            n *= d
+        return (self.grad if grad else self.slab)[off:off + n]
+
+    def buckets(self, n_buckets):
+        """[(lo, hi)] float ranges of the grad slab, in the order backward completes them:
+        head (+object) first, then encoder layers from the last to the first."""
+        enc = self.enc_floats
+        out = [(enc + self.obj_floats, self.total)]   # fc1..fc3 (object's grad is produced last, reduced separately)
+        per = max(1, (self.L + n_buckets - 1) // max(1, n_buckets))
+        hi = self.L
+        while hi > 0:
+            lo = max(0, hi - per)
+            out.append((lo * self.layer_floats, hi * self.layer_floats))
+            hi = lo
+        return out
+
+
+class _Pass:
+    """Buffers of one forward(+backward) pass of one network at a fixed (S, B)."""
+
+    def __init__(self, net, S, B, dev, need_bwd):
+        self.S, self.B, self.T = S, B, S * B
+        E = net.E
+        self.cfg_train = ops.enc_cfg(S, B, E, net.H, net.L, train=True, p_pe=net.p_pe, p_enc=net.p_enc)
+        self.cfg_eval = ops.enc_cfg(S, B, E, net.H, net.L, train=False, p_pe=net.p_pe, p_enc=net.p_enc)
+        n_saved, n_ws = ops.enc_sizes(self.cfg_train)
+        self.hcfg_train = HeadCfg(self.T, E, net.D1, net.D2, net.kind, net.p_head, 1)
+        self.hcfg_eval = HeadCfg(self.T, E, net.D1, net.D2, net.kind, net.p_head, 0)
+        h_saved, h_ws = ops.head_sizes(self.hcfg_train)
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.enc_out = torch.empty(S, B, E, **f32)
+        self.saved = torch.empty(n_saved, **f32) if need_bwd else None
+        self.hsaved = torch.empty(h_saved, **f32)
+        self.out = torch.empty(S, B, net.D2 if net.kind == 0 else 1, **f32)
+        self.dx = torch.empty(S, B, E, **f32) if need_bwd else None
+        self.n_ws = max(n_ws, h_ws)
+
+
+class GanEngine:
+    """train_GAN's inner loop (train_IEMOCAP.py:320-382) for a fixed batch shape."""
+
+    def __init__(self, gens, discs, lr=1e-4, b1=0.5, b2=0.6, process_group=None, n_buckets=3, use_graph=False):
+        # optimizers: train_IEMOCAP.py:292-297 (G lr, text-G 1.1*lr, every D lr/2); call site :603-606
+        self.G = {k: NetState(m, lr * (1.1 if k == "text" else 1.0), (b1, b2)) for k, m in gens.items()}
+        self.D = {k: NetState(m, lr / 2, (b1, b2)) for k, m in discs.items()}
+        self.dev = next(iter(self.G.values())).slab.device
+        self.rng = ops.DeviceRng.get(self.dev)
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+        self.n_buckets = n_buckets
+        self.use_graph = use_graph
+        self._shape = None
+        self._graph = None
+        self.losses = torch.zeros(12, device=self.dev)
+        self._adds = 0
+
+    # ------------------------------------------------------------------------------------------
+    def _prepare(self, S, B):
+        if self._shape == (S, B):
+            return
+        self._shape = (S, B)
+        self._graph = None
+        dev = self.dev
+        self.pass_G_nosave = {k: _Pass(n, S, B, dev, False) for k, n in self.G.items()}
+        self.pass_G = {k: _Pass(n, S, B, dev, True) for k, n in self.G.items()}
+        self.pass_D2 = {k: _Pass(n, S, 2 * B, dev, True) for k, n in self.D.items()}   # [real | fake]
+        self.pass_D1 = {k: _Pass(n, S, B, dev, True) for k, n in self.D.items()}       # frozen D in train_gen
+        n_ws = max(p.n_ws for d in (self.pass_G, self.pass_D2, self.pass_D1, self.pass_G_nosave) for p in d.values())
+        self.ws = torch.empty(n_ws, device=dev, dtype=torch.float32)
+        self.x_cat = torch.empty(S, 2 * B, 100, device=dev, dtype=torch.float32)
+        self.obj_out = torch.empty(S, B, 100, device=dev, dtype=torch.float32)
+        self.dprob2 = torch.empty(S, 2 * B, 1, device=dev, dtype=torch.float32)
+        self.dprob1 = torch.empty(S, B, 1, device=dev, dtype=torch.float32)
+        self.d_real = torch.empty(S, B, 100, device=dev, dtype=torch.float32)
+        self.static_batch = None
+
+    def _next_add(self):
+        v = self._adds
+        self._adds += 1
+        return v
+
+    # ------------------------------------------------------------------------------------------
+    def _net_fwd(self, net, ps, x, train, save):
+        """encoder + head forward into ps.out; returns (enc_add, head_add) rng offsets used."""
+        cfg = ps.cfg_train if train else ps.cfg_eval
+        hcfg = ps.hcfg_train if train else ps.hcfg_eval
+        a0, a1 = self._next_add(), self._next_add()
+        ops.encoder_fwd_raw(cfg, x, net.pe, net.slab, ps.enc_out, ps.saved if save else None, self.ws, self.rng.state, a0)
+        w = net.w
+        w3 = w("fc3.weight") if net.kind == 1 else None
+        b3 = w("fc3.bias") if net.kind == 1 else None
+        ops.head_fwd_raw(hcfg, ps.enc_out, w("fc1.weight"), w("fc1.bias"), w("fc2.weight"), w("fc2.bias"), w3, b3,
+                         ps.out, ps.hsaved, self.ws, self.rng.state, a1)
+        return a0, a1
+
+    def _net_bwd(self, net, ps, d_out, train, adds, want_wgrad, reduce_cb=None):
+        """head + encoder backward; ps.dx <- dL/d(network input).  Weight grads accumulate into net.grad."""
+        cfg = ps.cfg_train if train else ps.cfg_eval
+        hcfg = ps.hcfg_train if train else ps.hcfg_eval
+        a0, a1 = adds
+        w = net.w
+        g = (lambda n: net.w(n, grad=True)) if want_wgrad else (lambda n: None)
+        w3 = w("fc3.weight") if net.kind == 1 else None
+        ops.head_bwd_raw(hcfg, d_out, ps.enc_out, w("fc1.weight"), w("fc2.weight"), w3,
+                         g("fc1.weight"), g("fc1.bias"), g("fc2.weight"), g("fc2.bias"),
+                         g("fc3.weight") if net.kind == 1 else None, g("fc3.bias") if net.kind == 1 else None,
+                         ps.dx, ps.hsaved, self.ws, self.rng.state, a1)
+        gslab = net.grad if want_wgrad else None
+        if reduce_cb is None or not want_wgrad:
+            ops.encoder_bwd_raw(cfg, 0, net.L, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0)
+        else:
+            # bucketed: backward a group of layers, then hand that slice of the grad slab to the all-reduce
+            bks = net.buckets(self.n_buckets)
+            reduce_cb(*bks[0], last=False)                       # head (+object handled by caller before this)
+            for i, (lo_f, hi_f) in enumerate(bks[1:]):
+                lo, hi = lo_f // net.layer_floats, hi_f // net.layer_floats
+                ops.encoder_bwd_raw(cfg, lo, hi, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0)
+                reduce_cb(lo_f, hi_f, last=(i == len(bks) - 2))
+
+    def _adam(self, net):
+        ops.adam_step_raw(net.slab, net.grad, net.exp_avg, net.exp_avg_sq, net.step, net.total, net.lr,
+                          net.betas[0], net.betas[1], 1e-8, net.wd, 1.0 / self.world)
+
+    def _make_reducer(self, net):
+        """returns (callback, finish): async all-reduce (sum) of grad-slab slices on RCCL's own stream,
+        overlapping the rest of backward; Adam divides by world (grad_scale)."""
+        if self.world == 1:
+            return None, (lambda: None)
+        import torch.distributed as dist
+        works = []
+
+        def cb(lo, hi, last):
+            works.append(dist.all_reduce(net.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+        def finish():
+            for wk in works:
+                wk.wait()
+        return cb, finish
+
+    # ------------------------------------------------------------------------------------------
+    def train_disc(self, who, partner, batch, loss_slot):
+        """train_IEMOCAP.py:200-227."""
+        S, B = batch["text"].shape[:2]
+        Dn, Gn = self.D[who], self.G[partner]
+        pg_, pd = self.pass_G_nosave[partner], self.pass_D2[who]
+        # fusion = G(real_gen) in eval mode, nothing saved (detach(), :218-219)
+        self._net_fwd(Gn, pg_, batch[partner], train=False, save=False)
+        # real input of D_m is raw modality m; VisualDiscriminator maps 512 -> 100 first (model.py:1355-1356)
+        x_real = batch[who]
+        if who == "visual":
+            ops.linear_fwd_raw(x_real, Dn.w("object.weight"), Dn.w("object.bias"), self.obj_out, S * B, 512, 100)
+            x_real = self.obj_out
+        torch.cat((x_real, pg_.out), dim=1, out=self.x_cat)
+        adds = self._net_fwd(Dn, pd, self.x_cat, train=True, save=True)
+        n = S * 2 * B
+        ops._lib.call("ganffn_bce2_fwd", ops._ptr(pd.out), C.c_float(1.0), C.c_float(0.0), 2 * B, B, n, C.c_float(1.0),
+                      ops._ptr(self.losses[loss_slot:loss_slot + 1]), 0, ops._stream())
+        ops._lib.call("ganffn_bce2_bwd", ops._ptr(pd.out), C.c_float(1.0), C.c_float(0.0), 2 * B, B, n, C.c_float(1.0),
+                      ops._ptr(self.dprob2), ops._stream())
+        Dn.grad.zero_()                                              # opt.zero_grad(), :216
+        cb, finish = self._make_reducer(Dn)
+        self._net_bwd(Dn, pd, self.dprob2, True, adds, True, cb)
+        if who == "visual":
+            self.d_real.copy_(pd.dx[:, :B])                      # gradient of the real half of the batch
+            ops.linear_bwd_raw(self.d_real, batch[who], Dn.w("object.weight"), None, Dn.w("object.weight", True),
+                               Dn.w("object.bias", True), S * B, 512, 100)
+            if cb is not None:
+                cb(Dn.enc_floats, Dn.enc_floats + Dn.obj_floats, last=True)
+        finish()
+        self._adam(Dn)
+
+    def train_gen(self, who, partner, batch, loss_slot):
+        """train_IEMOCAP.py:230-252."""
+        S, B = batch["text"].shape[:2]
+        Gn, Dn = self.G[who], self.D[partner]
+        pg_, pd = self.pass_G[who], self.pass_D1[partner]
+        g_adds = self._net_fwd(Gn, pg_, batch[who], train=True, save=True)
+        d_adds = self._net_fwd(Dn, pd, pg_.out, train=False, save=True)       # disc.eval(), :243
+        n = S * B
+        ops.bce_fwd_raw(pd.out, 1.0, n, 1.0, self.losses[loss_slot:loss_slot + 1], False)
+        ops.bce_bwd_raw(pd.out, 1.0, n, 1.0, self.dprob1)
+        self._net_bwd(Dn, pd, self.dprob1, False, d_adds, False)             # through the frozen D: dgrad only
+        Gn.grad.zero_()
+        cb, finish = self._make_reducer(Gn)
+        self._net_bwd(Gn, pg_, pd.dx, True, g_adds, True, cb)
+        finish()
+        self._adam(Gn)
+
+    # ------------------------------------------------------------------------------------------
+    def _iteration_body(self, batch):
+        self._adds = 0
+        for i, (kind, who, partner) in enumerate(SCHEDULE):
+            if kind == "D":
+                self.train_disc(who, partner, batch, i)
+            else:
+                self.train_gen(who, partner, batch, i)
+        ops.rng_advance_raw(self.rng.state, self._adds)
+
+    def iteration(self, batch):
+        """One batch = 12 sub-steps.  Returns the device tensor of the 12 sub-step losses (no host sync)."""
+        S, B = batch["text"].shape[:2]
+        self._prepare(S, B)
+        if not self.use_graph:
+            self._iteration_body(batch)
+            return self.losses
+        if self.static_batch is None:
+            self.static_batch = {k: batch[k].clone() for k in ("text", "visual", "acoustic")}
+        else:
+            for k in self.static_batch:
+                self.static_batch[k].copy_(batch[k])
+        if self._graph is None:
+            # warm up on a side stream (allocations, lazy module init), then capture
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._iteration_body(self.static_batch)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._iteration_body(self.static_batch)
+        self._graph.replay()
+        return self.losses
+
+    def loss_dict(self):
+        """host copy of the last iteration's losses under the reference's column names (last value per key,
+        as train_IEMOCAP.py:355-382 keeps)."""
+        v = self.losses.tolist()
+        out = {}
+        for (kind, who, _), x in zip(SCHEDULE, v):
+            out["%s_%s_loss" % (who, kind)] = x
+        return out
+
+
+def build_networks(D_h=100, dropout=0.2, device="cuda", seed=None):
+    """the six networks as train_IEMOCAP.py:580-585 builds them"""
+    from . import model
+    if seed is not None:
+        torch.manual_seed(seed)
+    discs = {"acoustic": model.AcousticDiscriminator(D_h, dropout=dropout),
+             "visual": model.VisualDiscriminator(D_h, dropout=dropout),
+             "text": model.TextDiscriminator(D_h, dropout=dropout)}
+    gens = {"acoustic": model.AcousticGenerator(D_h, dropout=dropout),
+            "visual": model.VisualGenerator(D_h, dropout=dropout),
+            "text": model.TextGenerator(D_h, dropout=dropout)}
+    for d in (gens, discs):
+        for k in d:
+            d[k] = d[k].to(device)
+    return gens, discs
+
+
+def train_GAN(gens, discs, batches, epochs=1, lr=1e-4, b1=0.5, b2=0.6, process_group=None, use_graph=False, log=None):
+    """Counterpart of train_GAN (train_IEMOCAP.py:255-393) over an iterable of batches per epoch.
+    Returns rows of the GAN_loss table (columns train_IEMOCAP.py:308-316): last batch of each epoch."""
+    eng = GanEngine(gens, discs, lr, b1, b2, process_group, use_graph=use_graph)
+    rows = []
+    for epoch in range(epochs):
+        last = None
+        for batch in batches:
+            eng.iteration(batch)
+            last = eng.loss_dict()
+            if log:
+                log(epoch, last)
+        if last is not None:
+            rows.append(dict(epoch=epoch, **{c: last[c] for c in LOSS_COLUMNS}))
+    return rows

@@ -136,6 +136,13 @@ int ganffn_bce_fwd(const float* prob, float target, int n, float scale, float* l
                    int accumulate, void* stream);
 /* dprob[i] = scale/n * (p - y) / max(p*(1-p), 1e-12)   (torch's binary_cross_entropy_backward) */
 int ganffn_bce_bwd(const float* prob, float target, int n, float scale, float* dprob, void* stream);
+/* Two-valued periodic target: y_i = (i % period) < split ? target_a : target_b.  train_disc's loss
+ * (BCE(D(real),1) + BCE(D(fake),0)) / 2 (train_IEMOCAP.py:220-223) is ONE call on the batched
+ * [real | fake] pass (batch axis 2B: period 2B, split B, target_a 1, target_b 0, scale 1). */
+int ganffn_bce2_fwd(const float* prob, float target_a, float target_b, int period, int split, int n,
+                    float scale, float* loss_out, int accumulate, void* stream);
+int ganffn_bce2_bwd(const float* prob, float target_a, float target_b, int period, int split, int n,
+                    float scale, float* dprob, void* stream);
 
 /* ---- A10: Adam over a flat slab (train_IEMOCAP.py:292-297; phase 2 :661) ------------- */
 /* step: device int32 counter, incremented by this call BEFORE use (t = ++*step).
