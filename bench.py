@@ -85,10 +85,29 @@ def cpu_baseline(S, B_sample, threads):
     wb = {k: batch[k][:, :2].contiguous() for k in ("text", "visual", "acoustic")}
     SM.stock_gan_iteration(gens, discs, opts, wb, SCHEDULE[:1])
     t0 = time.perf_counter()
-    SM.stock_gan_iteration(gens, discs, opts, batch, SCHEDULE)
+    for i, step in enumerate(SCHEDULE):            # one sub-step at a time so progress is visible
+        SM.stock_gan_iteration(gens, discs, opts, batch, [step])
+        print("[bench] cpu_baseline sub-step %d/12 done at %.1f s" % (i + 1, time.perf_counter() - t0), file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
     utts = float(batch["umask"].sum())
     return utts / dt, dt, utts
+
+
+def host_threads():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota (a 1-GPU box
+    exposes many cores but grants a 16-core share)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("GANFFN_CPU_THREADS", "16"))))
 
 
 def main():
@@ -100,7 +119,7 @@ def main():
     ap.add_argument("--seq", type=int, default=94, help="padded dialogue length S (model.py:1437)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    ap.add_argument("--cpu-sample-batch", type=int, default=16)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,9 +131,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    force_dist = os.environ.get("GANFFN_FORCE_DIST", "0") == "1"   # exercise the RCCL path on a single GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
 
@@ -123,7 +144,7 @@ def main():
     _lib.load()
 
     gens, discs = engine.build_networks(device=dev, seed=3407)       # random init of the reference architecture
-    if world > 1:
+    if pg is not None:
         import torch.distributed as dist
         for d in (gens, discs):
             for m in d.values():
@@ -131,12 +152,12 @@ def main():
     ops.manual_seed(3407 + 1000 * rank, dev)                          # rank-offset dropout streams
     batch = D.synthetic_batch(B=args.batch, S_max=args.seq, seed=3407 + rank, device=dev)
     S, B = batch["text"].shape[:2]
-    use_graph = (not args.no_graph) and world == 1
+    use_graph = (not args.no_graph) and pg is None
     eng = engine.GanEngine(gens, discs, process_group=pg, use_graph=use_graph)
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if pg is not None:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
@@ -152,7 +173,7 @@ def main():
     losses = eng.loss_dict()
 
     utts = torch.tensor([float(batch["umask"].sum()), dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if pg is not None:
         import torch.distributed as dist
         tmax = utts[1:2].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -163,6 +184,9 @@ def main():
         total_utts = float(utts[0])
     ms_per_step = dt / args.steps * 1e3
     value = total_utts * args.steps / dt
+    if rank == 0:
+        print("[bench] gpu: %.3f ms/step, %.1f utterances/s (%s)" % (ms_per_step, value, "hipGraph" if use_graph else "eager"),
+              file=sys.stderr, flush=True)
 
     if rank == 0:
         kt, kflop = time_dominant_kernel(S, B)
@@ -187,11 +211,7 @@ def main():
                          "avg_kernel_us": round(kt * 1e6, 2)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
-            try:
-                threads = len(os.sched_getaffinity(0))
-            except Exception:
-                pass
+            threads = host_threads()
             cv, cdt, cutts = cpu_baseline(S, args.cpu_sample_batch, threads)
             out["cpu_baseline"] = {"value": round(cv, 2), "unit": "utterances/s", "cores": threads, "kind": "port",
                                    "sample": "1 full 12-sub-step iteration, stock PyTorch CPU nn.TransformerEncoder "
@@ -200,7 +220,7 @@ def main():
                                              (args.cpu_sample_batch, S, int(cutts), cdt)}
             out["config"]["gpu_over_cpu"] = round(value / cv, 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg is not None:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -76,15 +76,43 @@ class NetState:
     def buckets(self, n_buckets):
         """[(lo, hi)] float ranges of the grad slab, in the order backward completes them:
         head (+object) first, then encoder layers from the last to the first."""
-        enc = self.enc_floats
-        out = [(enc + self.obj_floats, self.total)]   # fc1..fc3 (object's grad is produced last, reduced separately)
-        per = max(1, (self.L + n_buckets - 1) // max(1, n_buckets))
-        hi = self.L
-        while hi > 0:
-            lo = max(0, hi - per)
-            out.append((lo * self.layer_floats, hi * self.layer_floats))
-            hi = lo
-        return out
+        return bucket_ranges(self.enc_floats, self.obj_floats, self.total, self.layer_floats, self.L, n_buckets)
+
+
+class GradReducer:
+    """Bucketed gradient all-reduce for data parallelism over the DIALOGUE axis (one process per GPU).
+    Each call sums one contiguous slice of a gradient slab across ranks, asynchronously (on RCCL's own
+    stream for the nccl backend), so it overlaps whatever backward work is enqueued next; finish()
+    makes the current stream wait for all of them.  The 1/world factor is applied by Adam (grad_scale).
+    Backend-agnostic (nccl on MI355X, gloo in the CPU tests)."""
+
+    def __init__(self, process_group):
+        import torch.distributed as dist
+        self.dist, self.pg = dist, process_group
+        self.world = dist.get_world_size(process_group)
+        self.works = []
+
+    def reduce_async(self, flat_slice):
+        self.works.append(self.dist.all_reduce(flat_slice, op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+def bucket_ranges(enc_floats, obj_floats, total, layer_floats, L, n_buckets):
+    """[(lo, hi)] float ranges of a gradient slab in the order backward completes them: fc head first,
+    then groups of encoder layers from the last layer to the first (`object`, whose gradient is produced
+    last, is reduced separately by the caller)."""
+    out = [(enc_floats + obj_floats, total)]
+    per = max(1, (L + n_buckets - 1) // max(1, n_buckets))
+    hi = L
+    while hi > 0:
+        lo = max(0, hi - per)
+        out.append((lo * layer_floats, hi * layer_floats))
+        hi = lo
+    return out
 
 
 class _Pass:
@@ -199,18 +227,13 @@ class GanEngine:
     def _make_reducer(self, net):
         """returns (callback, finish): async all-reduce (sum) of grad-slab slices on RCCL's own stream,
         overlapping the rest of backward; Adam divides by world (grad_scale)."""
-        if self.world == 1:
+        if self.pg is None:
             return None, (lambda: None)
-        import torch.distributed as dist
-        works = []
+        red = GradReducer(self.pg)
 
         def cb(lo, hi, last):
-            works.append(dist.all_reduce(net.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-
-        def finish():
-            for wk in works:
-                wk.wait()
-        return cb, finish
+            red.reduce_async(net.grad[lo:hi])
+        return cb, red.finish
 
     # ------------------------------------------------------------------------------------------
     def train_disc(self, who, partner, batch, loss_slot):
