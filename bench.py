@@ -44,30 +44,39 @@ def flops_per_token(S):
     return fwd + bwd
 
 
-def time_dominant_kernel(S, B, reps=30):
-    """Live HIP-event timing of the dominant kernel on the stream it is launched on (torch's current stream):
-    the FFN linear1 forward GEMM of the batched discriminator pass, M = S*2B tokens, N = 2048, K = 100,
-    with its fused bias + ReLU + Philox-dropout epilogue.  Returns (avg seconds per launch, flops per launch)."""
+def time_dominant_kernel(S, B, reps=3):
+    """Live HIP-event timing, on the stream the kernels are launched on (torch's current stream), of every launch
+    of the FFN linear1 forward kernel `gemm_kernel<NT, 64, 64, RELU_DROP>` that ONE iteration issues at B dialogues:
+    per iteration 112 launches at (M=S*B, N=2048, K=100) [8 G100 + 6 frozen-D forwards x 8 layers] and 32 at
+    (M=S*B, N=2048, K=512) [4 G512 forwards x 8 layers], each with its fused bias + ReLU + Philox-dropout epilogue.
+    Returns (average seconds per launch, average algorithmic flops per launch)."""
     from gan_ffn_amd import _lib, ops
-    M, N, K = S * 2 * B, 2048, 100
-    a = torch.rand(M, K, device="cuda")
-    w = torch.rand(N, K, device="cuda") - 0.5
-    b = torch.rand(N, device="cuda")
+    M, N = S * B, 2048
+    mix = [(100, 112), (512, 32)]
+    rng = torch.tensor([3407, 0], dtype=torch.int64, device="cuda")
+    bufs = {}
+    for K, _ in mix:
+        bufs[K] = (torch.rand(M, K, device="cuda"), torch.rand(N, K, device="cuda") - 0.5, torch.rand(N, device="cuda"))
     c = torch.empty(M, N, device="cuda")
     st = ops._stream()
 
-    def launch():
-        _lib.call("ganffn_gemm_nt", ops._ptr(a), ops._ptr(w), ops._ptr(b), ops._ptr(c), M, N, K, st)
-    for _ in range(5):
-        launch()
+    def one_iteration():
+        for K, cnt in mix:
+            a, w, b = bufs[K]
+            for _ in range(cnt):
+                _lib.call("ganffn_ffn_linear1_fwd", ops._ptr(a), ops._ptr(w), ops._ptr(b), ops._ptr(c), M, K, N,
+                          C.c_float(0.1), C.c_uint32(18), ops._ptr(rng), C.c_uint64(0), 1, st)
+    one_iteration()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
-        launch()
+        one_iteration()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / reps, 2.0 * M * N * K
+    n = sum(cnt for _, cnt in mix)
+    flops = sum(2.0 * M * N * K * cnt for K, cnt in mix) / n
+    return e0.elapsed_time(e1) * 1e-3 / (reps * n), flops
 
 
 def cpu_baseline(S, B_sample, threads):
@@ -205,7 +214,8 @@ def main():
                        "step_tflops_reference_equivalent": round(step_tflops, 2),
                        "step_frac_of_fp32_mfma_peak": round(step_tflops * 1e12 / (FP32_MFMA_PEAK * world), 4),
                        "last_losses": {k: round(v, 4) for k, v in losses.items()}},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<NT,RELU_DROP> FFN linear1 fwd M=%d N=2048 K=100" % (S * 2 * B),
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<0, 64, 64, 1> (NT, bias+ReLU+dropout epilogue): FFN linear1 fwd, "
+                                                     "M=%d N=2048, 112 launches K=100 + 32 launches K=512 per iteration" % (S * B),
                          "achieved": round(kflop / kt / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": round(kflop / kt / FP32_MFMA_PEAK, 4), "traffic": None,
                          "avg_kernel_us": round(kt * 1e6, 2)},

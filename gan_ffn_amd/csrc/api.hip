@@ -405,6 +405,14 @@ extern "C" int ganffn_gemm_nn(const float* A, const float* Bm, float* C, int M, 
 extern "C" int ganffn_gemm_tn_acc(const float* At, const float* Bm, float* C, float* colsum, int M, int N, int K, void* stream) {
     return launch_gemm_tn_acc(At, M, Bm, N, C, N, colsum, M, N, K, (hipStream_t)stream);
 }
+extern "C" int ganffn_ffn_linear1_fwd(const float* x, const float* w1, const float* b1, float* h, int T, int E, int F, float p,
+                                      uint32_t site, const uint64_t* rng, uint64_t add, int train, void* stream) {
+    GF_CHECK_ARG(x && w1 && b1 && h && T > 0 && E > 0 && F > 0, "ffn_linear1_fwd: bad arguments");
+    GF_CHECK_ARG(!(train && p > 0.f) || rng, "ffn_linear1_fwd: rng required when dropout is active");
+    EpiArgs e;
+    e.bias = b1; e.p = p; e.site = site; e.rng = rng; e.rng_add = add; e.train = train;
+    return launch_gemm_nt(x, E, w1, E, h, F, T, F, E, EPI_RELU_DROP, e, (hipStream_t)stream);
+}
 extern "C" int ganffn_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p, uint32_t site,
                                     const uint64_t* rng, uint64_t add, void* stream) {
     return launch_attention_fwd(qkv, o, S, B, E, H, p, site, rng, add, 1, (hipStream_t)stream);

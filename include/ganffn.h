@@ -171,6 +171,11 @@ int ganffn_gemm_nn(const float* A, const float* Bm, float* C, int M, int N, int 
 /* C[M x N] += At[K x M]^T * B[K x N];  colsum[M] += sum_k At[k][m] when colsum != NULL */
 int ganffn_gemm_tn_acc(const float* At, const float* Bm, float* C, float* colsum, int M, int N, int K,
                        void* stream);
+/* h[T x F] = dropout_p(relu(x[T x E] * W1[F x E]^T + b1)): linear1 + activation + dropout of the encoder layer's
+ * feed-forward block (torch TransformerEncoderLayer._ff_block; call site model.py:1210), one fused GEMM */
+int ganffn_ffn_linear1_fwd(const float* x, const float* w1, const float* b1, float* h, int T, int E, int F,
+                           float p, uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, int train,
+                           void* stream);
 /* qkv [T x 3E] -> o [T x E]; site = dropout site id; p = 0 disables dropout */
 int ganffn_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p,
                          uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, void* stream);
