@@ -93,11 +93,13 @@ static int check_cfg(const ganffn_enc_cfg* c) {
     return 0;
 }
 
+constexpr int MAX_SPLITS = 8;   // split-K slabs of the small-N, long-K GEMMs (FFN linear2 fwd, linear1 dgrad)
+
 static int64_t enc_ws_floats(const ganffn_enc_cfg* c) {
     const int64_t T = (int64_t)c->S * c->B, TE = T * c->E, TF = T * c->F;
-    const int64_t bwd = TF + 8 * TE;                               // dh | dz dy tmp d_attn d_qkv(3)
+    const int64_t bwd = TF + (7 + MAX_SPLITS) * TE;                // dh | dz2 dz1 dy d_attn d_qkv(3) | tmp slabs
     const SavedOff s = saved_off(c);
-    const int64_t fwd_nosave = 2 * TE + s.per_layer + TE;          // X ping-pong + one layer's saved set + tmp
+    const int64_t fwd_nosave = 2 * TE + s.per_layer + MAX_SPLITS * TE;   // X ping-pong + one layer's saved set + tmp slabs
     return (bwd > fwd_nosave ? bwd : fwd_nosave) + 64;
 }
 
@@ -178,9 +180,10 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
         e1.bias = P + lo.b1; e1.p = c->p_enc; e1.site = site + 2; e1.rng = rng; e1.rng_add = add; e1.train = train;
         GF_TRY(launch_gemm_nt(sv + so.x1, E, P + lo.w1, E, sv + so.h, F, T, F, E, EPI_RELU_DROP, e1, st));
         ea.bias = P + lo.b2;
-        GF_TRY(launch_gemm_nt(sv + so.h, F, P + lo.w2, F, tmp, E, T, E, F, EPI_NONE, ea, st));
+        int splits = gemm_splitk_factor(T, E, F);      // few output tiles, K = 2048: split K, LN sums the slabs
+        GF_TRY(launch_gemm_nt(sv + so.h, F, P + lo.w2, F, tmp, E, T, E, F, EPI_NONE, ea, st, &splits, TE));
         GF_TRY(launch_add_drop_ln_fwd(sv + so.x1, tmp, P + lo.n2w, P + lo.n2b, Xnext, sv + so.xhat2, sv + so.rstd2, T, E,
-                                      c->ln_eps, c->p_enc, site + 3, rng, add, train, st));
+                                      c->ln_eps, c->p_enc, site + 3, rng, add, train, st, splits, TE));
         if (saved && l == L - 1) {
             // keep X[L] in the saved set too (not needed by backward, but keeps the layout uniform) — skip the copy:
             // nothing reads X[L].
@@ -212,11 +215,12 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
     const float pdrop = (train ? c->p_enc : 0.f);
 
     float* dh = workspace;            // [T x F]
-    float* dz = dh + TF;              // [T x E] LN input gradient (residual branch)
-    float* dy = dz + TE;              // [T x E] gradient of the sub-layer output (after dropout bwd)
-    float* tmp = dy + TE;             // [T x E]
-    float* d_attn = tmp + TE;         // [T x E]
+    float* dz2 = dh + TF;             // [T x E] LN2 input gradient (residual branch into x1)
+    float* dz1 = dz2 + TE;            // [T x E] LN1 input gradient (residual branch into X[l])
+    float* dy = dz1 + TE;             // [T x E] gradient of the sub-layer output (after dropout bwd)
+    float* d_attn = dy + TE;          // [T x E]
     float* d_qkv = d_attn + TE;       // [T x 3E]
+    float* tmp = d_qkv + 3 * TE;      // [MAX_SPLITS][T x E] split-K slabs of dh W1
 
     for (int l = layer_hi - 1; l >= layer_lo; --l) {
         const float* P = params + (int64_t)l * lo.total;
@@ -226,7 +230,7 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
         const uint32_t site = SITE_LAYER0 + 4 * l;
         EpiArgs none;
         // LN2 backward: dx = dL/dX[l+1] -> dz (to x1), dy (to FFN output)
-        GF_TRY(launch_add_drop_ln_bwd(dx, sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz, dy, G ? G + lo.n2w : nullptr,
+        GF_TRY(launch_add_drop_ln_bwd(dx, sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dy, G ? G + lo.n2w : nullptr,
                                       G ? G + lo.n2b : nullptr, T, E, c->p_enc, site + 3, rng, add, train, st));
         // linear2 wgrad: gW2[E,F] += dy^T h ; gb2 += colsum(dy)
         if (G) GF_TRY(launch_gemm_tn_acc(dy, E, sv + so.h, F, G + lo.w2, F, G + lo.b2, E, F, T, st));
@@ -237,12 +241,11 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
         GF_TRY(launch_gemm_nn(dy, E, P + lo.w2, F, dh, F, T, F, E, EPI_MASK_POS, em, st));
         // linear1 wgrad: gW1[F,E] += dh^T x1 ; gb1 += colsum(dh)
         if (G) GF_TRY(launch_gemm_tn_acc(dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T, st));
-        // d x1 = dh W1 + dz
-        GF_TRY(launch_gemm_nn(dh, F, P + lo.w1, E, tmp, E, T, E, F, EPI_NONE, none, st));
-        GF_TRY(launch_add_inplace(tmp, dz, TE, st));
-        // LN1 backward
-        GF_TRY(launch_add_drop_ln_bwd(tmp, sv + so.xhat1, sv + so.rstd1, P + lo.n1w, dz, dy, G ? G + lo.n1w : nullptr,
-                                      G ? G + lo.n1b : nullptr, T, E, c->p_enc, site + 1, rng, add, train, st));
+        // d x1 = dh W1 (split-K slabs) + dz2, consumed directly by the LN1 backward
+        int splits = gemm_splitk_factor(T, E, F);
+        GF_TRY(launch_gemm_nn(dh, F, P + lo.w1, E, tmp, E, T, E, F, EPI_NONE, none, st, &splits, TE));
+        GF_TRY(launch_add_drop_ln_bwd(tmp, sv + so.xhat1, sv + so.rstd1, P + lo.n1w, dz1, dy, G ? G + lo.n1w : nullptr,
+                                      G ? G + lo.n1b : nullptr, T, E, c->p_enc, site + 1, rng, add, train, st, splits, TE, dz2));
         // out-proj wgrad + dgrad
         if (G) GF_TRY(launch_gemm_tn_acc(dy, E, sv + so.attn_o, E, G + lo.out_w, E, G + lo.out_b, E, E, T, st));
         GF_TRY(launch_gemm_nn(dy, E, P + lo.out_w, E, d_attn, E, T, E, E, EPI_NONE, none, st));
@@ -250,8 +253,9 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
         GF_TRY(launch_attention_bwd(sv + so.qkv, d_attn, d_qkv, S, B, E, H, c->p_enc, site + 0, rng, add, train, st));
         // in-proj wgrad + dgrad; dX[l] = d_qkv W_in + dz
         if (G) GF_TRY(launch_gemm_tn_acc(d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T, st));
-        GF_TRY(launch_gemm_nn(d_qkv, 3 * E, P + lo.in_w, E, dx, E, T, E, 3 * E, EPI_NONE, none, st));
-        GF_TRY(launch_add_inplace(dx, dz, TE, st));
+        EpiArgs eadd;
+        eadd.aux_in = dz1;            // dX[l] = d_qkv W_in + dz1 (residual) in the GEMM epilogue
+        GF_TRY(launch_gemm_nn(d_qkv, 3 * E, P + lo.in_w, E, dx, E, T, E, 3 * E, EPI_NONE, eadd, st));
     }
     if (layer_lo == 0) GF_TRY(launch_dropout_bwd_inplace(dx, T, E, c->p_pe, SITE_PE, rng, add, train, st));
     return 0;

@@ -171,10 +171,11 @@ struct EpiArgs {
 
 // C[MxN] = A[MxK] * W[NxK]^T (NT)
 int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
-                   int epi, const EpiArgs& ea, hipStream_t st);
+                   int epi, const EpiArgs& ea, hipStream_t st, int* splits_io = nullptr, long slab_stride = 0);
+int gemm_splitk_factor(int M, int N, int K);
 // C[MxN] = A[MxK] * B[KxN] (NN)
 int launch_gemm_nn(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
-                   int epi, const EpiArgs& ea, hipStream_t st);
+                   int epi, const EpiArgs& ea, hipStream_t st, int* splits_io = nullptr, long slab_stride = 0);
 // C[MxN] += At[KxM]^T * B[KxN]  (TN, split-K, atomic accumulate); colsum[M] += sum_k At[k][m]
 int launch_gemm_tn_acc(const float* At, int lda, const float* Bm, int ldb, float* C, int ldc, float* colsum,
                        int M, int N, int K, hipStream_t st);
@@ -190,12 +191,15 @@ int launch_dropout_bwd_inplace(float* dx, int R, int C, float p, uint32_t site, 
                                int train, hipStream_t st);
 int launch_dropout(const float* x, float* out, int R, int C, float p, uint32_t site, const uint64_t* rng,
                    uint64_t add, int train, hipStream_t st);
+// y / d_out may be given as `nslab` partial slabs `slab_stride` floats apart (split-K GEMM output): they are summed
+// on the fly; d_out additionally takes an optional addend (the residual-branch gradient).
 int launch_add_drop_ln_fwd(const float* x, const float* y, const float* w, const float* b, float* out, float* xhat,
                            float* rstd, int T, int E, float eps, float p, uint32_t site, const uint64_t* rng,
-                           uint64_t add, int train, hipStream_t st);
+                           uint64_t add, int train, hipStream_t st, int nslab = 1, long slab_stride = 0);
 int launch_add_drop_ln_bwd(const float* d_out, const float* xhat, const float* rstd, const float* w, float* dz,
                            float* dy, float* gw, float* gb, int T, int E, float p, uint32_t site,
-                           const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+                           const uint64_t* rng, uint64_t add, int train, hipStream_t st, int nslab = 1,
+                           long slab_stride = 0, const float* addend = nullptr);
 int launch_add_inplace(float* a, const float* b, int64_t n, hipStream_t st);
 int launch_gelu_drop_fwd(const float* x, float* out, int R, int C, float p, uint32_t site, const uint64_t* rng,
                          uint64_t add, int train, hipStream_t st);

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __res
                                                               float* __restrict__ out, float* __restrict__ xhat,
                                                               float* __restrict__ rstd, int T, int E, float eps, float p,
                                                               uint32_t site, const uint64_t* __restrict__ rng,
-                                                              uint64_t add, int train) {
+                                                              uint64_t add, int train, int nslab, long slab_stride) {
     const int lane = threadIdx.x & 63;
     const int rg = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rg * 4 >= T) return;
@@ -97,7 +97,11 @@ __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __res
             for (int q = 0; q < 4; ++q) {
                 const int t = rg * 4 + q;
                 float v = 0.f;
-                if (t < T) v = x[(size_t)t * E + c] + y[(size_t)t * E + c] * mult[q];
+                if (t < T) {
+                    float yy = y[(size_t)t * E + c];
+                    for (int sl = 1; sl < nslab; ++sl) yy += y[(size_t)sl * slab_stride + (size_t)t * E + c];
+                    v = x[(size_t)t * E + c] + yy * mult[q];
+                }
                 z[k][q] = v;
                 sum[q] += v;
             }
@@ -150,7 +154,8 @@ __global__ __launch_bounds__(256) void add_drop_ln_bwd_kernel(const float* __res
                                                               float* __restrict__ dz, float* __restrict__ dy,
                                                               float* __restrict__ gw, float* __restrict__ gb, int T, int E,
                                                               float p, uint32_t site, const uint64_t* __restrict__ rng,
-                                                              uint64_t add, int train) {
+                                                              uint64_t add, int train, int nslab, long slab_stride,
+                                                              const float* __restrict__ addend) {
     __shared__ float red[2][4][64 * LN_MAXC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const DropCtx dc = make_drop(rng, add, site, p, train);
@@ -175,6 +180,8 @@ __global__ __launch_bounds__(256) void add_drop_ln_bwd_kernel(const float* __res
                 float d = 0.f, h = 0.f;
                 if (c < E && t < T) {
                     d = d_out[(size_t)t * E + c];
+                    for (int sl = 1; sl < nslab; ++sl) d += d_out[(size_t)sl * slab_stride + (size_t)t * E + c];
+                    if (addend) d += addend[(size_t)t * E + c];
                     h = xhat[(size_t)t * E + c];
                 }
                 aw[k] += d * h;
@@ -491,24 +498,25 @@ int launch_add_inplace(float* a, const float* b, int64_t n, hipStream_t st) {
 
 int launch_add_drop_ln_fwd(const float* x, const float* y, const float* w, const float* b, float* out, float* xhat,
                            float* rstd, int T, int E, float eps, float p, uint32_t site, const uint64_t* rng,
-                           uint64_t add, int train, hipStream_t st) {
+                           uint64_t add, int train, hipStream_t st, int nslab, long slab_stride) {
     GF_CHECK_ARG(E <= 64 * LN_MAXC, "layernorm: E=%d > %d", E, 64 * LN_MAXC);
     const int G = (T + 3) / 4;
     hipLaunchKernelGGL(add_drop_ln_fwd_kernel, dim3((G + 3) / 4), dim3(256), 0, st, x, y, w, b, out, xhat, rstd, T, E, eps, p,
-                       site, rng, add, train);
+                       site, rng, add, train, nslab, slab_stride);
     GF_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_add_drop_ln_bwd(const float* d_out, const float* xhat, const float* rstd, const float* w, float* dz,
                            float* dy, float* gw, float* gb, int T, int E, float p, uint32_t site,
-                           const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
+                           const uint64_t* rng, uint64_t add, int train, hipStream_t st, int nslab, long slab_stride,
+                           const float* addend) {
     GF_CHECK_ARG(E <= 64 * LN_MAXC, "layernorm: E=%d > %d", E, 64 * LN_MAXC);
     const int G = (T + 3) / 4;
     int blocks = (G + 3) / 4;
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(add_drop_ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, d_out, xhat, rstd, w, dz, dy, gw, gb, T, E, p,
-                       site, rng, add, train);
+                       site, rng, add, train, nslab, slab_stride, addend);
     GF_LAUNCH_CHECK();
     return 0;
 }

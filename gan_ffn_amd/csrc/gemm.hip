@@ -24,8 +24,7 @@ namespace ganffn {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
-constexpr int LDK = 20;  // K-contiguous LDS row stride (floats)
+// BK in {16, 32, 64}; K-contiguous LDS row stride BK + 4 = 4 * odd  (20, 36, 68)
 
 enum { MODE_NT = 0, MODE_NN = 1, MODE_TN = 2 };
 
@@ -35,19 +34,22 @@ struct GemmArgs {
     float* C; int ldc;
     float* colsum;
     int M, N, K;
-    int kchunk;  // TN split-K chunk (multiple of BK); others: K
+    int kchunk;  // split-K chunk (multiple of 64); K when not split
+    long slab_stride;  // NT/NN split-K: split z writes its partial product to C + z*slab_stride (plain stores)
     EpiArgs ea;
 };
 
-template <int ROWS>  // K-contiguous operand tile: ROWS x 16 floats -> regs (ROWS*4/256 float4 per thread)
+template <int ROWS, int BK>  // K-contiguous operand tile: ROWS x BK floats -> regs (ROWS*BK/4/256 float4 per thread)
 struct KcTile {
-    static constexpr int NV = ROWS * 4 / 256;
+    static constexpr int KV = BK / 4;
+    static constexpr int LDK = BK + 4;
+    static constexpr int NV = ROWS * KV / 256;
     float4 v[NV];
     __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int kend, int tid) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i = tid + j * 256;
-            const int row = i >> 2, kc = (i & 3) << 2;
+            const int row = i / KV, kc = (i % KV) << 2;
             const int gr = row0 + row, gk = k0 + kc;
             if (gr < nrows && gk < kend)
                 v[j] = *reinterpret_cast<const float4*>(P + (size_t)gr * ld + gk);
@@ -59,15 +61,15 @@ struct KcTile {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i = tid + j * 256;
-            const int row = i >> 2, kc = (i & 3) << 2;
+            const int row = i / KV, kc = (i % KV) << 2;
             *reinterpret_cast<float4*>(S + row * LDK + kc) = v[j];
         }
     }
 };
 
-template <int COLS>  // K-major operand tile: 16 x COLS floats
+template <int COLS, int BK>  // K-major operand tile: BK x COLS floats
 struct KmTile {
-    static constexpr int NV = COLS * 4 / 256;
+    static constexpr int NV = COLS * BK / 4 / 256;
     static constexpr int LD = COLS + 4;
     float4 v[NV];
     __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int col0, int ncols, int k0, int kend, int tid) {
@@ -92,28 +94,30 @@ struct KmTile {
     }
 };
 
-template <int MODE, int BM, int BN>
+template <int MODE, int BM, int BN, int BK>
 struct Smem {
+    static constexpr int LDK = BK + 4;
     static constexpr int A_FLOATS = (MODE == MODE_TN) ? BK * (BM + 4) : BM * LDK;
     static constexpr int B_FLOATS = (MODE == MODE_NT) ? BN * LDK : BK * (BN + 4);
     static constexpr int STAGE = A_FLOATS + B_FLOATS;
     static constexpr int TOTAL = 2 * STAGE;
 };
 
-template <int MODE, int BM, int BN, int EPI>
+template <int MODE, int BM, int BN, int BK, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;
-    using SM = Smem<MODE, BM, BN>;
-    __shared__ __attribute__((aligned(16))) float smem[SM::TOTAL];
+    constexpr int LDK = BK + 4;
+    using SM = Smem<MODE, BM, BN, BK>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = (MODE == MODE_TN) ? blockIdx.z * g.kchunk : 0;
-    const int kend = (MODE == MODE_TN) ? min(g.K, kbeg + g.kchunk) : g.K;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
     const int nt = (kend - kbeg + BK - 1) / BK;
 
     floatx16 acc[TM][TN];
@@ -124,10 +128,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    KcTile<BM> ta_kc;
-    KmTile<BM> ta_km;
-    KcTile<BN> tb_kc;
-    KmTile<BN> tb_km;
+    KcTile<BM, BK> ta_kc;
+    KmTile<BM, BK> ta_km;
+    KcTile<BN, BK> tb_kc;
+    KmTile<BN, BK> tb_km;
 
     auto gload = [&](int t) {
         const int k0 = kbeg + t * BK;
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             const bool colok = col < g.N;
             float bias = 0.f;
             if (EPI == EPI_NONE || EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU)
-                if (g.ea.bias != nullptr && colok) bias = g.ea.bias[col];
+                if (g.ea.bias != nullptr && colok && blockIdx.z == 0) bias = g.ea.bias[col];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int rb = m0 + wm * WM + a * 32 + 8 * gq + 4 * h;  // 4 consecutive rows rb..rb+3
@@ -245,6 +249,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                         float v = acc[a][b][gq * 4 + q];
                         if (EPI == EPI_NONE) {
                             v += bias;
+                            if (g.ea.aux_in != nullptr && blockIdx.z == 0) v += g.ea.aux_in[off];   // fused residual / branch add
                         } else if (EPI == EPI_RELU_DROP) {
                             v = fmaxf(v + bias, 0.f) * mult[q];
                         } else if (EPI == EPI_DROP_GELU) {
@@ -258,27 +263,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                         } else if (EPI == EPI_GELU_BWD) {
                             v = v * gelu_grad_f(g.ea.aux_in[off]);
                         }
-                        g.C[off] = v;
+                        g.C[(size_t)blockIdx.z * g.slab_stride + off] = v;
                     }
                 }
             }
         }
 }
 
-template <int MODE, int BM, int BN, int EPI>
+int g_gemm_tn_target = 0;
+int g_gemm_cfg = 0;  // tuning knob (ganffn_debug_set_gemm_cfg): 0 = heuristic; else forces a tile config
+
+template <int MODE, int BM, int BN, int BK, int EPI>
 static int launch_cfg(const GemmArgs& g, int splits, hipStream_t st) {
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
-    hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, EPI>), grid, dim3(256), 0, st, g);
+    constexpr size_t lds = Smem<MODE, BM, BN, BK>::TOTAL * sizeof(float);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<MODE, BM, BN, BK, EPI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail((int)e, "gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, BK, EPI>), grid, dim3(256), lds, st, g);
     GF_LAUNCH_CHECK();
     return 0;
 }
 
 template <int MODE, int EPI>
-static int launch_pick(const GemmArgs& g, hipStream_t st) {
-    // big tile only when it still yields >= 2 blocks per CU
+static int launch_pick(const GemmArgs& g, int splits, hipStream_t st) {
+    switch (g_gemm_cfg) {
+        case 1: return launch_cfg<MODE, 64, 64, 16, EPI>(g, splits, st);
+        case 2: return launch_cfg<MODE, 64, 64, 32, EPI>(g, splits, st);
+        case 4: return launch_cfg<MODE, 128, 128, 16, EPI>(g, splits, st);
+        default: break;
+    }
+    // measured on MI355X (tools/gemm_bench.py): 64x64 tiles win at every shape of this workload except the
+    // largest M*N (>= 512 tiles of 128x128); BK = 32 wins for long K with few output tiles.
     const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    if (tiles128 >= 512) return launch_cfg<MODE, 128, 128, EPI>(g, 1, st);
-    return launch_cfg<MODE, 64, 64, EPI>(g, 1, st);
+    if (tiles128 >= 512) return launch_cfg<MODE, 128, 128, 16, EPI>(g, splits, st);
+    if (g.kchunk >= 512) return launch_cfg<MODE, 64, 64, 32, EPI>(g, splits, st);
+    return launch_cfg<MODE, 64, 64, 16, EPI>(g, splits, st);
 }
 
 static int check_common(const float* A, int lda, const float* B, int ldb, const float* C, int M, int N, int K) {
@@ -291,29 +313,56 @@ static int check_common(const float* A, int lda, const float* B, int ldb, const 
 
 #define EPI_SWITCH(MODE, g, st)                                                            \
     switch (epi) {                                                                         \
-        case EPI_NONE: return launch_pick<MODE, EPI_NONE>(g, st);                          \
-        case EPI_RELU_DROP: return launch_pick<MODE, EPI_RELU_DROP>(g, st);                \
-        case EPI_DROP_GELU: return launch_pick<MODE, EPI_DROP_GELU>(g, st);                \
-        case EPI_MASK_POS: return launch_pick<MODE, EPI_MASK_POS>(g, st);                  \
+        case EPI_NONE: return launch_pick<MODE, EPI_NONE>(g, splits, st);                  \
+        case EPI_RELU_DROP: return launch_pick<MODE, EPI_RELU_DROP>(g, 1, st);             \
+        case EPI_DROP_GELU: return launch_pick<MODE, EPI_DROP_GELU>(g, 1, st);             \
+        case EPI_MASK_POS: return launch_pick<MODE, EPI_MASK_POS>(g, 1, st);               \
         case EPI_GELU_BWD_DROP:                                                            \
-        case EPI_GELU_BWD_DROP0: return launch_pick<MODE, EPI_GELU_BWD_DROP>(g, st);       \
-        case EPI_GELU_BWD: return launch_pick<MODE, EPI_GELU_BWD>(g, st);                  \
+        case EPI_GELU_BWD_DROP0: return launch_pick<MODE, EPI_GELU_BWD_DROP>(g, 1, st);    \
+        case EPI_GELU_BWD: return launch_pick<MODE, EPI_GELU_BWD>(g, 1, st);               \
         default: return fail(-1, "gemm: unknown epilogue %d", epi);                        \
     }
 
+// number of K splits for a plain (EPI_NONE) GEMM whose output has too few tiles to fill 256 CUs
+int gemm_splitk_factor(int M, int N, int K) {
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    if (tiles >= 384 || K < 512) return 1;
+    long s = (768 + tiles - 1) / tiles;
+    const long maxs = K / 256;
+    if (s > maxs) s = maxs;
+    if (s > 8) s = 8;
+    return s < 1 ? 1 : (int)s;
+}
+
+static void set_split(GemmArgs& g, int& splits, long slab_stride) {
+    if (splits <= 1) { splits = 1; g.kchunk = g.K; g.slab_stride = 0; return; }
+    int kchunk = ((g.K + splits - 1) / splits + 63) / 64 * 64;
+    splits = (g.K + kchunk - 1) / kchunk;
+    g.kchunk = kchunk;
+    g.slab_stride = slab_stride;
+}
+
+// splits > 1 (EPI_NONE only): split z writes its partial to C + z*slab_stride; the consumer sums the slabs.
+// *splits_io returns the number of slabs actually written.
 int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
-                   int epi, const EpiArgs& ea, hipStream_t st) {
+                   int epi, const EpiArgs& ea, hipStream_t st, int* splits_io, long slab_stride) {
     GF_TRY(check_common(A, lda, W, ldw, C, M, N, K));
     GF_CHECK_ARG((K & 3) == 0, "gemm_nt: K=%d must be a multiple of 4", K);
-    GemmArgs g{A, lda, W, ldw, C, ldc, nullptr, M, N, K, K, ea};
+    GemmArgs g{A, lda, W, ldw, C, ldc, nullptr, M, N, K, K, 0, ea};
+    int splits = (splits_io && epi == EPI_NONE) ? *splits_io : 1;
+    set_split(g, splits, slab_stride);
+    if (splits_io) *splits_io = splits;
     EPI_SWITCH(MODE_NT, g, st)
 }
 
 int launch_gemm_nn(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
-                   int epi, const EpiArgs& ea, hipStream_t st) {
+                   int epi, const EpiArgs& ea, hipStream_t st, int* splits_io, long slab_stride) {
     GF_TRY(check_common(A, lda, Bm, ldb, C, M, N, K));
     GF_CHECK_ARG((K & 3) == 0 && (N & 3) == 0, "gemm_nn: K=%d and N=%d must be multiples of 4", K, N);
-    GemmArgs g{A, lda, Bm, ldb, C, ldc, nullptr, M, N, K, K, ea};
+    GemmArgs g{A, lda, Bm, ldb, C, ldc, nullptr, M, N, K, K, 0, ea};
+    int splits = (splits_io && epi == EPI_NONE) ? *splits_io : 1;
+    set_split(g, splits, slab_stride);
+    if (splits_io) *splits_io = splits;
     EPI_SWITCH(MODE_NN, g, st)
 }
 
@@ -322,16 +371,24 @@ int launch_gemm_tn_acc(const float* At, int lda, const float* Bm, int ldb, float
     GF_TRY(check_common(At, lda, Bm, ldb, C, M, N, K));
     GF_CHECK_ARG((M & 3) == 0 && (N & 3) == 0, "gemm_tn: M=%d and N=%d must be multiples of 4", M, N);
     EpiArgs ea;
-    GemmArgs g{At, lda, Bm, ldb, C, ldc, colsum, M, N, K, K, ea};
+    GemmArgs g{At, lda, Bm, ldb, C, ldc, colsum, M, N, K, K, 0, ea};
     const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-    long splits = (1536 + tiles - 1) / tiles;            // aim at ~6 blocks per CU
-    const long maxsplits = (K + 63) / 64;                // at least 64 k per block
+    long splits = (768 + tiles - 1) / tiles;             // ~3 blocks per CU measured best (tools/gemm_bench.py)
+    long maxsplits = (K + 63) / 64;                      // at least 64 k per block
+    if (g_gemm_tn_target > 0) { splits = (g_gemm_tn_target + tiles - 1) / tiles; }
     if (splits > maxsplits) splits = maxsplits;
     if (splits < 1) splits = 1;
-    int kchunk = (int)(((K + splits - 1) / splits + BK - 1) / BK * BK);
+    int kchunk = (int)(((K + splits - 1) / splits + 63) / 64 * 64);   // multiple of every BK
     splits = (K + kchunk - 1) / kchunk;
     g.kchunk = kchunk;
-    return launch_cfg<MODE_TN, 64, 64, EPI_NONE>(g, (int)splits, st);
+    if (g_gemm_cfg == 2) return launch_cfg<MODE_TN, 64, 64, 32, EPI_NONE>(g, (int)splits, st);
+    return launch_cfg<MODE_TN, 64, 64, 16, EPI_NONE>(g, (int)splits, st);
 }
 
 }  // namespace ganffn
+
+extern "C" int ganffn_debug_set_gemm_cfg(int cfg, int tn_target_blocks) {
+    ganffn::g_gemm_cfg = cfg;
+    ganffn::g_gemm_tn_target = tn_target_blocks;
+    return 0;
+}

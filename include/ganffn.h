@@ -196,6 +196,10 @@ int ganffn_add_dropout_layernorm_bwd(const float* d_out, const float* xhat, cons
 int ganffn_dropout(const float* x, float* out, int R, int C, float p, uint32_t site,
                    const uint64_t* rng, uint64_t rng_offset_add, void* stream);
 
+/* Tuning hook (process-wide, not for production use): force a GEMM tile configuration
+ * (0 = built-in heuristic) and the split-K block target of the wgrad GEMM (0 = default). */
+int ganffn_debug_set_gemm_cfg(int cfg, int tn_target_blocks);
+
 #ifdef __cplusplus
 }
 #endif

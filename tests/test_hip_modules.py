@@ -45,8 +45,8 @@ def test_module_matches_reference_fixture(case, shape):
         if f.startswith(tag + "/grad/") and (f.endswith("/full") or f.endswith("/sample")):
             k = f[len(tag) + 6:].rsplit("/", 1)[0]
             assert sd[k].grad is not None, k
-            # see tests/test_oracle_golden.py: one relu-kink flip moves summed grads by ~5e-4 of scale
-            check_summary(g, tag + "/grad/" + k, sd[k].grad, rtol=1e-3, atol=1e-7, what="hip", outlier_frac=0.10)
+            # see tests/test_oracle_golden.py: one relu-kink flip moves every element of a summed grad by ~1e-3 of scale (TextDiscriminator 110x3 has such a unit)
+            check_summary(g, tag + "/grad/" + k, sd[k].grad, rtol=2e-3, atol=1e-7, what="hip", outlier_frac=0.10)
             n += 1
     assert n >= 12
     assert all(p.grad is None for k, p in sd.items() if k.startswith("encoder_layer."))

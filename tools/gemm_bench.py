@@ -1,0 +1,67 @@
+"""Micro-benchmark of the GEMM kernels over the shapes of the GAN-FFN step (tuning aid, GPU only)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gan_ffn_amd import _lib, ops  # noqa: E402
+
+lib = _lib.load()
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps  # us
+
+
+def bench(kind, M, N, K, cfgs, tn_targets=(0,)):
+    st = ops._stream()
+    out = []
+    if kind == "nt":
+        a, w, b, c = torch.rand(M, K, device="cuda"), torch.rand(N, K, device="cuda"), torch.rand(N, device="cuda"), torch.empty(M, N, device="cuda")
+        fn = lambda: _lib.call("ganffn_gemm_nt", ops._ptr(a), ops._ptr(w), ops._ptr(b), ops._ptr(c), M, N, K, st)
+    elif kind == "nn":
+        a, w, c = torch.rand(M, K, device="cuda"), torch.rand(K, N, device="cuda"), torch.empty(M, N, device="cuda")
+        fn = lambda: _lib.call("ganffn_gemm_nn", ops._ptr(a), ops._ptr(w), ops._ptr(c), M, N, K, st)
+    else:
+        a, w, c, s = torch.rand(K, M, device="cuda"), torch.rand(K, N, device="cuda"), torch.zeros(M, N, device="cuda"), torch.zeros(M, device="cuda")
+        fn = lambda: _lib.call("ganffn_gemm_tn_acc", ops._ptr(a), ops._ptr(w), ops._ptr(c), ops._ptr(s), M, N, K, st)
+    for cfg in cfgs:
+        for tt in (tn_targets if kind == "tn" else (0,)):
+            lib.ganffn_debug_set_gemm_cfg(cfg, tt)
+            try:
+                us = timeit(fn)
+                out.append("cfg%d%s: %6.1fus %5.1fTF" % (cfg, ("/t%d" % tt) if kind == "tn" else "", us, 2.0 * M * N * K / us / 1e6))
+            except Exception as e:
+                out.append("cfg%d: ERR %s" % (cfg, str(e)[:40]))
+    lib.ganffn_debug_set_gemm_cfg(0, 0)
+    print("%s M=%5d N=%5d K=%5d | %s" % (kind, M, N, K, " | ".join(out)), flush=True)
+
+
+if __name__ == "__main__":
+    cfgs = [1, 2, 3, 4, 5, 6, 7]
+    for T in (3008, 6016):
+        for (N, K) in ((300, 100), (100, 100), (2048, 100), (100, 2048)):
+            bench("nt", T, N, K, cfgs)
+    for (N, K) in ((1536, 512), (512, 512), (2048, 512), (512, 2048), (1024, 512), (100, 1024)):
+        bench("nt", 3008, N, K, cfgs)
+    for T in (3008, 6016):
+        for (N, K) in ((2048, 100), (100, 2048), (100, 100), (100, 300)):
+            bench("nn", T, N, K, cfgs)
+    for (N, K) in ((2048, 512), (512, 2048), (512, 512), (512, 1536)):
+        bench("nn", 3008, N, K, cfgs)
+    for T in (3008, 6016):
+        for (M, N) in ((100, 2048), (2048, 100), (100, 100), (300, 100)):
+            bench("tn", M, N, T, [1, 2, 3], (0, 512, 1024, 3072))
+    for (M, N) in ((512, 2048), (2048, 512), (512, 512), (1536, 512)):
+        bench("tn", M, N, 3008, [1, 2, 3], (0, 1024, 3072))
