@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--seq", type=int, default=94, help="padded dialogue length S (model.py:1437)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams running independent sub-steps concurrently")
     ap.add_argument("--cpu-sample-batch", type=int, default=16)
     args = ap.parse_args()
 
@@ -161,10 +162,11 @@ def main():
     ops.manual_seed(3407 + 1000 * rank, dev)                          # rank-offset dropout streams
     batch = D.synthetic_batch(B=args.batch, S_max=args.seq, seed=3407 + rank, device=dev)
     S, B = batch["text"].shape[:2]
-    use_graph = (not args.no_graph) and pg is None
-    eng = engine.GanEngine(gens, discs, process_group=pg, use_graph=use_graph)
+    use_graph = (not args.no_graph) and pg is None and args.streams == 1
+    eng = engine.GanEngine(gens, discs, process_group=pg, use_graph=use_graph, n_streams=args.streams)
 
     def sync():
+        eng.synchronize()
         torch.cuda.synchronize()
         if pg is not None:
             import torch.distributed as dist
@@ -210,7 +212,7 @@ def main():
                                    "(12 sub-steps: 6 train_disc + 6 train_gen, train-mode dropout, BCE, Adam)",
                        "dialogues_per_gpu": B, "seq_len": S, "real_utterances_per_gpu_batch": float(batch["umask"].sum()),
                        "padded_tokens_per_s": round(S * B * world * args.steps / dt, 1),
-                       "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager",
+                       "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager", "streams": eng.n_streams,
                        "step_tflops_reference_equivalent": round(step_tflops, 2),
                        "step_frac_of_fp32_mfma_peak": round(step_tflops * 1e12 / (FP32_MFMA_PEAK * world), 4),
                        "last_losses": {k: round(v, 4) for k, v in losses.items()}},

@@ -5,336 +5,437 @@
 //   P = softmax(q k^T / sqrt(hd)) over keys, NO masks (padded utterances attend and are attended to),
 //   dropout(0.1) on P in train mode, O = P v.
 // The sequence is one dialogue (S <= 110 utterances), so one workgroup owns one (b, h) problem with
-// q, k, v and the S x S probabilities resident in LDS; nothing S x S ever touches HBM, and the
-// backward recomputes P (and the Philox dropout mask) instead of saving it.
+// q, k, v resident in LDS; nothing S x S ever touches HBM, and the backward recomputes P (and the
+// Philox dropout mask) instead of saving it.
 //
+// Formulation: everything is computed TRANSPOSED, with the QUERY index on the MFMA lane (column) axis.
+// One wave owns 32 queries.  S^T = K Q^T puts, for each lane's query, all its keys in that lane's
+// accumulator registers (plus the other half-wave), so
+//   * the softmax max / sum are in-lane reductions + ONE cross-half shuffle (instead of 5 shuffles per
+//     register in the row-major form);
+//   * the probabilities are already the B operand of the next products (O^T = V^T P^T, dQ^T = K^T dS^T):
+//     an accumulator tile feeds the next MFMA directly (k index = key, permuted consistently on the
+//     LDS-side operand), so P never goes through LDS in the forward pass;
+//   * only the two products that contract over queries (dV, dK) need P~^T / dS^T in LDS.
+// All MFMAs are v_mfma_f32_32x32x2_f32 (exact fp32).  LDS matrices use ODD row strides: row-indexed and
+// column-indexed fragment reads (ds_read_b32) are both bank-conflict-free.
 // Layout: qkv [T x 3E] packed q|k|v per token (t = s*B + b), head h = columns h*hd .. h*hd+hd-1.
-// All small products run on v_mfma_f32_32x32x2_f32 with both operands read from LDS by ds_read_b32;
-// every LDS matrix has an ODD row stride, which makes row-indexed and column-indexed fragment reads
-// bank-conflict-free alike.  4 waves; wave w owns query (or key) rows 32w .. 32w+31.
 #include "common.h"
 
 namespace ganffn {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-// acc[t] += sum_k A(m, k) * B(k, n_t),  m = lane&31 of this wave's row block, n_t = 32*t + lane&31.
-// A(m,k) at A[m*sam + k*sak], B(k,n) at Bp[n*sbn + k*sbk]; K = 2*ksteps.
-template <int NT>
-__device__ __forceinline__ void mma_lds(floatx16 (&acc)[NT], int ntiles, const float* __restrict__ A, int sam, int sak,
-                                        const float* __restrict__ Bp, int sbn, int sbk, int ksteps, int r, int h) {
-    const float* pa = A + r * sam + h * sak;
-    const float* pb = Bp + r * sbn + h * sbk;
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const float a = pa[2 * ks * sak];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t < ntiles) {
-                const float b = pb[t * 32 * sbn + 2 * ks * sbk];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ float half_max(float v) {  // reduce over the 32 lanes of a wave half
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+// row inside a 32x32 accumulator tile held by (register s, lane half h)
+__device__ __forceinline__ int krow(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
 
 struct AttnGeom {
     int S, B, E, H, hd;
-    int NTr;  // 32-row tiles covering S
-    int SK;   // S rounded up to even (K extent of P*V)
+    int NT;   // 32-wide tiles covering S (= waves per workgroup)
     int LDH;  // row stride of the [*, hd] matrices (odd)
     int LDP;  // row stride of the S x S matrix (odd)
-    int ROWS; // rows allocated per [*, hd] matrix (NTr*32 + 1 spare row for over-reads)
+    int ROWS; // rows allocated per [*, hd] matrix
 };
 
 __host__ __device__ inline AttnGeom make_geom(int S, int B, int E, int H) {
     AttnGeom g;
     g.S = S; g.B = B; g.E = E; g.H = H; g.hd = E / H;
-    g.NTr = (S + 31) / 32;
-    g.SK = (S + 1) & ~1;
+    g.NT = (S + 31) / 32;
     g.LDH = g.hd | 1;
-    g.LDP = g.SK | 1;
-    g.ROWS = g.NTr * 32 + 1;
+    g.LDP = ((S + 1) & ~1) | 1;   // query columns 0 .. S_even-1 are stored; S_even <= LDP
+    g.ROWS = g.NT * 32 + 1;
     return g;
 }
 static inline size_t hd_mat_floats(const AttnGeom& g) { return (size_t)g.ROWS * g.LDH + 64; }
-static inline size_t ss_mat_floats(const AttnGeom& g) { return (size_t)g.NTr * 32 * g.LDP + 64; }
+static inline size_t ss_mat_floats(const AttnGeom& g) { return (size_t)g.NT * 32 * g.LDP + 64; }
 
-// load one [S x hd] head slice of qkv (which = 0 q, 1 k, 2 v) into LDS, zero-padding rows >= S
-__device__ __forceinline__ void load_head(float* __restrict__ dst, const float* __restrict__ src, int ld_src,
-                                          const AttnGeom& g, int b, float scale, int tid) {
+// Load up to three [S x hd] head slices into LDS (rows >= S zero-filled).  All global loads of a batch of
+// U items per thread are issued before the first LDS write, so a workgroup pays ONE memory round trip per
+// batch instead of one per item (a plain per-item loop serialises them: that was 60-80 % of this kernel).
+struct HeadSrc {
+    float* dst;
+    const float* src;
+    int ld_src;
+    float scale;
+};
+
+template <int NM>
+__device__ __forceinline__ void load_heads(const HeadSrc (&m)[NM], const AttnGeom& g, int b, int tid, int nthreads) {
+    constexpr int U = 8;
     const int hd2 = g.hd >> 1;
-    const int total = g.NTr * 32 * hd2;
-    for (int i = tid; i < total; i += 256) {
-        const int s = i / hd2, d = (i - s * hd2) * 2;
-        float2 v = make_float2(0.f, 0.f);
-        if (s < g.S) v = *reinterpret_cast<const float2*>(src + (size_t)(s * g.B + b) * ld_src + d);
-        dst[s * g.LDH + d] = v.x * scale;
-        dst[s * g.LDH + d + 1] = v.y * scale;
+    const int per = g.NT * 32 * hd2;          // float2 items per matrix
+    const int total = per * NM;
+    for (int base = tid; base < total; base += nthreads * U) {
+        float2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * nthreads;
+            v[u] = make_float2(0.f, 0.f);
+            if (i < total) {
+                const int mi = i / per, k = i - mi * per;
+                const int s = k / hd2, d = (k - s * hd2) * 2;
+                if (s < g.S) {
+                    const float* src = NM == 1 ? m[0].src : (mi == 0 ? m[0].src : (mi == 1 ? m[1 % NM].src : m[2 % NM].src));
+                    const int ld = NM == 1 ? m[0].ld_src : (mi == 0 ? m[0].ld_src : (mi == 1 ? m[1 % NM].ld_src : m[2 % NM].ld_src));
+                    v[u] = *reinterpret_cast<const float2*>(src + (size_t)(s * g.B + b) * ld + d);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * nthreads;
+            if (i < total) {
+                const int mi = i / per, k = i - mi * per;
+                const int s = k / hd2, d = (k - s * hd2) * 2;
+                float* dst = NM == 1 ? m[0].dst : (mi == 0 ? m[0].dst : (mi == 1 ? m[1 % NM].dst : m[2 % NM].dst));
+                const float sc = NM == 1 ? m[0].scale : (mi == 0 ? m[0].scale : (mi == 1 ? m[1 % NM].scale : m[2 % NM].scale));
+                dst[s * g.LDH + d] = v[u].x * sc;
+                dst[s * g.LDH + d + 1] = v[u].y * sc;
+            }
+        }
     }
 }
 
-// scores (this wave's 32 query rows x all keys) -> probabilities in registers; returns keep bits
-template <int NTC>
-__device__ __forceinline__ void softmax_rows(floatx16 (&p)[NTC], int ntc, int S, int r, int h) {
+// acc[c][s] (key tile c, row krow(s,h)) += sum_d Km[32c + r][d] * Qm[q0 + r][d]   ->  S^T tiles for this wave's queries
+// NOTE: tile counts (NT key/query tiles, NTD head-dim tiles) are COMPILE-TIME: an MFMA under a run-time
+// condition makes hipcc copy the 16-register accumulator tuples at every control-flow merge (measured:
+// ~60 v_accvgpr/v_mov per MFMA, 750 cycles per MFMA instead of 64).
+template <int HD, int NT>
+__device__ __forceinline__ void scores_T(floatx16 (&acc)[NT], const float* __restrict__ Km,
+                                         const float* __restrict__ Qm, int LDH, int hd, int q0, int r, int h) {
+    const int steps = (HD ? HD : hd) >> 1;
+    const float* pb = Qm + (q0 + r) * LDH + h;
+    const float* pa = Km + r * LDH + h;
+#pragma unroll 4
+    for (int s = 0; s < steps; ++s) {
+        const float b = pb[2 * s];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        float m = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < NTC; ++c)
-            if (c < ntc) {
-                const int j = 32 * c + r;
-                if (j >= S) p[c][i] = -INFINITY;
-                m = fmaxf(m, p[c][i]);
-            }
-        m = half_max(m);
-        float sum = 0.f;
-#pragma unroll
-        for (int c = 0; c < NTC; ++c)
-            if (c < ntc) {
-                const float e = expf(p[c][i] - m);  // exp(-inf) = 0 for padded keys
-                p[c][i] = e;
-                sum += e;
-            }
-        sum = half_sum(sum);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int c = 0; c < NTC; ++c)
-            if (c < ntc) p[c][i] *= inv;
+        for (int c = 0; c < NT; ++c)
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c * 32 * LDH + 2 * s], b, acc[c], 0, 0, 0);
     }
 }
 
+// out[dt][s] (row d = 32dt + krow(s,h), col = query) += sum_keys Mm[key][d] * P[c][s]   (P = accumulator tiles as B operand)
+template <int NT, int NTD>
+__device__ __forceinline__ void apply_T(floatx16 (&out)[NTD], const floatx16 (&P)[NT],
+                                        const float* __restrict__ Mm, int LDH, int r, int h) {
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float* row = Mm + (32 * c + krow(s, h)) * LDH + r;
+            const float b = P[c][s];
+#pragma unroll
+            for (int dt = 0; dt < NTD; ++dt)
+                out[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(row[32 * dt], b, out[dt], 0, 0, 0);
+        }
+    }
+}
+
+// softmax over keys for each lane's query; P^T tiles in place
+template <int NT>
+__device__ __forceinline__ void softmax_T(floatx16 (&p)[NT], int S, int h) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if (32 * c + krow(s, h) >= S) p[c][s] = -INFINITY;
+            m = fmaxf(m, p[c][s]);
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float e = __expf(p[c][s] - m);   // exp(-inf) = 0 for padded keys
+            p[c][s] = e;
+            sum += e;
+        }
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) p[c][s] *= inv;
+    }
+}
+
+// Dropout keep-bits for this lane's query and all its keys.  Contract: one Philox call = 4 consecutive
+// queries at one key; the 4 lanes of a quad are 4 consecutive queries, so each lane evaluates the calls of
+// the registers s with (s & 3) == (lane & 3) and the quad exchanges 64-bit masks.
+// keep(c, s) = (mq[s & 3] >> (((c * 4 + (s >> 2)) * 4) + (lane & 3))) & 1
+template <int NT>
+__device__ __forceinline__ void keep_masks(unsigned long long (&mq)[4], const DropCtx& dc, int bh, int w, int lane) {
+    if (!dc.on) {
+        mq[0] = mq[1] = mq[2] = mq[3] = ~0ull;
+        return;
+    }
+    const int r = lane & 31, h = lane >> 5, ql = lane & 3;
+    unsigned long long mine = 0ull;
+    const uint32_t rowgroup = (uint32_t)(bh * 28 + 8 * w + (r >> 2));
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int j = 32 * c + krow(4 * gq + ql, h);
+            uint32_t wd[4];
+            philox4(rowgroup * 128u + (uint32_t)j, dc.site, dc.o0, dc.o1, dc.k0, dc.k1, wd);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (wd[q] >= dc.thr) mine |= 1ull << ((c * 4 + gq) * 4 + q);
+        }
+    }
+    const uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int src = (lane & ~3) | q;
+        const uint32_t l2 = __shfl(lo, src, 64), h2 = __shfl(hi, src, 64);
+        mq[q] = ((unsigned long long)h2 << 32) | l2;
+    }
+}
+__device__ __forceinline__ bool kept(const unsigned long long (&mq)[4], int c, int s, int lane) {
+    return (mq[s & 3] >> (((c * 4 + (s >> 2)) * 4) + (lane & 3))) & 1ull;
+}
+
 // ------------------------------------------------------------------------------------------
-// forward
+// forward: one wave per 32 queries, blockDim = 64 * NT
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o,
-                                                            AttnGeom g, float p, uint32_t site,
-                                                            const uint64_t* __restrict__ rng, uint64_t add, int train) {
+template <int HD, int NT>
+__global__ __launch_bounds__(64 * NT) void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, AttnGeom g,
+                                                                float p, uint32_t site, const uint64_t* __restrict__ rng,
+                                                                uint64_t add, int train) {
+    constexpr int NTD = HD ? (HD + 31) / 32 : 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
     const int bh = blockIdx.x, b = bh / g.H, head = bh % g.H;
+    const int nth = 64 * NT;
     const size_t HM = (size_t)g.ROWS * g.LDH + 64;
     float* Qs = smem;
     float* Ks = Qs + HM;
     float* Vs = Ks + HM;
-    float* Ps = Vs + HM;
     const int ld3 = 3 * g.E;
     const float scale = rsqrtf((float)g.hd);
-
-    load_head(Qs, qkv + head * g.hd, ld3, g, b, scale, tid);
-    load_head(Ks, qkv + g.E + head * g.hd, ld3, g, b, 1.f, tid);
-    load_head(Vs, qkv + 2 * g.E + head * g.hd, ld3, g, b, 1.f, tid);
-    __syncthreads();
-
-    const bool active = w < g.NTr;
-    floatx16 pr[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) pr[c][i] = 0.f;
-
-    if (active) {
-        mma_lds<4>(pr, g.NTr, Qs + 32 * w * g.LDH, g.LDH, 1, Ks, g.LDH, 1, g.hd >> 1, r, h);
-        softmax_rows<4>(pr, g.NTr, g.S, r, h);
-        const DropCtx dc = make_drop(rng, add, site, p, train);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c < g.NTr) {
-                const int j = 32 * c + r;
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    float mult[4];
-                    drop_mult4(dc, (uint32_t)(bh * 28 + 8 * w + 2 * gq + h), 128u, (uint32_t)j, mult);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int i = 32 * w + 8 * gq + 4 * h + q;
-                        if (j < g.SK) Ps[i * g.LDP + j] = (j < g.S) ? pr[c][gq * 4 + q] * mult[q] : 0.f;
-                    }
-                }
-            }
-        }
+    {
+        const HeadSrc m3[3] = {{Qs, qkv + head * g.hd, ld3, scale}, {Ks, qkv + g.E + head * g.hd, ld3, 1.f},
+                               {Vs, qkv + 2 * g.E + head * g.hd, ld3, 1.f}};
+        load_heads<3>(m3, g, b, tid, nth);
     }
     __syncthreads();
 
-    if (active) {
-        floatx16 oacc[2];
+    floatx16 pr[NT];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+    for (int c = 0; c < NT; ++c)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
-        const int ntd = (g.hd + 31) / 32;
-        mma_lds<2>(oacc, ntd, Ps + 32 * w * g.LDP, g.LDP, 1, Vs, 1, g.LDH, g.SK >> 1, r, h);
+        for (int i = 0; i < 16; ++i) pr[c][i] = 0.f;
+    scores_T<HD, NT>(pr, Ks, Qs, g.LDH, g.hd, 32 * w, r, h);
+    softmax_T<NT>(pr, g.S, h);
+
+    const DropCtx dc = make_drop(rng, add, site, p, train);
+    if (dc.on) {
+        unsigned long long mq[4];
+        keep_masks<NT>(mq, dc, bh, w, lane);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int d = 32 * t + r;
-            if (t < ntd && d < g.hd) {
+        for (int c = 0; c < NT; ++c) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int s = 32 * w + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (s < g.S) o[(size_t)(s * g.B + b) * g.E + head * g.hd + d] = oacc[t][i];
-                }
+            for (int s = 0; s < 16; ++s) pr[c][s] = kept(mq, c, s, lane) ? pr[c][s] * dc.scale : 0.f;
+        }
+    }
+
+    floatx16 oacc[NTD];
+#pragma unroll
+    for (int t = 0; t < NTD; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
+    apply_T<NT, NTD>(oacc, pr, Vs, g.LDH, r, h);
+
+    const int i = 32 * w + r;
+    if (i < g.S) {
+        float* orow = o + (size_t)(i * g.B + b) * g.E + head * g.hd;
+#pragma unroll
+        for (int t = 0; t < NTD; ++t) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int d = 32 * t + krow(s, h);
+                if (d < g.hd) orow[d] = oacc[t][s];
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// backward: d_qkv from d_o, recomputing P and the dropout mask
+// backward: d_qkv from d_o, recomputing P^T and the dropout mask
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
-                                                            float* __restrict__ d_qkv, AttnGeom g, float p,
-                                                            uint32_t site, const uint64_t* __restrict__ rng,
-                                                            uint64_t add, int train) {
+template <int HD, int NT>
+__global__ __launch_bounds__(64 * NT) void attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                                float* __restrict__ d_qkv, AttnGeom g, float p, uint32_t site,
+                                                                const uint64_t* __restrict__ rng, uint64_t add, int train) {
+    constexpr int NTD = HD ? (HD + 31) / 32 : 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
     const int bh = blockIdx.x, b = bh / g.H, head = bh % g.H;
+    const int nth = 64 * NT;
     const size_t HM = (size_t)g.ROWS * g.LDH + 64;
     float* RA = smem;        // Q, later dO
     float* RB = RA + HM;     // K
     float* RC = RB + HM;     // V, later Q
-    float* SS = RC + HM;     // Pdrop, later dS
+    float* SS = RC + HM;     // P~^T [key][query], later dS^T
     const int ld3 = 3 * g.E;
     const float scale = rsqrtf((float)g.hd);
-    const bool active = w < g.NTr;
-    const int ntd = (g.hd + 31) / 32;
 
-    load_head(RA, qkv + head * g.hd, ld3, g, b, scale, tid);
-    load_head(RB, qkv + g.E + head * g.hd, ld3, g, b, 1.f, tid);
-    load_head(RC, qkv + 2 * g.E + head * g.hd, ld3, g, b, 1.f, tid);
+    {
+        const HeadSrc m3[3] = {{RA, qkv + head * g.hd, ld3, scale}, {RB, qkv + g.E + head * g.hd, ld3, 1.f},
+                               {RC, qkv + 2 * g.E + head * g.hd, ld3, 1.f}};
+        load_heads<3>(m3, g, b, tid, nth);
+    }
     __syncthreads();
 
-    floatx16 pr[4];   // P (pre-dropout probabilities), later dS
-    floatx16 dp[4];   // dPdrop
+    floatx16 pr[NT];   // P^T (pre-dropout probabilities), later dS^T
+    floatx16 dp[NT];   // dP~^T
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < NT; ++c)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { pr[c][i] = 0.f; dp[c][i] = 0.f; }
-    unsigned long long keep = ~0ull;  // bit (c*16 + i): element kept by dropout
+
+    scores_T<HD, NT>(pr, RB, RA, g.LDH, g.hd, 32 * w, r, h);
+    softmax_T<NT>(pr, g.S, h);
     const DropCtx dc = make_drop(rng, add, site, p, train);
-
-    if (active) {
-        mma_lds<4>(pr, g.NTr, RA + 32 * w * g.LDH, g.LDH, 1, RB, g.LDH, 1, g.hd >> 1, r, h);
-        softmax_rows<4>(pr, g.NTr, g.S, r, h);
+    unsigned long long mq[4];
+    keep_masks<NT>(mq, dc, bh, w, lane);
+    // P~^T -> LDS [key][query] (this wave's 32 query columns)
+    {
+        const int i = 32 * w + r;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c < g.NTr) {
-                const int j = 32 * c + r;
+        for (int c = 0; c < NT; ++c) {
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    float mult[4];
-                    drop_mult4(dc, (uint32_t)(bh * 28 + 8 * w + 2 * gq + h), 128u, (uint32_t)j, mult);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int i = 32 * w + 8 * gq + 4 * h + q;
-                        if (mult[q] == 0.f) keep &= ~(1ull << (c * 16 + gq * 4 + q));
-                        if (j < g.SK) SS[i * g.LDP + j] = (j < g.S) ? pr[c][gq * 4 + q] * mult[q] : 0.f;
-                    }
-                }
+            for (int s = 0; s < 16; ++s) {
+                const float v = kept(mq, c, s, lane) ? pr[c][s] * dc.scale : 0.f;
+                if (i < g.LDP) SS[(32 * c + krow(s, h)) * g.LDP + i] = v;
             }
         }
     }
-    __syncthreads();                                    // everyone is done with Q; Pdrop is visible
-    load_head(RA, d_o + head * g.hd, g.E, g, b, 1.f, tid);  // dO over Q
+    __syncthreads();                                           // all waves are done with Q; P~^T complete
+    {
+        const HeadSrc m1[1] = {{RA, d_o + head * g.hd, g.E, 1.f}};   // dO over Q
+        load_heads<1>(m1, g, b, tid, nth);
+    }
     __syncthreads();
 
-    if (active) {
-        // dPdrop = dO V^T
-        mma_lds<4>(dp, g.NTr, RA + 32 * w * g.LDH, g.LDH, 1, RC, g.LDH, 1, g.hd >> 1, r, h);
-        // D_i = sum_j dPdrop_ij * Pdrop_ij ;  dS_ij = P_ij * (mult_ij * dPdrop_ij - D_i)
+    // dP~^T = V dO^T (same structure as the scores)
+    scores_T<HD, NT>(dp, RC, RA, g.LDH, g.hd, 32 * w, r, h);
+    // D_i = sum_j dP_ij P_ij with dP = keep*scale*dP~ ;  dS = P * (dP - D)
+    {
+        float dsum = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float d = 0.f;
+        for (int c = 0; c < NT; ++c) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < g.NTr) {
-                    const float mm = ((keep >> (c * 16 + i)) & 1ull) ? dc.scale : 0.f;
-                    dp[c][i] *= mm;
-                    d += dp[c][i] * pr[c][i];
-                }
-            d = half_sum(d);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < g.NTr) pr[c][i] = pr[c][i] * (dp[c][i] - d);
+            for (int s = 0; s < 16; ++s) {
+                dp[c][s] = kept(mq, c, s, lane) ? dp[c][s] * dc.scale : 0.f;
+                dsum += dp[c][s] * pr[c][s];
+            }
         }
-        // dV = Pdrop^T dO   (rows = keys 32w.., K = queries)
-        floatx16 acc[2];
+        dsum += __shfl_xor(dsum, 32, 64);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int c = 0; c < NT; ++c) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) pr[c][s] = pr[c][s] * (dp[c][s] - dsum);
+        }
+    }
+    // dQ^T = scale * K^T dS^T  (accumulator tiles feed the MFMA directly)
+    {
+        floatx16 acc[NTD];
+#pragma unroll
+        for (int t = 0; t < NTD; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        mma_lds<2>(acc, ntd, SS + 32 * w, 1, g.LDP, RA, 1, g.LDH, g.NTr * 16, r, h);
+        apply_T<NT, NTD>(acc, pr, RB, g.LDH, r, h);
+        const int i = 32 * w + r;
+        if (i < g.S) {
+            float* row = d_qkv + (size_t)(i * g.B + b) * ld3 + head * g.hd;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < NTD; ++t) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int d = 32 * t + krow(s, h);
+                    if (d < g.hd) row[d] = acc[t][s] * scale;
+                }
+            }
+        }
+    }
+    // dV[j][d] = sum_i P~^T[j][i] dO[i][d]   (this wave: key rows 32w .. 32w+31)
+    {
+        floatx16 acc[NTD];
+#pragma unroll
+        for (int t = 0; t < NTD; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        const float* pa = SS + (32 * w + r) * g.LDP + h;
+        const float* pb = RA + h * g.LDH + r;
+        const int ks = (g.S + 1) >> 1;   // queries 0 .. S_even-1 (rows beyond S of dO / Q are zero)
+#pragma unroll 4
+        for (int s = 0; s < ks; ++s) {
+            const float a = pa[2 * s];
+#pragma unroll
+            for (int t = 0; t < NTD; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[2 * s * g.LDH + 32 * t], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NTD; ++t) {
             const int d = 32 * t + r;
-            if (t < ntd && d < g.hd) {
+            if (d < g.hd) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int s = 32 * w + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (s < g.S) d_qkv[(size_t)(s * g.B + b) * ld3 + 2 * g.E + head * g.hd + d] = acc[t][i];
+                for (int s = 0; s < 16; ++s) {
+                    const int j = 32 * w + krow(s, h);
+                    if (j < g.S) d_qkv[(size_t)(j * g.B + b) * ld3 + 2 * g.E + head * g.hd + d] = acc[t][s];
                 }
             }
         }
     }
-    __syncthreads();                                    // Pdrop, dO and V are dead
-    if (active) {
+    __syncthreads();                                           // P~^T, V and dO are dead
+    {
+        const int i = 32 * w + r;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c < g.NTr) {
-                const int j = 32 * c + r;
+        for (int c = 0; c < NT; ++c) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = 32 * w + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (j < g.SK) SS[row * g.LDP + j] = (row < g.S && j < g.S) ? pr[c][i] : 0.f;
-                }
+            for (int s = 0; s < 16; ++s) {
+                const int j = 32 * c + krow(s, h);
+                if (i < g.LDP) SS[j * g.LDP + i] = (i < g.S && j < g.S) ? pr[c][s] : 0.f;
             }
         }
     }
-    load_head(RC, qkv + head * g.hd, ld3, g, b, scale, tid);  // scaled Q over V
+    {
+        const HeadSrc m1[1] = {{RC, qkv + head * g.hd, ld3, scale}};  // scaled Q over V
+        load_heads<1>(m1, g, b, tid, nth);
+    }
     __syncthreads();
-
-    if (active) {
-        floatx16 acc[2];
-        // dQ = scale * dS K        (rows = queries, K = keys)
+    // dK[j][d] = sum_i dS^T[j][i] (scale*Q)[i][d]
+    {
+        floatx16 acc[NTD];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NTD; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        mma_lds<2>(acc, ntd, SS + 32 * w * g.LDP, g.LDP, 1, RB, 1, g.LDH, g.SK >> 1, r, h);
+        const float* pa = SS + (32 * w + r) * g.LDP + h;
+        const float* pb = RC + h * g.LDH + r;
+        const int ks = (g.S + 1) >> 1;   // queries 0 .. S_even-1 (rows beyond S of dO / Q are zero)
+#pragma unroll 4
+        for (int s = 0; s < ks; ++s) {
+            const float a = pa[2 * s];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int d = 32 * t + r;
-            if (t < ntd && d < g.hd) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int s = 32 * w + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (s < g.S) d_qkv[(size_t)(s * g.B + b) * ld3 + head * g.hd + d] = acc[t][i] * scale;
-                }
-            }
+            for (int t = 0; t < NTD; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[2 * s * g.LDH + 32 * t], acc[t], 0, 0, 0);
         }
-        // dK = dS^T (scale*Q)      (rows = keys, K = queries)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        mma_lds<2>(acc, ntd, SS + 32 * w, 1, g.LDP, RC, 1, g.LDH, g.NTr * 16, r, h);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NTD; ++t) {
             const int d = 32 * t + r;
-            if (t < ntd && d < g.hd) {
+            if (d < g.hd) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int s = 32 * w + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (s < g.S) d_qkv[(size_t)(s * g.B + b) * ld3 + g.E + head * g.hd + d] = acc[t][i];
+                for (int s = 0; s < 16; ++s) {
+                    const int j = 32 * w + krow(s, h);
+                    if (j < g.S) d_qkv[(size_t)(j * g.B + b) * ld3 + g.E + head * g.hd + d] = acc[t][s];
                 }
             }
         }
@@ -350,21 +451,52 @@ static int check_attn(int S, int B, int E, int H) {
     return 0;
 }
 
+template <typename K>
+static int set_lds(K kern, size_t lds, const char* what) {
+    if (lds > 48 * 1024) {  // opt in to large dynamic LDS (per device, so done per launch; host-only call)
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
+    }
+    return 0;
+}
+
+template <int HD, int NT>
+static int launch_fwd_t(const float* qkv, float* o, const AttnGeom& g, size_t lds, float p, uint32_t site, const uint64_t* rng,
+                        uint64_t add, int train, hipStream_t st) {
+    GF_TRY(set_lds(attention_fwd_kernel<HD, NT>, lds, "attention_fwd"));
+    hipLaunchKernelGGL((attention_fwd_kernel<HD, NT>), dim3(g.B * g.H), dim3(64 * NT), lds, st, qkv, o, g, p, site, rng, add, train);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+template <int HD, int NT>
+static int launch_bwd_t(const float* qkv, const float* d_o, float* d_qkv, const AttnGeom& g, size_t lds, float p, uint32_t site,
+                        const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
+    GF_TRY(set_lds(attention_bwd_kernel<HD, NT>, lds, "attention_bwd"));
+    hipLaunchKernelGGL((attention_bwd_kernel<HD, NT>), dim3(g.B * g.H), dim3(64 * NT), lds, st, qkv, d_o, d_qkv, g, p, site, rng,
+                       add, train);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+#define NT_SWITCH(FN, HD, ...)                                  \
+    switch (g.NT) {                                             \
+        case 1: return FN<HD, 1>(__VA_ARGS__);                  \
+        case 2: return FN<HD, 2>(__VA_ARGS__);                  \
+        case 3: return FN<HD, 3>(__VA_ARGS__);                  \
+        default: return FN<HD, 4>(__VA_ARGS__);                 \
+    }
+
 int launch_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p, uint32_t site,
                          const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
     GF_TRY(check_attn(S, B, E, H));
     GF_CHECK_ARG(qkv && o, "attention_fwd: null pointer");
     GF_CHECK_ARG(!(train && p > 0.f) || rng, "attention_fwd: rng required when dropout is active");
     const AttnGeom g = make_geom(S, B, E, H);
-    const size_t lds = (3 * hd_mat_floats(g) + ss_mat_floats(g)) * sizeof(float);
+    const size_t lds = 3 * hd_mat_floats(g) * sizeof(float);
     GF_CHECK_ARG(lds <= 160 * 1024, "attention_fwd: LDS need %zu > 160 KiB", lds);
-    if (lds > 48 * 1024) {  // opt in to large dynamic LDS (per device, so done per launch; host-only call)
-        hipError_t e = hipFuncSetAttribute((const void*)attention_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail((int)e, "attention_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(256), lds, st, qkv, o, g, p, site, rng, add, train);
-    GF_LAUNCH_CHECK();
-    return 0;
+    if (g.hd == 10) { NT_SWITCH(launch_fwd_t, 10, qkv, o, g, lds, p, site, rng, add, train, st) }
+    if (g.hd == 64) { NT_SWITCH(launch_fwd_t, 64, qkv, o, g, lds, p, site, rng, add, train, st) }
+    NT_SWITCH(launch_fwd_t, 0, qkv, o, g, lds, p, site, rng, add, train, st)
 }
 
 int launch_attention_bwd(const float* qkv, const float* d_o, float* d_qkv, int S, int B, int E, int H, float p,
@@ -375,13 +507,9 @@ int launch_attention_bwd(const float* qkv, const float* d_o, float* d_qkv, int S
     const AttnGeom g = make_geom(S, B, E, H);
     const size_t lds = (3 * hd_mat_floats(g) + ss_mat_floats(g)) * sizeof(float);
     GF_CHECK_ARG(lds <= 160 * 1024, "attention_bwd: LDS need %zu > 160 KiB", lds);
-    if (lds > 48 * 1024) {  // opt in to large dynamic LDS (per device, so done per launch; host-only call)
-        hipError_t e = hipFuncSetAttribute((const void*)attention_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail((int)e, "attention_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(256), lds, st, qkv, d_o, d_qkv, g, p, site, rng, add, train);
-    GF_LAUNCH_CHECK();
-    return 0;
+    if (g.hd == 10) { NT_SWITCH(launch_bwd_t, 10, qkv, d_o, d_qkv, g, lds, p, site, rng, add, train, st) }
+    if (g.hd == 64) { NT_SWITCH(launch_bwd_t, 64, qkv, d_o, d_qkv, g, lds, p, site, rng, add, train, st) }
+    NT_SWITCH(launch_bwd_t, 0, qkv, d_o, d_qkv, g, lds, p, site, rng, add, train, st)
 }
 
 }  // namespace ganffn

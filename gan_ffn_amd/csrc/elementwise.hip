@@ -74,6 +74,7 @@ __global__ void add3_kernel(const float* __restrict__ a, const float* __restrict
 // one wave per group of 4 rows; lane covers columns lane, lane+64, ...  (E <= 64*MAXC)
 // ------------------------------------------------------------------------------------------
 constexpr int LN_MAXC = 8;  // E <= 512
+constexpr int LN_MAXSLAB = 8;  // split-K slabs summed on the fly (api.hip MAX_SPLITS)
 
 __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ w, const float* __restrict__ b,
@@ -98,8 +99,14 @@ __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __res
                 const int t = rg * 4 + q;
                 float v = 0.f;
                 if (t < T) {
-                    float yy = y[(size_t)t * E + c];
-                    for (int sl = 1; sl < nslab; ++sl) yy += y[(size_t)sl * slab_stride + (size_t)t * E + c];
+                    // all slab loads are issued before the first add (a runtime-bounded loop would serialise them)
+                    float ys[LN_MAXSLAB];
+#pragma unroll
+                    for (int sl = 0; sl < LN_MAXSLAB; ++sl)
+                        ys[sl] = (sl < nslab) ? y[(size_t)sl * slab_stride + (size_t)t * E + c] : 0.f;
+                    float yy = ys[0];
+#pragma unroll
+                    for (int sl = 1; sl < LN_MAXSLAB; ++sl) yy += ys[sl];
                     v = x[(size_t)t * E + c] + yy * mult[q];
                 }
                 z[k][q] = v;
@@ -179,10 +186,15 @@ __global__ __launch_bounds__(256) void add_drop_ln_bwd_kernel(const float* __res
                 const int t = rg * 4 + q;
                 float d = 0.f, h = 0.f;
                 if (c < E && t < T) {
-                    d = d_out[(size_t)t * E + c];
-                    for (int sl = 1; sl < nslab; ++sl) d += d_out[(size_t)sl * slab_stride + (size_t)t * E + c];
-                    if (addend) d += addend[(size_t)t * E + c];
+                    float ds[LN_MAXSLAB];
+#pragma unroll
+                    for (int sl = 0; sl < LN_MAXSLAB; ++sl)
+                        ds[sl] = (sl < nslab) ? d_out[(size_t)sl * slab_stride + (size_t)t * E + c] : 0.f;
+                    const float ad = addend ? addend[(size_t)t * E + c] : 0.f;
                     h = xhat[(size_t)t * E + c];
+                    d = ds[0] + ad;
+#pragma unroll
+                    for (int sl = 1; sl < LN_MAXSLAB; ++sl) d += ds[sl];
                 }
                 aw[k] += d * h;
                 ab[k] += d;
@@ -500,6 +512,7 @@ int launch_add_drop_ln_fwd(const float* x, const float* y, const float* w, const
                            float* rstd, int T, int E, float eps, float p, uint32_t site, const uint64_t* rng,
                            uint64_t add, int train, hipStream_t st, int nslab, long slab_stride) {
     GF_CHECK_ARG(E <= 64 * LN_MAXC, "layernorm: E=%d > %d", E, 64 * LN_MAXC);
+    GF_CHECK_ARG(nslab >= 1 && nslab <= LN_MAXSLAB, "layernorm: nslab=%d out of [1,%d]", nslab, LN_MAXSLAB);
     const int G = (T + 3) / 4;
     hipLaunchKernelGGL(add_drop_ln_fwd_kernel, dim3((G + 3) / 4), dim3(256), 0, st, x, y, w, b, out, xhat, rstd, T, E, eps, p,
                        site, rng, add, train, nslab, slab_stride);
@@ -512,6 +525,7 @@ int launch_add_drop_ln_bwd(const float* d_out, const float* xhat, const float* r
                            const uint64_t* rng, uint64_t add, int train, hipStream_t st, int nslab, long slab_stride,
                            const float* addend) {
     GF_CHECK_ARG(E <= 64 * LN_MAXC, "layernorm: E=%d > %d", E, 64 * LN_MAXC);
+    GF_CHECK_ARG(nslab >= 1 && nslab <= LN_MAXSLAB, "layernorm: nslab=%d out of [1,%d]", nslab, LN_MAXSLAB);
     const int G = (T + 3) / 4;
     int blocks = (G + 3) / 4;
     if (blocks > 256) blocks = 256;

@@ -136,10 +136,34 @@ class _Pass:
         self.n_ws = max(n_ws, h_ws)
 
 
-class GanEngine:
-    """train_GAN's inner loop (train_IEMOCAP.py:320-382) for a fixed batch shape."""
+class _Res:
+    """A resource touched by sub-steps on different HIP streams (a network's parameter slab, a pass buffer):
+    the event of its last writer and the events of the readers since then."""
 
-    def __init__(self, gens, discs, lr=1e-4, b1=0.5, b2=0.6, process_group=None, n_buckets=3, use_graph=False):
+    def __init__(self):
+        self.last_write = None
+        self.reads = []
+
+
+# Sub-step -> stream map for n_streams = 2: the visual generator's chain (the long pole: its two D steps and two
+# G steps are 45 % of the work) runs beside everything else; dependencies are enforced by events, so any map is
+# correct — this one balances the two streams (tools: see DESIGN.md §4).
+STREAM_MAP = {1: [0] * 12,
+              2: [0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1],     # measured best of six 2-stream maps (60.9 ms vs 81.6 ms on 1)
+              3: [0, 0, 1, 1, 2, 2, 1, 1, 2, 2, 0, 0]}
+
+
+class GanEngine:
+    """train_GAN's inner loop (train_IEMOCAP.py:320-382) for a fixed batch shape.
+
+    n_streams > 1: independent sub-steps run concurrently on several HIP streams.  The 12 sub-steps form a
+    DAG over the six networks (e.g. (D_t|G_a) only needs G_a from sub-step 2 and can run beside
+    (D_v|G_t)/(G_t|D_v)); every sub-step waits for the writers of what it reads and, before its Adam, for
+    the readers of what it writes — so each one sees exactly the parameter versions of the sequential
+    schedule.  Most kernels of this workload fill a fraction of the 256 CUs, so overlapping them is free."""
+
+    def __init__(self, gens, discs, lr=1e-4, b1=0.5, b2=0.6, process_group=None, n_buckets=3, use_graph=False,
+                 n_streams=1):
         # optimizers: train_IEMOCAP.py:292-297 (G lr, text-G 1.1*lr, every D lr/2); call site :603-606
         self.G = {k: NetState(m, lr * (1.1 if k == "text" else 1.0), (b1, b2)) for k, m in gens.items()}
         self.D = {k: NetState(m, lr / 2, (b1, b2)) for k, m in discs.items()}
@@ -152,6 +176,19 @@ class GanEngine:
             self.world = dist.get_world_size(process_group)
         self.n_buckets = n_buckets
         self.use_graph = use_graph
+        self.n_streams = n_streams if n_streams in STREAM_MAP else 1
+        if use_graph and self.n_streams > 1:
+            # multi-stream capture is not used: replay == eager here (the step is GPU-bound, not launch-bound), and
+            # eager streams additionally overlap consecutive iterations
+            self.use_graph = use_graph = False
+        import os
+        self.stream_map = STREAM_MAP[self.n_streams]
+        if os.environ.get("GANFFN_STREAM_MAP"):
+            self.stream_map = [int(x) for x in os.environ["GANFFN_STREAM_MAP"].split(",")]
+            assert len(self.stream_map) == 12 and max(self.stream_map) < self.n_streams
+        self.streams = None
+        self._res = {}
+        self._base_add = 0
         self._shape = None
         self._graph = None
         self.losses = torch.zeros(12, device=self.dev)
@@ -169,18 +206,54 @@ class GanEngine:
         self.pass_D2 = {k: _Pass(n, S, 2 * B, dev, True) for k, n in self.D.items()}   # [real | fake]
         self.pass_D1 = {k: _Pass(n, S, B, dev, True) for k, n in self.D.items()}       # frozen D in train_gen
         n_ws = max(p.n_ws for d in (self.pass_G, self.pass_D2, self.pass_D1, self.pass_G_nosave) for p in d.values())
-        self.ws = torch.empty(n_ws, device=dev, dtype=torch.float32)
-        self.x_cat = torch.empty(S, 2 * B, 100, device=dev, dtype=torch.float32)
-        self.obj_out = torch.empty(S, B, 100, device=dev, dtype=torch.float32)
-        self.dprob2 = torch.empty(S, 2 * B, 1, device=dev, dtype=torch.float32)
-        self.dprob1 = torch.empty(S, B, 1, device=dev, dtype=torch.float32)
-        self.d_real = torch.empty(S, B, 100, device=dev, dtype=torch.float32)
+        f32 = dict(device=dev, dtype=torch.float32)
+        # scratch is per stream (sub-steps on different streams run concurrently)
+        self.scratch = [dict(ws=torch.empty(n_ws, **f32), x_cat=torch.empty(S, 2 * B, 100, **f32),
+                             obj_out=torch.empty(S, B, 100, **f32), dprob2=torch.empty(S, 2 * B, 1, **f32),
+                             dprob1=torch.empty(S, B, 1, **f32), d_real=torch.empty(S, B, 100, **f32))
+                        for _ in range(self.n_streams)]
+        self._use_scratch(0)
+        if self.n_streams > 1 and self.streams is None:
+            self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
+        self._res = {}
         self.static_batch = None
+
+    def _use_scratch(self, i):
+        sc = self.scratch[i]
+        self.ws, self.x_cat, self.obj_out = sc["ws"], sc["x_cat"], sc["obj_out"]
+        self.dprob2, self.dprob1, self.d_real = sc["dprob2"], sc["dprob1"], sc["d_real"]
+
+    # ---- cross-stream dependencies -------------------------------------------------------------
+    def _r(self, key):
+        r = self._res.get(key)
+        if r is None:
+            r = self._res[key] = _Res()
+        return r
+
+    def _wait_writers(self, stream, keys):
+        for k in keys:
+            ev = self._r(k).last_write
+            if ev is not None:
+                stream.wait_event(ev)
+
+    def _wait_readers(self, stream, keys):
+        for k in keys:
+            for ev in self._r(k).reads:
+                stream.wait_event(ev)
+
+    def _done(self, stream, reads, writes):
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        for k in reads:
+            self._r(k).reads.append(ev)
+        for k in writes:
+            r = self._r(k)
+            r.last_write, r.reads = ev, []
 
     def _next_add(self):
         v = self._adds
         self._adds += 1
-        return v
+        return self._base_add + v
 
     # ------------------------------------------------------------------------------------------
     def _net_fwd(self, net, ps, x, train, save):
@@ -265,6 +338,7 @@ class GanEngine:
             if cb is not None:
                 cb(Dn.enc_floats, Dn.enc_floats + Dn.obj_floats, last=True)
         finish()
+        self._pre_write(("D", who))
         self._adam(Dn)
 
     def train_gen(self, who, partner, batch, loss_slot):
@@ -282,24 +356,71 @@ class GanEngine:
         cb, finish = self._make_reducer(Gn)
         self._net_bwd(Gn, pg_, pd.dx, True, g_adds, True, cb)
         finish()
+        self._pre_write(("G", who))
         self._adam(Gn)
 
+    def _pre_write(self, net_key):
+        """called right before a sub-step's Adam: wait for other streams' readers of that network (WAR)"""
+        if self.n_streams > 1 and self._cur_stream is not None:
+            self._wait_readers(self._cur_stream, [net_key])
+
     # ------------------------------------------------------------------------------------------
-    def _iteration_body(self, batch):
+    _cur_stream = None
+
+    def _iteration_body(self, batch, device_rng_advance):
         self._adds = 0
-        for i, (kind, who, partner) in enumerate(SCHEDULE):
-            if kind == "D":
-                self.train_disc(who, partner, batch, i)
-            else:
-                self.train_gen(who, partner, batch, i)
-        ops.rng_advance_raw(self.rng.state, self._adds)
+        if self.n_streams == 1:
+            for i, (kind, who, partner) in enumerate(SCHEDULE):
+                (self.train_disc if kind == "D" else self.train_gen)(who, partner, batch, i)
+        else:
+            origin = torch.cuda.current_stream()
+            fork = torch.cuda.Event()
+            fork.record(origin)
+            smap = self.stream_map
+            for st in self.streams:
+                st.wait_event(fork)
+            for i, (kind, who, partner) in enumerate(SCHEDULE):
+                st = self.streams[smap[i]]
+                trained = (kind, who)
+                other = ("G" if kind == "D" else "D", partner)
+                # pass buffers are resources too (same (net, role) buffer reused by a later sub-step)
+                if kind == "D":
+                    bufs = [("buf", "G_nosave", partner), ("buf", "D2", who)]
+                else:
+                    bufs = [("buf", "G", who), ("buf", "D1", partner)]
+                self._use_scratch(smap[i])
+                self._cur_stream = st
+                with torch.cuda.stream(st):
+                    self._wait_writers(st, [trained, other] + bufs)
+                    self._wait_readers(st, bufs)
+                    (self.train_disc if kind == "D" else self.train_gen)(who, partner, batch, i)
+                    self._done(st, reads=[other], writes=[trained] + bufs)
+                self._cur_stream = None
+            self._use_scratch(0)
+            if device_rng_advance:
+                # graph mode: join everything (the device-side offset bump below must follow every kernel)
+                for st in self.streams:
+                    origin.wait_stream(st)
+                self._res = {}
+        if device_rng_advance:
+            ops.rng_advance_raw(self.rng.state, self._adds)
+        else:
+            self._base_add += self._adds        # eager: offsets advance on the host, iterations may overlap
+
+    def synchronize(self):
+        """make the current stream wait for all side-stream work (call before reading results / timing)"""
+        if self.n_streams > 1 and self.streams is not None:
+            cur = torch.cuda.current_stream()
+            for st in self.streams:
+                cur.wait_stream(st)
 
     def iteration(self, batch):
-        """One batch = 12 sub-steps.  Returns the device tensor of the 12 sub-step losses (no host sync)."""
+        """One batch = 12 sub-steps.  Returns the device tensor of the 12 sub-step losses (no host sync).
+        With n_streams > 1 call synchronize() (or loss_dict()) before reading it on the current stream."""
         S, B = batch["text"].shape[:2]
         self._prepare(S, B)
         if not self.use_graph:
-            self._iteration_body(batch)
+            self._iteration_body(batch, device_rng_advance=False)
             return self.losses
         if self.static_batch is None:
             self.static_batch = {k: batch[k].clone() for k in ("text", "visual", "acoustic")}
@@ -311,18 +432,19 @@ class GanEngine:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                self._iteration_body(self.static_batch)
+                self._iteration_body(self.static_batch, device_rng_advance=True)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
-                self._iteration_body(self.static_batch)
+                self._iteration_body(self.static_batch, device_rng_advance=True)
         self._graph.replay()
         return self.losses
 
     def loss_dict(self):
         """host copy of the last iteration's losses under the reference's column names (last value per key,
         as train_IEMOCAP.py:355-382 keeps)."""
+        self.synchronize()
         v = self.losses.tolist()
         out = {}
         for (kind, who, _), x in zip(SCHEDULE, v):

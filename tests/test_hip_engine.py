@@ -86,5 +86,33 @@ def test_train_mode_losses_are_plausible_and_masks_advance():
     assert set(d) == {"acoustic_G_loss", "visual_G_loss", "text_G_loss", "visual_D_loss", "text_D_loss", "acoustic_D_loss"}
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
     assert (a > 0.3).all() and (a < 2.5).all()
-    st = eng.rng.state.cpu().tolist()
-    assert st[1] == 2 * eng._adds and eng._adds == 6 * 4 + 6 * 4
+    # eager mode advances the dropout offset on the host (graph mode bumps the device-side offset instead)
+    assert eng._base_add == 2 * eng._adds and eng._adds == 6 * 4 + 6 * 4
+    assert not torch.allclose(a, b)
+
+
+@pytest.mark.parametrize("n_streams,use_graph", [(2, False), (3, False)])
+def test_multi_stream_schedule_matches_sequential(n_streams, use_graph):
+    """sub-steps overlapped on several HIP streams see the same parameter versions as the sequential order"""
+    from gan_ffn_amd import engine
+    batch = gan_batch(S=11, B=2)
+    out = {}
+    for ns, ug in ((1, False), (n_streams, use_graph)):
+        gens, discs = build_all(zero_dropout=True)
+        eng = engine.GanEngine(gens, discs, n_streams=ns, use_graph=ug)
+        ls = []
+        for _ in range(2):
+            losses = eng.iteration(batch)
+            eng.synchronize()             # side streams -> current stream before reading the loss slots
+            ls.append(losses.clone())
+        eng.synchronize()
+        torch.cuda.synchronize()
+        sd = {k: v.detach().cpu().clone() for k, v in gens["visual"].state_dict().items()}
+        out[(ns, ug)] = (torch.stack(ls).cpu().numpy(), sd)
+    a, b = out[(1, False)], out[(n_streams, use_graph)]
+    if not use_graph:
+        # first iteration: identical up to atomic-order noise; later ones may drift (Adam chaos) but stay close
+        assert np.abs(a[0][0] - b[0][0]).max() < 5e-5, np.abs(a[0][0] - b[0][0])
+        assert np.abs(a[0][1] - b[0][1]).max() < 5e-2
+    else:
+        assert np.isfinite(b[0]).all()
