@@ -20,6 +20,8 @@
 // the MFMAs of tile t and written to the other LDS buffer after them; one barrier per K tile.
 #include "common.h"
 
+#include <type_traits>
+
 namespace ganffn {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -39,19 +41,20 @@ struct GemmArgs {
     EpiArgs ea;
 };
 
-template <int ROWS, int BK>  // K-contiguous operand tile: ROWS x BK floats -> regs (ROWS*BK/4/256 float4 per thread)
+template <int ROWS, int BK, int NTH>  // K-contiguous operand tile: ROWS x BK floats -> regs (ROWS*BK/4/NTH float4 per thread)
 struct KcTile {
     static constexpr int KV = BK / 4;
     static constexpr int LDK = BK + 4;
-    static constexpr int NV = ROWS * KV / 256;
+    static constexpr int TOTALV = ROWS * KV;
+    static constexpr int NV = (TOTALV + NTH - 1) / NTH;
     float4 v[NV];
     __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int kend, int tid) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = tid + j * 256;
+            const int i = tid + j * NTH;
             const int row = i / KV, kc = (i % KV) << 2;
             const int gr = row0 + row, gk = k0 + kc;
-            if (gr < nrows && gk < kend)
+            if (i < TOTALV && gr < nrows && gk < kend)
                 v[j] = *reinterpret_cast<const float4*>(P + (size_t)gr * ld + gk);
             else
                 v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -60,25 +63,26 @@ struct KcTile {
     __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = tid + j * 256;
+            const int i = tid + j * NTH;
             const int row = i / KV, kc = (i % KV) << 2;
-            *reinterpret_cast<float4*>(S + row * LDK + kc) = v[j];
+            if (i < TOTALV) *reinterpret_cast<float4*>(S + row * LDK + kc) = v[j];
         }
     }
 };
 
-template <int COLS, int BK>  // K-major operand tile: BK x COLS floats
+template <int COLS, int BK, int NTH>  // K-major operand tile: BK x COLS floats
 struct KmTile {
-    static constexpr int NV = COLS * BK / 4 / 256;
+    static constexpr int TOTALV = COLS * BK / 4;
+    static constexpr int NV = (TOTALV + NTH - 1) / NTH;
     static constexpr int LD = COLS + 4;
     float4 v[NV];
     __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int col0, int ncols, int k0, int kend, int tid) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = tid + j * 256;
+            const int i = tid + j * NTH;
             const int kr = i / (COLS / 4), c4 = (i % (COLS / 4)) << 2;
             const int gk = k0 + kr, gc = col0 + c4;
-            if (gk < kend && gc < ncols)
+            if (i < TOTALV && gk < kend && gc < ncols)
                 v[j] = *reinterpret_cast<const float4*>(P + (size_t)gk * ld + gc);
             else
                 v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -87,9 +91,9 @@ struct KmTile {
     __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = tid + j * 256;
+            const int i = tid + j * NTH;
             const int kr = i / (COLS / 4), c4 = (i % (COLS / 4)) << 2;
-            *reinterpret_cast<float4*>(S + kr * LD + c4) = v[j];
+            if (i < TOTALV) *reinterpret_cast<float4*>(S + kr * LD + c4) = v[j];
         }
     }
 };
@@ -103,9 +107,10 @@ struct Smem {
     static constexpr int TOTAL = 2 * STAGE;
 };
 
-template <int MODE, int BM, int BN, int BK, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
+template <int MODE, int BM, int BN, int BK, int EPI, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmArgs g) {
+    constexpr int NTH = 64 * WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;  // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int LDK = BK + 4;
     using SM = Smem<MODE, BM, BN, BK>;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * g.kchunk;
@@ -128,36 +133,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    KcTile<BM, BK> ta_kc;
-    KmTile<BM, BK> ta_km;
-    KcTile<BN, BK> tb_kc;
-    KmTile<BN, BK> tb_km;
+    // Register prefetch queue: PD tiles in flight.  The loads of tile t+PD are issued at iteration t, the tile
+    // written to LDS at iteration t is the one loaded PD-1 iterations ago, so a K loop pays the global-load
+    // latency once instead of once per tile (measured: the 1-deep version was load-latency-bound at 1-2 waves/SIMD).
+    constexpr int PD = (BM * BN / (WGM * WGN) >= 64 * 64) ? 2 : 4;   // bigger per-wave tiles: fewer tiles in flight (VGPRs)
+    KcTile<BM, BK, NTH> ta_kc[PD];
+    KmTile<BM, BK, NTH> ta_km[PD];
+    KcTile<BN, BK, NTH> tb_kc[PD];
+    KmTile<BN, BK, NTH> tb_km[PD];
 
-    auto gload = [&](int t) {
-        const int k0 = kbeg + t * BK;
-        if (MODE == MODE_TN) ta_km.load(g.A, g.lda, m0, g.M, k0, kend, tid);
-        else ta_kc.load(g.A, g.lda, m0, g.M, k0, kend, tid);
-        if (MODE == MODE_NT) tb_kc.load(g.B, g.ldb, n0, g.N, k0, kend, tid);
-        else tb_km.load(g.B, g.ldb, n0, g.N, k0, kend, tid);
+    auto gload = [&](auto slot, int t) {
+        constexpr int u = decltype(slot)::value;
+        const int k0 = kbeg + t * BK;     // beyond kend -> the tile loads zeros (no memory access)
+        if (MODE == MODE_TN) ta_km[u].load(g.A, g.lda, m0, g.M, k0, kend, tid);
+        else ta_kc[u].load(g.A, g.lda, m0, g.M, k0, kend, tid);
+        if (MODE == MODE_NT) tb_kc[u].load(g.B, g.ldb, n0, g.N, k0, kend, tid);
+        else tb_km[u].load(g.B, g.ldb, n0, g.N, k0, kend, tid);
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](auto slot, int buf) {
+        constexpr int u = decltype(slot)::value;
         float* sa = smem + buf * SM::STAGE;
         float* sb = sa + SM::A_FLOATS;
-        if (MODE == MODE_TN) ta_km.store(sa, tid); else ta_kc.store(sa, tid);
-        if (MODE == MODE_NT) tb_kc.store(sb, tid); else tb_km.store(sb, tid);
+        if (MODE == MODE_TN) ta_km[u].store(sa, tid); else ta_kc[u].store(sa, tid);
+        if (MODE == MODE_NT) tb_kc[u].store(sb, tid); else tb_km[u].store(sb, tid);
     };
 
     float colsum_acc = 0.f;  // TN: thread tid < BM sums column (m0+tid) of At over k
 
-    if (nt > 0) {
-        gload(0);
-        sstore(0);
-    }
-    __syncthreads();
-
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) gload(t + 1);
+    auto compute = [&](int buf, int t) {
         const float* sa = smem + buf * SM::STAGE;
         const float* sb = sa + SM::A_FLOATS;
         const int kvalid = min(BK, kend - (kbeg + t * BK));
@@ -200,9 +203,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 for (int k = 0; k < BK; ++k) colsum_acc += sa[k * (BM + 4) + tid];  // zero-filled beyond kend
             }
         }
-        if (t + 1 < nt) sstore(buf ^ 1);
-        __syncthreads();
+    };
+
+    // prologue: PD tiles in flight, tile 0 to LDS
+    gload(std::integral_constant<int, 0>{}, 0);
+    if constexpr (PD > 1) gload(std::integral_constant<int, 1>{}, 1);
+    if constexpr (PD > 2) gload(std::integral_constant<int, 2>{}, 2);
+    if constexpr (PD > 3) gload(std::integral_constant<int, 3>{}, 3);
+    sstore(std::integral_constant<int, 0>{}, 0);
+    __syncthreads();
+
+#define GF_STEP(U)                                                                      \
+    if (t0 + U < nt) {                                                                  \
+        const int t = t0 + U;                                                           \
+        gload(std::integral_constant<int, U>{}, t + PD);        /* slot U is free */    \
+        compute(U & 1, t);                                                              \
+        if (t + 1 < nt) sstore(std::integral_constant<int, (U + 1) % PD>{}, (U + 1) & 1); \
+        __syncthreads();                                                                \
     }
+    for (int t0 = 0; t0 < nt; t0 += PD) {
+        GF_STEP(0)
+        if constexpr (PD > 1) { GF_STEP(1) }
+        if constexpr (PD > 2) { GF_STEP(2) }
+        if constexpr (PD > 3) { GF_STEP(3) }
+    }
+#undef GF_STEP
 
     // ---------------- epilogue ----------------
     if (MODE == MODE_TN) {
@@ -273,16 +298,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 int g_gemm_tn_target = 0;
 int g_gemm_cfg = 0;  // tuning knob (ganffn_debug_set_gemm_cfg): 0 = heuristic; else forces a tile config
 
-template <int MODE, int BM, int BN, int BK, int EPI>
+template <int MODE, int BM, int BN, int BK, int EPI, int WGM = 2, int WGN = 2>
 static int launch_cfg(const GemmArgs& g, int splits, hipStream_t st) {
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
     constexpr size_t lds = Smem<MODE, BM, BN, BK>::TOTAL * sizeof(float);
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<MODE, BM, BN, BK, EPI>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<MODE, BM, BN, BK, EPI, WGM, WGN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail((int)e, "gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, BK, EPI>), grid, dim3(256), lds, st, g);
+    hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, BK, EPI, WGM, WGN>), grid, dim3(64 * WGM * WGN), lds, st, g);
     GF_LAUNCH_CHECK();
     return 0;
 }
@@ -293,12 +318,20 @@ static int launch_pick(const GemmArgs& g, int splits, hipStream_t st) {
         case 1: return launch_cfg<MODE, 64, 64, 16, EPI>(g, splits, st);
         case 2: return launch_cfg<MODE, 64, 64, 32, EPI>(g, splits, st);
         case 4: return launch_cfg<MODE, 128, 128, 16, EPI>(g, splits, st);
+        case 5: return launch_cfg<MODE, 128, 128, 16, EPI, 4, 2>(g, splits, st);   // 8 waves, wave tile 32 x 64
+        case 6: return launch_cfg<MODE, 128, 128, 32, EPI, 4, 2>(g, splits, st);
+        case 7: return launch_cfg<MODE, 128, 64, 16, EPI, 4, 1>(g, splits, st);    // 4 waves, wave tile 32 x 64
+        case 8: return launch_cfg<MODE, 128, 64, 32, EPI, 4, 1>(g, splits, st);
+        case 9: return launch_cfg<MODE, 128, 128, 16, EPI, 4, 4>(g, splits, st);   // 16 waves, wave tile 32 x 32
         default: break;
     }
     // measured on MI355X (tools/gemm_bench.py): 64x64 tiles win at every shape of this workload except the
     // largest M*N (>= 512 tiles of 128x128); BK = 32 wins for long K with few output tiles.
+    // (tools/gemm_bench.py, MI355X) at this workload's sizes (M = 3008/6016) the 4-wave 64x64 block is never beaten
+    // by more than ~5 % by 128x64 / 128x128 blocks with 4, 8 or 16 waves and wins clearly whenever N <= 512;
+    // the one exception kept is the 128x64 block for wide outputs with long K.
     const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    if (tiles128 >= 512) return launch_cfg<MODE, 128, 128, 16, EPI>(g, splits, st);
+    if (tiles128 * splits >= 350 && g.kchunk >= 512) return launch_cfg<MODE, 128, 64, 16, EPI, 4, 1>(g, splits, st);
     if (g.kchunk >= 512) return launch_cfg<MODE, 64, 64, 32, EPI>(g, splits, st);
     return launch_cfg<MODE, 64, 64, 16, EPI>(g, splits, st);
 }
