@@ -152,6 +152,8 @@ def main():
     from gan_ffn_amd import _lib, engine, ops
     from gan_ffn_amd import data as D
     _lib.load()
+    if os.environ.get("GANFFN_FFN_MODE"):
+        _lib.load().ganffn_debug_set_ffn_mode(int(os.environ["GANFFN_FFN_MODE"]))
 
     gens, discs = engine.build_networks(device=dev, seed=3407)       # random init of the reference architecture
     if pg is not None:

@@ -93,7 +93,10 @@ static int check_cfg(const ganffn_enc_cfg* c) {
     return 0;
 }
 
-constexpr int MAX_SPLITS = 8;   // split-K slabs of the small-N, long-K GEMMs (FFN linear2 fwd, linear1 dgrad)
+// which FFN passes use the fused kernel: 1 = forward (h saved), 2 = forward (nothing saved), 4 = backward dgrad.
+// Tuning hook ganffn_debug_set_ffn_mode; default chosen from measurements.
+int g_ffn_mode = 0;   // measured neutral at T = 3008/6016 (1.5 / 2.9 workgroups per CU leave SIMDs unevenly loaded); see DESIGN.md
+constexpr int MAX_SPLITS = 16;  // partial-output slabs: fused FFN (16 F splits) / split-K GEMMs (<= 8)
 
 static int64_t enc_ws_floats(const ganffn_enc_cfg* c) {
     const int64_t T = (int64_t)c->S * c->B, TE = T * c->E, TF = T * c->F;
@@ -176,12 +179,19 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
         GF_TRY(launch_add_drop_ln_fwd(Xcur, tmp, P + lo.n1w, P + lo.n1b, sv + so.x1, sv + so.xhat1, sv + so.rstd1, T, E,
                                       c->ln_eps, c->p_enc, site + 1, rng, add, train, st));
         // FFN: h = drop(relu(x1 W1^T + b1)); y = h W2^T + b2
-        EpiArgs e1;
-        e1.bias = P + lo.b1; e1.p = c->p_enc; e1.site = site + 2; e1.rng = rng; e1.rng_add = add; e1.train = train;
-        GF_TRY(launch_gemm_nt(sv + so.x1, E, P + lo.w1, E, sv + so.h, F, T, F, E, EPI_RELU_DROP, e1, st));
-        ea.bias = P + lo.b2;
-        int splits = gemm_splitk_factor(T, E, F);      // few output tiles, K = 2048: split K, LN sums the slabs
-        GF_TRY(launch_gemm_nt(sv + so.h, F, P + lo.w2, F, tmp, E, T, E, F, EPI_NONE, ea, st, &splits, TE));
+        int splits = 1;
+        if (ffn_fused_supported(E, F) && (g_ffn_mode & (saved ? 1 : 2))) {
+            // one kernel; the hidden tile feeds linear2 from registers; h is streamed out only when backward needs it
+            GF_TRY(launch_ffn_fused_fwd(sv + so.x1, P + lo.w1, P + lo.b1, P + lo.w2, P + lo.b2, saved ? sv + so.h : nullptr,
+                                        tmp, TE, T, E, F, c->p_enc, site + 2, rng, add, train, &splits, st));
+        } else {
+            EpiArgs e1;
+            e1.bias = P + lo.b1; e1.p = c->p_enc; e1.site = site + 2; e1.rng = rng; e1.rng_add = add; e1.train = train;
+            GF_TRY(launch_gemm_nt(sv + so.x1, E, P + lo.w1, E, sv + so.h, F, T, F, E, EPI_RELU_DROP, e1, st));
+            ea.bias = P + lo.b2;
+            splits = gemm_splitk_factor(T, E, F);      // few output tiles, K = 2048: split K, LN sums the slabs
+            GF_TRY(launch_gemm_nt(sv + so.h, F, P + lo.w2, F, tmp, E, T, E, F, EPI_NONE, ea, st, &splits, TE));
+        }
         GF_TRY(launch_add_drop_ln_fwd(sv + so.x1, tmp, P + lo.n2w, P + lo.n2b, Xnext, sv + so.xhat2, sv + so.rstd2, T, E,
                                       c->ln_eps, c->p_enc, site + 3, rng, add, train, st, splits, TE));
         if (saved && l == L - 1) {
@@ -234,16 +244,23 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
                                       G ? G + lo.n2b : nullptr, T, E, c->p_enc, site + 3, rng, add, train, st));
         // linear2 wgrad: gW2[E,F] += dy^T h ; gb2 += colsum(dy)
         if (G) GF_TRY(launch_gemm_tn_acc(dy, E, sv + so.h, F, G + lo.w2, F, G + lo.b2, E, F, T, st));
-        // dh = (dy W2) * [h > 0] / (1-p)
-        EpiArgs em;
-        em.aux_in = sv + so.h;
-        em.mscale = (pdrop > 0.f) ? 1.0f / (1.0f - pdrop) : 1.0f;
-        GF_TRY(launch_gemm_nn(dy, E, P + lo.w2, F, dh, F, T, F, E, EPI_MASK_POS, em, st));
-        // linear1 wgrad: gW1[F,E] += dh^T x1 ; gb1 += colsum(dh)
-        if (G) GF_TRY(launch_gemm_tn_acc(dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T, st));
-        // d x1 = dh W1 (split-K slabs) + dz2, consumed directly by the LN1 backward
-        int splits = gemm_splitk_factor(T, E, F);
-        GF_TRY(launch_gemm_nn(dh, F, P + lo.w1, E, tmp, E, T, E, F, EPI_NONE, none, st, &splits, TE));
+        const float mscale = (pdrop > 0.f) ? 1.0f / (1.0f - pdrop) : 1.0f;
+        int splits = 1;
+        if (ffn_fused_supported(E, F) && (g_ffn_mode & 4)) {
+            // dh = (dy W2) * [h > 0] / (1-p) and d x1 = dh W1 in one kernel (dh streamed out for the wgrad below)
+            GF_TRY(launch_ffn_fused_bwd(dy, P + lo.w1, P + lo.w2, sv + so.h, dh, tmp, TE, T, E, F, mscale, &splits, st));
+            if (G) GF_TRY(launch_gemm_tn_acc(dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T, st));
+        } else {
+            EpiArgs em;
+            em.aux_in = sv + so.h;
+            em.mscale = mscale;
+            GF_TRY(launch_gemm_nn(dy, E, P + lo.w2, F, dh, F, T, F, E, EPI_MASK_POS, em, st));
+            // linear1 wgrad: gW1[F,E] += dh^T x1 ; gb1 += colsum(dh)
+            if (G) GF_TRY(launch_gemm_tn_acc(dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T, st));
+            // d x1 = dh W1 (split-K slabs) + dz2, consumed directly by the LN1 backward
+            splits = gemm_splitk_factor(T, E, F);
+            GF_TRY(launch_gemm_nn(dh, F, P + lo.w1, E, tmp, E, T, E, F, EPI_NONE, none, st, &splits, TE));
+        }
         GF_TRY(launch_add_drop_ln_bwd(tmp, sv + so.xhat1, sv + so.rstd1, P + lo.n1w, dz1, dy, G ? G + lo.n1w : nullptr,
                                       G ? G + lo.n1b : nullptr, T, E, c->p_enc, site + 1, rng, add, train, st, splits, TE, dz2));
         // out-proj wgrad + dgrad
@@ -416,6 +433,24 @@ extern "C" int ganffn_ffn_linear1_fwd(const float* x, const float* w1, const flo
     EpiArgs e;
     e.bias = b1; e.p = p; e.site = site; e.rng = rng; e.rng_add = add; e.train = train;
     return launch_gemm_nt(x, E, w1, E, h, F, T, F, E, EPI_RELU_DROP, e, (hipStream_t)stream);
+}
+extern "C" int ganffn_debug_set_ffn_mode(int bits) {
+    g_ffn_mode = bits;
+    return 0;
+}
+extern "C" int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h,
+                                    float* slabs, int T, int E, int F, float p, uint32_t site, const uint64_t* rng, uint64_t add,
+                                    int train, void* stream) {
+    int splits = 0;
+    GF_TRY(launch_ffn_fused_fwd(x, w1, b1, w2, b2, h, slabs, (long)T * E, T, E, F, p, site, rng, add, train, &splits,
+                                (hipStream_t)stream));
+    return -1000 - splits;   // negative "code" carries the slab count back to the test harness (see ganffn.h)
+}
+extern "C" int ganffn_ffn_fused_bwd(const float* dy, const float* w1, const float* w2, const float* h, float* dh, float* slabs,
+                                    int T, int E, int F, float mscale, void* stream) {
+    int splits = 0;
+    GF_TRY(launch_ffn_fused_bwd(dy, w1, w2, h, dh, slabs, (long)T * E, T, E, F, mscale, &splits, (hipStream_t)stream));
+    return -1000 - splits;
 }
 extern "C" int ganffn_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p, uint32_t site,
                                     const uint64_t* rng, uint64_t add, void* stream) {

@@ -180,6 +180,14 @@ int launch_gemm_nn(const float* A, int lda, const float* Bm, int ldb, float* C, 
 int launch_gemm_tn_acc(const float* At, int lda, const float* Bm, int ldb, float* C, int ldc, float* colsum,
                        int M, int N, int K, hipStream_t st);
 
+// fused feed-forward block (ffn.hip), d_model = 100 only
+bool ffn_fused_supported(int E, int F);
+int launch_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h,
+                         float* slabs, long slab_stride, int T, int E, int F, float p, uint32_t site, const uint64_t* rng,
+                         uint64_t add, int train, int* splits_out, hipStream_t st);
+int launch_ffn_fused_bwd(const float* dy, const float* w1, const float* w2, const float* h, float* dh, float* slabs,
+                         long slab_stride, int T, int E, int F, float mscale, int* splits_out, hipStream_t st);
+
 int launch_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p, uint32_t site,
                          const uint64_t* rng, uint64_t add, int train, hipStream_t st);
 int launch_attention_bwd(const float* qkv, const float* d_o, float* d_qkv, int S, int B, int E, int H, float p,

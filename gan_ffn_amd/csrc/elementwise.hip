@@ -74,7 +74,7 @@ __global__ void add3_kernel(const float* __restrict__ a, const float* __restrict
 // one wave per group of 4 rows; lane covers columns lane, lane+64, ...  (E <= 64*MAXC)
 // ------------------------------------------------------------------------------------------
 constexpr int LN_MAXC = 8;  // E <= 512
-constexpr int LN_MAXSLAB = 8;  // split-K slabs summed on the fly (api.hip MAX_SPLITS)
+constexpr int LN_MAXSLAB = 16;  // split-K / split-F slabs summed on the fly (api.hip MAX_SPLITS)
 
 __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ w, const float* __restrict__ b,

@@ -176,6 +176,14 @@ int ganffn_gemm_tn_acc(const float* At, const float* Bm, float* C, float* colsum
 int ganffn_ffn_linear1_fwd(const float* x, const float* w1, const float* b1, float* h, int T, int E, int F,
                            float p, uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, int train,
                            void* stream);
+/* Fused feed-forward block for d_model = 100 (ffn.hip): linear1 + ReLU + dropout + linear2 in one kernel, and its
+ * dgrad chain.  The output is returned as partial slabs slabs[s][T x E], s < nslab, to be summed by the caller
+ * (the LayerNorm kernels do it on the fly).  Test hook: on success these two return -(1000 + nslab). */
+int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                         float* h /* [T x F] or NULL */, float* slabs /* [16][T x E] */, int T, int E, int F, float p,
+                         uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, int train, void* stream);
+int ganffn_ffn_fused_bwd(const float* dy, const float* w1, const float* w2, const float* h, float* dh,
+                         float* slabs, int T, int E, int F, float mscale, void* stream);
 /* qkv [T x 3E] -> o [T x E]; site = dropout site id; p = 0 disables dropout */
 int ganffn_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p,
                          uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, void* stream);
@@ -199,6 +207,8 @@ int ganffn_dropout(const float* x, float* out, int R, int C, float p, uint32_t s
 /* Tuning hook (process-wide, not for production use): force a GEMM tile configuration
  * (0 = built-in heuristic) and the split-K block target of the wgrad GEMM (0 = default). */
 int ganffn_debug_set_gemm_cfg(int cfg, int tn_target_blocks);
+/* which encoder FFN passes use the fused kernel: bit 0 forward (saving h), bit 1 forward (inference), bit 2 backward */
+int ganffn_debug_set_ffn_mode(int bits);
 
 #ifdef __cplusplus
 }

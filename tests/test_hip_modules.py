@@ -122,3 +122,16 @@ def test_cpu_tensor_fails_loudly():
     m = model.TextGenerator(100)
     with pytest.raises(GanffnError):
         m(torch.zeros(4, 2, 100))
+
+
+@pytest.mark.parametrize("mode", [0, 7])
+def test_fused_ffn_modes_agree_with_fixture(mode):
+    """the encoder's FFN can run as two GEMMs (mode 0) or as the fused kernel (mode 7): both match the reference"""
+    from gan_ffn_amd import _lib
+    lib = _lib.load()
+    lib.ganffn_debug_set_ffn_mode(mode)
+    try:
+        test_module_matches_reference_fixture(("TextGenerator", 100), (110, 3))
+        test_train_mode_matches_oracle_with_same_masks("AcousticDiscriminator", 100, 94, 4)
+    finally:
+        lib.ganffn_debug_set_ffn_mode(0)

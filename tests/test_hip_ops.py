@@ -228,3 +228,42 @@ def test_logsoftmax_nll_matches_reference_fixture(lib):
         l = O.masked_nll(torch.log_softmax(x, 2), labels.cpu(), umask.cpu().double(), None if cw is None else cw.cpu().double())
         l.backward()
         assert rel_err(dl, x.grad) < 1e-5
+
+
+@pytest.mark.parametrize("T", [3008, 6016, 14, 130])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_ffn_fused_fwd_bwd(lib, T, p):
+    """fused linear1+ReLU+dropout+linear2 (and its dgrad chain) vs fp64 torch with the same Philox mask"""
+    E, F = 100, 2048
+    g = torch.Generator().manual_seed(T + int(p * 10))
+    x = torch.randn(T, E, generator=g)
+    w1, b1 = torch.randn(F, E, generator=g) / 10, torch.randn(F, generator=g) / 10
+    w2, b2 = torch.randn(E, F, generator=g) / 45, torch.randn(E, generator=g) / 10
+    dy = torch.randn(T, E, generator=g)
+    seed, off, add, site = 31337, 2, 9, 22
+    keep = torch.from_numpy(philox.keep_mask(T, F, p, site, seed, off + add)).double() / (1 - p)
+    x64 = x.double().requires_grad_(True)
+    h_ref = torch.relu(x64 @ w1.double().T + b1.double()) * keep
+    y_ref = h_ref @ w2.double().T + b2.double()
+    rng = torch.tensor([seed, off], dtype=torch.int64, device="cuda")
+    xd, w1d, b1d, w2d, b2d, dyd = dev(x), dev(w1), dev(b1), dev(w2), dev(b2), dev(dy)
+    h = torch.full((T, F), float("nan"), device="cuda")
+    slabs = torch.full((16, T, E), float("nan"), device="cuda")
+    rc = lib.load().ganffn_ffn_fused_fwd(ptr(xd), ptr(w1d), ptr(b1d), ptr(w2d), ptr(b2d), ptr(h), ptr(slabs), T, E, F,
+                                         C.c_float(p), C.c_uint32(site), ptr(rng), C.c_uint64(add), 1, stream())
+    assert rc <= -1001, (rc, lib.load().ganffn_last_error())
+    ns = -rc - 1000
+    y = slabs[:ns].sum(0)
+    assert rel_err(h, h_ref.detach()) < 5e-6
+    assert rel_err(y, y_ref.detach()) < 2e-5
+    # backward dgrad chain
+    (y_ref * dy.double()).sum().backward()
+    dh_ref = (dy.double() @ w2.double()) * (h_ref.detach() > 0).double() / (1 - p)
+    dh = torch.full((T, F), float("nan"), device="cuda")
+    slabs.fill_(float("nan"))
+    rc = lib.load().ganffn_ffn_fused_bwd(ptr(dyd), ptr(w1d), ptr(w2d), ptr(h), ptr(dh), ptr(slabs), T, E, F,
+                                         C.c_float(1.0 / (1.0 - p)), stream())
+    assert rc <= -1001, (rc, lib.load().ganffn_last_error())
+    dx = slabs[:-rc - 1000].sum(0)
+    assert rel_err(dh, dh_ref) < 2e-5
+    assert rel_err(dx, x64.grad) < 3e-5
