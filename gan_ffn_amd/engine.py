@@ -153,7 +153,26 @@ STREAM_MAP = {1: [0] * 12,
               3: [0, 0, 1, 1, 2, 2, 1, 1, 2, 2, 0, 0]}
 
 
-class GanEngine:
+class _Runner:
+    """network-level forward / backward / Adam on preallocated buffers — shared by the GAN step runner and the
+    phase-2 (classifier) step runner"""
+    n_streams = 1
+    _cur_stream = None
+    _base_add = 0
+    _adds = 0
+
+    def _init_common(self, device, process_group, n_buckets):
+        self.dev = device
+        self.rng = ops.DeviceRng.get(device)
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+        self.n_buckets = n_buckets
+
+
+class GanEngine(_Runner):
     """train_GAN's inner loop (train_IEMOCAP.py:320-382) for a fixed batch shape.
 
     n_streams > 1: independent sub-steps run concurrently on several HIP streams.  The 12 sub-steps form a
@@ -167,14 +186,7 @@ class GanEngine:
         # optimizers: train_IEMOCAP.py:292-297 (G lr, text-G 1.1*lr, every D lr/2); call site :603-606
         self.G = {k: NetState(m, lr * (1.1 if k == "text" else 1.0), (b1, b2)) for k, m in gens.items()}
         self.D = {k: NetState(m, lr / 2, (b1, b2)) for k, m in discs.items()}
-        self.dev = next(iter(self.G.values())).slab.device
-        self.rng = ops.DeviceRng.get(self.dev)
-        self.pg = process_group
-        self.world = 1
-        if process_group is not None:
-            import torch.distributed as dist
-            self.world = dist.get_world_size(process_group)
-        self.n_buckets = n_buckets
+        self._init_common(next(iter(self.G.values())).slab.device, process_group, n_buckets)
         self.use_graph = use_graph
         self.n_streams = n_streams if n_streams in STREAM_MAP else 1
         if use_graph and self.n_streams > 1:
@@ -484,3 +496,103 @@ def train_GAN(gens, discs, batches, epochs=1, lr=1e-4, b1=0.5, b2=0.6, process_g
         if last is not None:
             rows.append(dict(epoch=epoch, **{c: last[c] for c in LOSS_COLUMNS}))
     return rows
+
+
+# ================================================================================================
+# Phase 2: GAN_FFN classifier step      (/root/reference/model.py:1434-1462, train_IEMOCAP.py:103-197,653-661)
+# ================================================================================================
+CLASS_WEIGHTS = [1.2, 0.60072, 0.38066, 0.94019, 0.67924, 0.34332]   # train_IEMOCAP.py:653
+
+
+class Phase2Engine(GanEngine):
+    """One step of train_or_eval_model on GAN_FFN: log_softmax(fc(G_a(a) + G_v(v) + G_t(t))), MaskedNLLLoss with
+    class weights, backward through the three generators, Adam(lr, weight_decay=l2) on everything.
+    The reference re-creates a LambdaLR every batch, which pins the effective lr to its base value."""
+
+    def __init__(self, ffn_module, lr=1e-4, weight_decay=0.008, class_weights=CLASS_WEIGHTS, process_group=None,
+                 n_buckets=3):
+        gens = {"acoustic": ffn_module.acoustic_generator, "visual": ffn_module.visual_generator,
+                "text": ffn_module.text_generator}
+        self.module = ffn_module
+        self.G = {k: NetState(m, lr, (0.9, 0.999), weight_decay) for k, m in gens.items()}
+        self.D = {}
+        self._init_common(next(iter(self.G.values())).slab.device, process_group, n_buckets)
+        self.n_streams, self.use_graph = 1, False
+        self.n_classes = ffn_module.fc.weight.shape[0]
+        dev = self.dev
+        # fc (100 -> n_classes) parameters as one small slab [weight | bias], 16-byte aligned pieces
+        self.fc_w, self.fc_b = ffn_module.fc.weight, ffn_module.fc.bias
+        nw = self.fc_w.numel()
+        self.fc_off_b = (nw + 3) & ~3
+        self.fc_total = self.fc_off_b + ((self.fc_b.numel() + 3) & ~3)
+        self.fc_slab = torch.zeros(self.fc_total, device=dev)
+        with torch.no_grad():
+            self.fc_slab[:nw].copy_(self.fc_w.detach().reshape(-1))
+            self.fc_slab[self.fc_off_b:self.fc_off_b + self.fc_b.numel()].copy_(self.fc_b.detach())
+            self.fc_w.data = self.fc_slab[:nw].view_as(self.fc_w)
+            self.fc_b.data = self.fc_slab[self.fc_off_b:self.fc_off_b + self.fc_b.numel()]
+        self.fc_grad = torch.zeros_like(self.fc_slab)
+        self.fc_m, self.fc_v = torch.zeros_like(self.fc_slab), torch.zeros_like(self.fc_slab)
+        self.fc_step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr, self.wd = lr, weight_decay
+        self.class_w = torch.tensor(class_weights, device=dev, dtype=torch.float32) if class_weights is not None else None
+        self._shape = None
+        self.loss = torch.zeros(1, device=dev)
+        self._adds = 0
+        self._base_add = 0
+
+    def _prepare2(self, S, B):
+        if self._shape == (S, B):
+            return
+        self._shape = (S, B)
+        dev, C_ = self.dev, self.n_classes
+        self.pass_G = {k: _Pass(n, S, B, dev, True) for k, n in self.G.items()}
+        n_ws = max(p.n_ws for p in self.pass_G.values())
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.ws = torch.empty(n_ws, **f32)
+        self.fusion = torch.empty(S, B, 100, **f32)
+        self.logits = torch.empty(S, B, C_, **f32)
+        self.log_prob = torch.empty(S, B, C_, **f32)
+        self.dlogits = torch.empty(S, B, C_, **f32)
+        self.d_fusion = torch.empty(S, B, 100, **f32)
+        self.ws2 = torch.zeros(4, **f32)
+
+    def step(self, batch, train=True):
+        """batch: text/visual/acoustic (S,B,.), umask (B,S) float, label (B,S) int64.  Returns (loss tensor, log_prob).
+        train=False: forward + loss only (model.eval())."""
+        S, B = batch["text"].shape[:2]
+        self._prepare2(S, B)
+        T, C_ = S * B, self.n_classes
+        adds = {}
+        for k in ("acoustic", "visual", "text"):                    # model.py:1441-1443
+            adds[k] = self._net_fwd(self.G[k], self.pass_G[k], batch[k], train=train, save=train)
+        ops._lib.call("ganffn_add3", ops._ptr(self.pass_G["acoustic"].out), ops._ptr(self.pass_G["visual"].out),
+                      ops._ptr(self.pass_G["text"].out), ops._ptr(self.fusion), C.c_int64(T * 100), ops._stream())
+        ops.linear_fwd_raw(self.fusion, self.fc_w, self.fc_b, self.logits, T, 100, C_)          # model.py:1448
+        ops.logsoftmax_nll_raw(self.logits, batch["label"], batch["umask"], self.class_w, self.log_prob, self.loss,
+                               self.dlogits if train else None, self.ws2, S, B, C_)                # model.py:1449, :74-81
+        if train:
+            self.fc_grad.zero_()
+            ops.linear_bwd_raw(self.dlogits, self.fusion, self.fc_w, self.d_fusion, self.fc_grad[:self.fc_w.numel()],
+                               self.fc_grad[self.fc_off_b:], T, 100, C_)
+            for k in ("acoustic", "visual", "text"):
+                net = self.G[k]
+                net.grad.zero_()
+                cb, finish = self._make_reducer(net)
+                self._net_bwd(net, self.pass_G[k], self.d_fusion, True, adds[k], True, cb)
+                finish()
+                self._adam(net)
+            if self.pg is not None:
+                red = GradReducer(self.pg)
+                red.reduce_async(self.fc_grad)
+                red.finish()
+            ops.adam_step_raw(self.fc_slab, self.fc_grad, self.fc_m, self.fc_v, self.fc_step, self.fc_total, self.lr,
+                              0.9, 0.999, 1e-8, self.wd, 1.0 / self.world)
+        self._base_add += self._adds
+        self._adds = 0
+        return self.loss, self.log_prob
+
+    @staticmethod
+    def predictions(log_prob):
+        """argmax over classes in the reference's batch-major flattening (train_IEMOCAP.py:154,158)"""
+        return log_prob.transpose(0, 1).reshape(-1, log_prob.shape[2]).argmax(1)

@@ -116,3 +116,59 @@ def test_multi_stream_schedule_matches_sequential(n_streams, use_graph):
         assert np.abs(a[0][1] - b[0][1]).max() < 5e-2
     else:
         assert np.isfinite(b[0]).all()
+
+
+def test_phase2_step_matches_reference_fixture():
+    """GAN_FFN forward + MaskedNLLLoss + backward (A11) through the fast runner vs the reference's own numbers"""
+    from gan_ffn_amd import engine, model
+    from util import check_summary
+    g = golden("misc")
+    gens, _ = build_all(zero_dropout=True)
+    net = model.GAN_FFN(gens["acoustic"], gens["visual"], gens["text"], n_classes=6).cuda()
+    with torch.no_grad():
+        net.fc.weight.copy_(torch.from_numpy(F_.formula_tensor("phase2.fc.weight", (6, 100))))
+        net.fc.bias.copy_(torch.from_numpy(F_.formula_tensor("phase2.fc.bias", (6,))))
+    eng = engine.Phase2Engine(net, lr=0.0, weight_decay=0.0)       # lr 0: keep the weights, inspect the gradients
+    batch = gan_batch(S=7, B=2)
+    batch["umask"] = torch.from_numpy(g["phase2/umask"]).cuda()
+    batch["label"] = torch.from_numpy(g["phase2/label"]).cuda()
+    loss, lp = eng.step(batch, train=True)
+    torch.cuda.synchronize()
+    assert np.abs(lp.cpu().numpy() - g["phase2/log_prob"]).max() < 1e-4
+    assert abs(float(loss) - float(g["phase2/loss_weighted"])) < 1e-4
+    gw = eng.fc_grad[:600].view(6, 100).cpu().numpy()
+    assert np.abs(gw - g["phase2/grad_fc_weight"]).max() < 2e-5
+    check_summary(g, "phase2/grad_text_fc2_weight", eng.G["text"].w("fc2.weight", True).view(100, 512), rtol=1e-3, atol=1e-8)
+    n = 3 * 512 * 512
+    check_summary(g, "phase2/grad_visual_l0_inproj", eng.G["visual"].grad[:n].view(1536, 512), rtol=1e-3, atol=1e-9)
+    # the same through the nn.Module mirror + autograd
+    net2_gens, _ = build_all(zero_dropout=True)
+    net2 = model.GAN_FFN(net2_gens["acoustic"], net2_gens["visual"], net2_gens["text"]).cuda().eval()
+    with torch.no_grad():
+        net2.fc.weight.copy_(net.fc.weight)
+        net2.fc.bias.copy_(net.fc.bias)
+    lp2, _, _, _ = net2(batch["acoustic"], batch["visual"], batch["text"])
+    lp2_ = lp2.transpose(0, 1).contiguous().view(-1, 6)
+    w = torch.tensor(engine.CLASS_WEIGHTS, device="cuda")
+    l2 = model.MaskedNLLLoss(w)(lp2_, batch["label"].view(-1), batch["umask"])
+    assert abs(float(l2) - float(g["phase2/loss_weighted"])) < 1e-4
+    l2.backward()
+    assert np.abs(net2.fc.weight.grad.cpu().numpy() - g["phase2/grad_fc_weight"]).max() < 2e-5
+    # eval step: loss only, predictions in the reference's batch-major order
+    loss_e, lp_e = eng.step(batch, train=False)
+    pred = engine.Phase2Engine.predictions(lp_e)
+    assert pred.shape == (14,) and abs(float(loss_e) - float(loss)) < 1e-5
+
+
+def test_phase2_training_reduces_loss():
+    from gan_ffn_amd import engine, model, ops
+    from gan_ffn_amd import data as D
+    gens, _ = engine.build_networks(device="cuda", seed=11)
+    net = model.GAN_FFN(gens["acoustic"], gens["visual"], gens["text"]).cuda()
+    ops.manual_seed(5)
+    eng = engine.Phase2Engine(net)                                   # lr 1e-4, l2 0.008 (train_IEMOCAP.py:453-456,661)
+    batch = D.synthetic_batch(B=4, S_max=16, device="cuda")
+    first = float(eng.step(batch)[0])
+    for _ in range(25):
+        last = float(eng.step(batch)[0])
+    assert np.isfinite(last) and last < first
