@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--seq", type=int, default=94, help="padded dialogue length S (model.py:1437)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams running independent sub-steps concurrently")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams running independent sub-steps concurrently")
     ap.add_argument("--cpu-sample-batch", type=int, default=16)
     args = ap.parse_args()
 

@@ -100,7 +100,7 @@ constexpr int MAX_SPLITS = 16;  // partial-output slabs: fused FFN (16 F splits)
 
 static int64_t enc_ws_floats(const ganffn_enc_cfg* c) {
     const int64_t T = (int64_t)c->S * c->B, TE = T * c->E, TF = T * c->F;
-    const int64_t bwd = TF + (7 + MAX_SPLITS) * TE;                // dh | dz2 dz1 dy d_attn d_qkv(3) | tmp slabs
+    const int64_t bwd = 2 * (TF + 5 * TE) + (3 + MAX_SPLITS) * TE;     // 2 x (dh | dyA dyB d_qkv(3)) | dz2 dz1 d_attn | tmp slabs
     const SavedOff s = saved_off(c);
     const int64_t fwd_nosave = 2 * TE + s.per_layer + MAX_SPLITS * TE;   // X ping-pong + one layer's saved set + tmp slabs
     return (bwd > fwd_nosave ? bwd : fwd_nosave) + 64;
@@ -206,9 +206,35 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
 // ------------------------------------------------------------------------------------------
 // encoder stack backward over layers [lo_l, hi_l)
 // ------------------------------------------------------------------------------------------
-extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int layer_hi, float* dx, const float* params,
-                                  float* grads, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
-                                  void* stream) {
+// Event pool for the optional second ("aux") stream of the backward pass.  Host-side objects only, created
+// lazily, never destroyed; one set per (thread, layer).  Not used when aux_stream == NULL.
+namespace ganffn {
+struct AuxEvents {
+    hipEvent_t ev[64][5];
+    bool made[64] = {};
+};
+static thread_local AuxEvents g_aux;
+static int aux_events(int l, hipEvent_t** out) {
+    if (!g_aux.made[l]) {
+        for (int k = 0; k < 5; ++k) {
+            hipError_t e = hipEventCreateWithFlags(&g_aux.ev[l][k], hipEventDisableTiming);
+            if (e != hipSuccess) return fail((int)e, "encoder_bwd: hipEventCreate failed: %s", hipGetErrorString(e));
+        }
+        g_aux.made[l] = true;
+    }
+    *out = g_aux.ev[l];
+    return 0;
+}
+#define GF_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) return fail((int)e__, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+}  // namespace ganffn
+
+extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int layer_hi, float* dx, const float* params,
+                                   float* grads, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
+                                   void* stream, void* aux_stream) {
     GF_TRY(check_cfg(c));
     GF_CHECK_ARG(dx && params && saved && workspace, "encoder_bwd: null pointer");
     GF_CHECK_ARG(0 <= layer_lo && layer_lo < layer_hi && layer_hi <= c->L, "encoder_bwd: bad layer range [%d,%d)", layer_lo, layer_hi);
@@ -217,6 +243,9 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
     const bool drop = c->train && (c->p_pe > 0.f || c->p_enc > 0.f);
     GF_CHECK_ARG(!drop || rng, "encoder_bwd: rng required in train mode");
     hipStream_t st = (hipStream_t)stream;
+    // weight gradients on a second stream: they are off the critical (input-gradient) chain, so they overlap it
+    const bool use_aux = aux_stream != nullptr && aux_stream != stream && grads != nullptr;
+    hipStream_t ax = use_aux ? (hipStream_t)aux_stream : st;
     const int S = c->S, B = c->B, E = c->E, H = c->H, F = c->F, T = S * B;
     const int64_t TE = (int64_t)T * E, TF = (int64_t)T * F;
     const LayerOff lo = layer_off(E, F);
@@ -224,13 +253,14 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
     const int train = c->train;
     const float pdrop = (train ? c->p_enc : 0.f);
 
-    float* dh = workspace;            // [T x F]
-    float* dz2 = dh + TF;             // [T x E] LN2 input gradient (residual branch into x1)
+    // two buffer sets (layer parity) for everything the weight-gradient GEMMs read, so that the main chain of layer
+    // l-1 does not overwrite what the aux stream still reads for layer l
+    const int64_t SET = TF + 5 * TE;              // dh | dyA | dyB | d_qkv(3)
+    float* set0 = workspace;
+    float* dz2 = set0 + 2 * SET;      // [T x E] LN2 input gradient (residual branch into x1)
     float* dz1 = dz2 + TE;            // [T x E] LN1 input gradient (residual branch into X[l])
-    float* dy = dz1 + TE;             // [T x E] gradient of the sub-layer output (after dropout bwd)
-    float* d_attn = dy + TE;          // [T x E]
-    float* d_qkv = d_attn + TE;       // [T x 3E]
-    float* tmp = d_qkv + 3 * TE;      // [MAX_SPLITS][T x E] split-K slabs of dh W1
+    float* d_attn = dz1 + TE;         // [T x E]
+    float* tmp = d_attn + TE;         // [MAX_SPLITS][T x E] partial slabs of dh W1
 
     for (int l = layer_hi - 1; l >= layer_lo; --l) {
         const float* P = params + (int64_t)l * lo.total;
@@ -238,44 +268,79 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
         const float* sv = saved + so.layers + (int64_t)l * so.per_layer;
         const float* Xl = saved + so.X + (int64_t)l * TE;
         const uint32_t site = SITE_LAYER0 + 4 * l;
+        float* bs = set0 + (l & 1) * SET;
+        float* dh = bs;               // [T x F]
+        float* dyA = dh + TF;         // [T x E] d(FFN output)
+        float* dyB = dyA + TE;        // [T x E] d(attention block output)
+        float* d_qkv = dyB + TE;      // [T x 3E]
+        hipEvent_t* ev = nullptr;
+        if (use_aux) {
+            GF_TRY(aux_events(l, &ev));
+            if (l + 2 < layer_hi) {   // this buffer set was last read by the aux stream for layer l+2
+                hipEvent_t* ev2 = nullptr;
+                GF_TRY(aux_events(l + 2, &ev2));
+                GF_HIP(hipStreamWaitEvent(st, ev2[4], 0));
+            }
+        }
         EpiArgs none;
-        // LN2 backward: dx = dL/dX[l+1] -> dz (to x1), dy (to FFN output)
-        GF_TRY(launch_add_drop_ln_bwd(dx, sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dy, G ? G + lo.n2w : nullptr,
+        // LN2 backward: dx = dL/dX[l+1] -> dz2 (to x1), dyA (to FFN output)
+        GF_TRY(launch_add_drop_ln_bwd(dx, sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dyA, G ? G + lo.n2w : nullptr,
                                       G ? G + lo.n2b : nullptr, T, E, c->p_enc, site + 3, rng, add, train, st));
-        // linear2 wgrad: gW2[E,F] += dy^T h ; gb2 += colsum(dy)
-        if (G) GF_TRY(launch_gemm_tn_acc(dy, E, sv + so.h, F, G + lo.w2, F, G + lo.b2, E, F, T, st));
+        if (use_aux) { GF_HIP(hipEventRecord(ev[0], st)); GF_HIP(hipStreamWaitEvent(ax, ev[0], 0)); }
+        // linear2 wgrad: gW2[E,F] += dyA^T h ; gb2 += colsum(dyA)
+        if (G) GF_TRY(launch_gemm_tn_acc(dyA, E, sv + so.h, F, G + lo.w2, F, G + lo.b2, E, F, T, ax));
         const float mscale = (pdrop > 0.f) ? 1.0f / (1.0f - pdrop) : 1.0f;
         int splits = 1;
-        if (ffn_fused_supported(E, F) && (g_ffn_mode & 4)) {
+        const bool fused = ffn_fused_supported(E, F) && (g_ffn_mode & 4);
+        if (fused) {
             // dh = (dy W2) * [h > 0] / (1-p) and d x1 = dh W1 in one kernel (dh streamed out for the wgrad below)
-            GF_TRY(launch_ffn_fused_bwd(dy, P + lo.w1, P + lo.w2, sv + so.h, dh, tmp, TE, T, E, F, mscale, &splits, st));
-            if (G) GF_TRY(launch_gemm_tn_acc(dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T, st));
+            GF_TRY(launch_ffn_fused_bwd(dyA, P + lo.w1, P + lo.w2, sv + so.h, dh, tmp, TE, T, E, F, mscale, &splits, st));
         } else {
             EpiArgs em;
             em.aux_in = sv + so.h;
             em.mscale = mscale;
-            GF_TRY(launch_gemm_nn(dy, E, P + lo.w2, F, dh, F, T, F, E, EPI_MASK_POS, em, st));
-            // linear1 wgrad: gW1[F,E] += dh^T x1 ; gb1 += colsum(dh)
-            if (G) GF_TRY(launch_gemm_tn_acc(dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T, st));
+            GF_TRY(launch_gemm_nn(dyA, E, P + lo.w2, F, dh, F, T, F, E, EPI_MASK_POS, em, st));
+        }
+        if (use_aux) { GF_HIP(hipEventRecord(ev[1], st)); GF_HIP(hipStreamWaitEvent(ax, ev[1], 0)); }
+        // linear1 wgrad: gW1[F,E] += dh^T x1 ; gb1 += colsum(dh)
+        if (G) GF_TRY(launch_gemm_tn_acc(dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T, ax));
+        if (!fused) {
             // d x1 = dh W1 (split-K slabs) + dz2, consumed directly by the LN1 backward
             splits = gemm_splitk_factor(T, E, F);
             GF_TRY(launch_gemm_nn(dh, F, P + lo.w1, E, tmp, E, T, E, F, EPI_NONE, none, st, &splits, TE));
         }
-        GF_TRY(launch_add_drop_ln_bwd(tmp, sv + so.xhat1, sv + so.rstd1, P + lo.n1w, dz1, dy, G ? G + lo.n1w : nullptr,
+        GF_TRY(launch_add_drop_ln_bwd(tmp, sv + so.xhat1, sv + so.rstd1, P + lo.n1w, dz1, dyB, G ? G + lo.n1w : nullptr,
                                       G ? G + lo.n1b : nullptr, T, E, c->p_enc, site + 1, rng, add, train, st, splits, TE, dz2));
+        if (use_aux) { GF_HIP(hipEventRecord(ev[2], st)); GF_HIP(hipStreamWaitEvent(ax, ev[2], 0)); }
         // out-proj wgrad + dgrad
-        if (G) GF_TRY(launch_gemm_tn_acc(dy, E, sv + so.attn_o, E, G + lo.out_w, E, G + lo.out_b, E, E, T, st));
-        GF_TRY(launch_gemm_nn(dy, E, P + lo.out_w, E, d_attn, E, T, E, E, EPI_NONE, none, st));
+        if (G) GF_TRY(launch_gemm_tn_acc(dyB, E, sv + so.attn_o, E, G + lo.out_w, E, G + lo.out_b, E, E, T, ax));
+        GF_TRY(launch_gemm_nn(dyB, E, P + lo.out_w, E, d_attn, E, T, E, E, EPI_NONE, none, st));
         // attention core backward
         GF_TRY(launch_attention_bwd(sv + so.qkv, d_attn, d_qkv, S, B, E, H, c->p_enc, site + 0, rng, add, train, st));
-        // in-proj wgrad + dgrad; dX[l] = d_qkv W_in + dz
-        if (G) GF_TRY(launch_gemm_tn_acc(d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T, st));
+        if (use_aux) { GF_HIP(hipEventRecord(ev[3], st)); GF_HIP(hipStreamWaitEvent(ax, ev[3], 0)); }
+        // in-proj wgrad + dgrad; dX[l] = d_qkv W_in + dz1
+        if (G) GF_TRY(launch_gemm_tn_acc(d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T, ax));
+        if (use_aux) GF_HIP(hipEventRecord(ev[4], ax));
         EpiArgs eadd;
         eadd.aux_in = dz1;            // dX[l] = d_qkv W_in + dz1 (residual) in the GEMM epilogue
         GF_TRY(launch_gemm_nn(d_qkv, 3 * E, P + lo.in_w, E, dx, E, T, E, 3 * E, EPI_NONE, eadd, st));
     }
+    if (use_aux) {
+        // join: every weight gradient of this range is complete before the caller's next operation on `stream`
+        for (int l = layer_lo; l < layer_hi && l < layer_lo + 2; ++l) {
+            hipEvent_t* ev = nullptr;
+            GF_TRY(aux_events(l, &ev));
+            GF_HIP(hipStreamWaitEvent(st, ev[4], 0));
+        }
+    }
     if (layer_lo == 0) GF_TRY(launch_dropout_bwd_inplace(dx, T, E, c->p_pe, SITE_PE, rng, add, train, st));
     return 0;
+}
+
+extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int layer_hi, float* dx, const float* params,
+                                  float* grads, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
+                                  void* stream) {
+    return ganffn_encoder_bwd2(c, layer_lo, layer_hi, dx, params, grads, saved, workspace, rng, add, stream, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------

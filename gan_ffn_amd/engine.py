@@ -16,6 +16,7 @@ Differences from running the nn.Module mirror under torch autograd — all resul
   * optionally the whole iteration is captured once into a hipGraph and replayed (launch-bound otherwise).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -150,7 +151,7 @@ class _Res:
 # correct — this one balances the two streams (tools: see DESIGN.md §4).
 STREAM_MAP = {1: [0] * 12,
               2: [0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1],     # measured best of six 2-stream maps (60.9 ms vs 81.6 ms on 1)
-              3: [0, 0, 1, 1, 2, 2, 1, 1, 2, 2, 0, 0]}
+              3: [0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 2, 2]}     # visual generator's chain on its own stream: 49.9 ms
 
 
 class _Runner:
@@ -188,12 +189,12 @@ class GanEngine(_Runner):
         self.D = {k: NetState(m, lr / 2, (b1, b2)) for k, m in discs.items()}
         self._init_common(next(iter(self.G.values())).slab.device, process_group, n_buckets)
         self.use_graph = use_graph
+        self.use_aux = os.environ.get("GANFFN_AUX", "0") == "1"   # wgrad on a 2nd stream: measured slower with >1 sub-step stream
         self.n_streams = n_streams if n_streams in STREAM_MAP else 1
         if use_graph and self.n_streams > 1:
             # multi-stream capture is not used: replay == eager here (the step is GPU-bound, not launch-bound), and
             # eager streams additionally overlap consecutive iterations
             self.use_graph = use_graph = False
-        import os
         self.stream_map = STREAM_MAP[self.n_streams]
         if os.environ.get("GANFFN_STREAM_MAP"):
             self.stream_map = [int(x) for x in os.environ["GANFFN_STREAM_MAP"].split(",")]
@@ -294,16 +295,27 @@ class GanEngine(_Runner):
                          g("fc3.weight") if net.kind == 1 else None, g("fc3.bias") if net.kind == 1 else None,
                          ps.dx, ps.hsaved, self.ws, self.rng.state, a1)
         gslab = net.grad if want_wgrad else None
+        aux = self._aux_for_current() if want_wgrad else None
         if reduce_cb is None or not want_wgrad:
-            ops.encoder_bwd_raw(cfg, 0, net.L, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0)
+            ops.encoder_bwd_raw(cfg, 0, net.L, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0, aux)
         else:
             # bucketed: backward a group of layers, then hand that slice of the grad slab to the all-reduce
             bks = net.buckets(self.n_buckets)
             reduce_cb(*bks[0], last=False)                       # head (+object handled by caller before this)
             for i, (lo_f, hi_f) in enumerate(bks[1:]):
                 lo, hi = lo_f // net.layer_floats, hi_f // net.layer_floats
-                ops.encoder_bwd_raw(cfg, lo, hi, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0)
+                ops.encoder_bwd_raw(cfg, lo, hi, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0, aux)
                 reduce_cb(lo_f, hi_f, last=(i == len(bks) - 2))
+
+    def _aux_for_current(self):
+        """second HIP stream for the weight-gradient GEMMs of the sub-step running on the current stream"""
+        if not getattr(self, "use_aux", False):
+            return None
+        key = torch.cuda.current_stream().cuda_stream
+        pool = self.__dict__.setdefault("_aux_pool", {})
+        if key not in pool:
+            pool[key] = torch.cuda.Stream(device=self.dev)
+        return pool[key]
 
     def _adam(self, net):
         ops.adam_step_raw(net.slab, net.grad, net.exp_avg, net.exp_avg_sq, net.step, net.total, net.lr,

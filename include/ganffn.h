@@ -109,6 +109,14 @@ int ganffn_encoder_bwd(const ganffn_enc_cfg* cfg, int layer_lo, int layer_hi, fl
                        const float* params, float* grads, const float* saved, float* workspace,
                        const uint64_t* rng, uint64_t rng_offset_add, void* stream);
 
+/* Same, with the weight-gradient GEMMs enqueued on `aux_stream` (may be NULL = same as above).  They are off
+ * the input-gradient chain, so a second stream overlaps them with it; the call records/waits HIP events so
+ * that, for the caller, everything is complete in `stream` order when the next operation on `stream` starts.
+ * (The library keeps a small pool of hipEvent_t for this — its only internally created objects.) */
+int ganffn_encoder_bwd2(const ganffn_enc_cfg* cfg, int layer_lo, int layer_hi, float* dx,
+                        const float* params, float* grads, const float* saved, float* workspace,
+                        const uint64_t* rng, uint64_t rng_offset_add, void* stream, void* aux_stream);
+
 /* ---- A3-A6: heads ------------------------------------------------------------------- */
 /* x [T x E] = encoder output.  w1[D1,E] b1[D1] w2[D2,D1] b2[D2]; disc only: w3[1,D2] b3[1].
  * out: gen -> fusion [T x D2]; disc -> prob [T x 1]. */
