@@ -95,12 +95,13 @@ static int check_cfg(const ganffn_enc_cfg* c) {
 
 // which FFN passes use the fused kernel: 1 = forward (h saved), 2 = forward (nothing saved), 4 = backward dgrad.
 // Tuning hook ganffn_debug_set_ffn_mode; default chosen from measurements.
+int g_wgrad_grouped = 1;   // deferred + grouped weight-gradient GEMMs (ganffn_debug_set_ffn_mode bit 3 clears it)
 int g_ffn_mode = 0;   // measured neutral at T = 3008/6016 (1.5 / 2.9 workgroups per CU leave SIMDs unevenly loaded); see DESIGN.md
 constexpr int MAX_SPLITS = 16;  // partial-output slabs: fused FFN (16 F splits) / split-K GEMMs (<= 8)
 
 static int64_t enc_ws_floats(const ganffn_enc_cfg* c) {
     const int64_t T = (int64_t)c->S * c->B, TE = T * c->E, TF = T * c->F;
-    const int64_t bwd = 2 * (TF + 5 * TE) + (3 + MAX_SPLITS) * TE;     // 2 x (dh | dyA dyB d_qkv(3)) | dz2 dz1 d_attn | tmp slabs
+    const int64_t bwd = (int64_t)c->L * (TF + 5 * TE) + (3 + MAX_SPLITS) * TE;   // L x (dh | dyA dyB d_qkv(3)) | dz2 dz1 d_attn | tmp slabs
     const SavedOff s = saved_off(c);
     const int64_t fwd_nosave = 2 * TE + s.per_layer + MAX_SPLITS * TE;   // X ping-pong + one layer's saved set + tmp slabs
     return (bwd > fwd_nosave ? bwd : fwd_nosave) + 64;
@@ -253,11 +254,17 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
     const int train = c->train;
     const float pdrop = (train ? c->p_enc : 0.f);
 
-    // two buffer sets (layer parity) for everything the weight-gradient GEMMs read, so that the main chain of layer
-    // l-1 does not overwrite what the aux stream still reads for layer l
+    // Weight gradients are DEFERRED: every layer keeps what its 4 wgrad GEMMs read (dh, dyA, dyB, d_qkv) in its own
+    // buffer set, and one grouped launch at the end of the range computes all of them (4 x layers problems).
+    // With an aux stream instead (legacy mode) two sets by layer parity are enough.
+    const bool grouped = !use_aux && grads != nullptr && g_wgrad_grouped;
+    const int nsets = grouped ? (layer_hi - layer_lo) : 2;
     const int64_t SET = TF + 5 * TE;              // dh | dyA | dyB | d_qkv(3)
     float* set0 = workspace;
-    float* dz2 = set0 + 2 * SET;      // [T x E] LN2 input gradient (residual branch into x1)
+    float* dz2 = set0 + (int64_t)c->L * SET;      // [T x E] LN2 input gradient (residual branch into x1)
+    (void)nsets;
+    TnDesc tn[40];
+    int ntn = 0;
     float* dz1 = dz2 + TE;            // [T x E] LN1 input gradient (residual branch into X[l])
     float* d_attn = dz1 + TE;         // [T x E]
     float* tmp = d_attn + TE;         // [MAX_SPLITS][T x E] partial slabs of dh W1
@@ -268,7 +275,7 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
         const float* sv = saved + so.layers + (int64_t)l * so.per_layer;
         const float* Xl = saved + so.X + (int64_t)l * TE;
         const uint32_t site = SITE_LAYER0 + 4 * l;
-        float* bs = set0 + (l & 1) * SET;
+        float* bs = set0 + (int64_t)(grouped ? (l - layer_lo) : (l & 1)) * SET;
         float* dh = bs;               // [T x F]
         float* dyA = dh + TF;         // [T x E] d(FFN output)
         float* dyB = dyA + TE;        // [T x E] d(attention block output)
@@ -288,7 +295,8 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
                                       G ? G + lo.n2b : nullptr, T, E, c->p_enc, site + 3, rng, add, train, st));
         if (use_aux) { GF_HIP(hipEventRecord(ev[0], st)); GF_HIP(hipStreamWaitEvent(ax, ev[0], 0)); }
         // linear2 wgrad: gW2[E,F] += dyA^T h ; gb2 += colsum(dyA)
-        if (G) GF_TRY(launch_gemm_tn_acc(dyA, E, sv + so.h, F, G + lo.w2, F, G + lo.b2, E, F, T, ax));
+        if (G && grouped) tn[ntn++] = TnDesc{dyA, E, sv + so.h, F, G + lo.w2, F, G + lo.b2, E, F, T};
+        else if (G) GF_TRY(launch_gemm_tn_acc(dyA, E, sv + so.h, F, G + lo.w2, F, G + lo.b2, E, F, T, ax));
         const float mscale = (pdrop > 0.f) ? 1.0f / (1.0f - pdrop) : 1.0f;
         int splits = 1;
         const bool fused = ffn_fused_supported(E, F) && (g_ffn_mode & 4);
@@ -303,7 +311,8 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
         }
         if (use_aux) { GF_HIP(hipEventRecord(ev[1], st)); GF_HIP(hipStreamWaitEvent(ax, ev[1], 0)); }
         // linear1 wgrad: gW1[F,E] += dh^T x1 ; gb1 += colsum(dh)
-        if (G) GF_TRY(launch_gemm_tn_acc(dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T, ax));
+        if (G && grouped) tn[ntn++] = TnDesc{dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T};
+        else if (G) GF_TRY(launch_gemm_tn_acc(dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T, ax));
         if (!fused) {
             // d x1 = dh W1 (split-K slabs) + dz2, consumed directly by the LN1 backward
             splits = gemm_splitk_factor(T, E, F);
@@ -313,14 +322,20 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
                                       G ? G + lo.n1b : nullptr, T, E, c->p_enc, site + 1, rng, add, train, st, splits, TE, dz2));
         if (use_aux) { GF_HIP(hipEventRecord(ev[2], st)); GF_HIP(hipStreamWaitEvent(ax, ev[2], 0)); }
         // out-proj wgrad + dgrad
-        if (G) GF_TRY(launch_gemm_tn_acc(dyB, E, sv + so.attn_o, E, G + lo.out_w, E, G + lo.out_b, E, E, T, ax));
+        if (G && grouped) tn[ntn++] = TnDesc{dyB, E, sv + so.attn_o, E, G + lo.out_w, E, G + lo.out_b, E, E, T};
+        else if (G) GF_TRY(launch_gemm_tn_acc(dyB, E, sv + so.attn_o, E, G + lo.out_w, E, G + lo.out_b, E, E, T, ax));
         GF_TRY(launch_gemm_nn(dyB, E, P + lo.out_w, E, d_attn, E, T, E, E, EPI_NONE, none, st));
         // attention core backward
         GF_TRY(launch_attention_bwd(sv + so.qkv, d_attn, d_qkv, S, B, E, H, c->p_enc, site + 0, rng, add, train, st));
         if (use_aux) { GF_HIP(hipEventRecord(ev[3], st)); GF_HIP(hipStreamWaitEvent(ax, ev[3], 0)); }
         // in-proj wgrad + dgrad; dX[l] = d_qkv W_in + dz1
-        if (G) GF_TRY(launch_gemm_tn_acc(d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T, ax));
+        if (G && grouped) tn[ntn++] = TnDesc{d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T};
+        else if (G) GF_TRY(launch_gemm_tn_acc(d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T, ax));
         if (use_aux) GF_HIP(hipEventRecord(ev[4], ax));
+        if (ntn == 40 || (grouped && l == layer_lo && ntn > 0)) {
+            GF_TRY(launch_gemm_tn_grouped(tn, ntn, st));
+            ntn = 0;
+        }
         EpiArgs eadd;
         eadd.aux_in = dz1;            // dX[l] = d_qkv W_in + dz1 (residual) in the GEMM epilogue
         GF_TRY(launch_gemm_nn(d_qkv, 3 * E, P + lo.in_w, E, dx, E, T, E, 3 * E, EPI_NONE, eadd, st));
@@ -500,7 +515,8 @@ extern "C" int ganffn_ffn_linear1_fwd(const float* x, const float* w1, const flo
     return launch_gemm_nt(x, E, w1, E, h, F, T, F, E, EPI_RELU_DROP, e, (hipStream_t)stream);
 }
 extern "C" int ganffn_debug_set_ffn_mode(int bits) {
-    g_ffn_mode = bits;
+    g_ffn_mode = bits & 7;
+    g_wgrad_grouped = (bits & 8) ? 0 : 1;
     return 0;
 }
 extern "C" int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h,
@@ -516,6 +532,13 @@ extern "C" int ganffn_ffn_fused_bwd(const float* dy, const float* w1, const floa
     int splits = 0;
     GF_TRY(launch_ffn_fused_bwd(dy, w1, w2, h, dh, slabs, (long)T * E, T, E, F, mscale, &splits, (hipStream_t)stream));
     return -1000 - splits;
+}
+extern "C" int ganffn_gemm_tn_grouped(int n, const float* const* At, const float* const* Bm, float* const* C, float* const* colsum,
+                                      const int* M, const int* N, const int* K, void* stream) {
+    GF_CHECK_ARG(n >= 1 && n <= 40 && At && Bm && C && M && N && K, "gemm_tn_grouped: bad arguments");
+    TnDesc d[40];
+    for (int i = 0; i < n; ++i) d[i] = TnDesc{At[i], M[i], Bm[i], N[i], C[i], N[i], colsum ? colsum[i] : nullptr, M[i], N[i], K[i]};
+    return launch_gemm_tn_grouped(d, n, (hipStream_t)stream);
 }
 extern "C" int ganffn_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p, uint32_t site,
                                     const uint64_t* rng, uint64_t add, void* stream) {

@@ -188,6 +188,16 @@ int launch_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const
 int launch_ffn_fused_bwd(const float* dy, const float* w1, const float* w2, const float* h, float* dh, float* slabs,
                          long slab_stride, int T, int E, int F, float mscale, int* splits_out, hipStream_t st);
 
+// grouped wgrad: n independent TN problems in one launch
+struct TnDesc {
+    const float* At; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    float* colsum;
+    int M, N, K;
+};
+int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st);
+
 int launch_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p, uint32_t site,
                          const uint64_t* rng, uint64_t add, int train, hipStream_t st);
 int launch_attention_bwd(const float* qkv, const float* d_o, float* d_qkv, int S, int B, int E, int H, float p,

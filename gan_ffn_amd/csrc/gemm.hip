@@ -107,8 +107,8 @@ struct Smem {
     static constexpr int TOTAL = 2 * STAGE;
 };
 
-template <int MODE, int BM, int BN, int BK, int EPI, int WGM = 2, int WGN = 2>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmArgs g) {
+template <int MODE, int BM, int BN, int BK, int EPI, int WGM, int WGN>
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz) {
     constexpr int NTH = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN;  // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmArgs g) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.kchunk;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nt = (kend - kbeg + BK - 1) / BK;
 
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmArgs g) {
             }
         }
         if (MODE == MODE_TN) {
-            if (g.colsum != nullptr && blockIdx.x == 0 && tid < BM) {
+            if (g.colsum != nullptr && bx == 0 && tid < BM) {
 #pragma unroll
                 for (int k = 0; k < BK; ++k) colsum_acc += sa[k * (BM + 4) + tid];  // zero-filled beyond kend
             }
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmArgs g) {
                     if (row < g.M && col < g.N) atomicAdd(g.C + (size_t)row * g.ldc + col, acc[a][b][i]);
                 }
             }
-        if (g.colsum != nullptr && blockIdx.x == 0 && tid < BM && (m0 + tid) < g.M)
+        if (g.colsum != nullptr && bx == 0 && tid < BM && (m0 + tid) < g.M)
             atomicAdd(g.colsum + m0 + tid, colsum_acc);
         return;
     }
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmArgs g) {
             const bool colok = col < g.N;
             float bias = 0.f;
             if (EPI == EPI_NONE || EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU)
-                if (g.ea.bias != nullptr && colok && blockIdx.z == 0) bias = g.ea.bias[col];
+                if (g.ea.bias != nullptr && colok && bz == 0) bias = g.ea.bias[col];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int rb = m0 + wm * WM + a * 32 + 8 * gq + 4 * h;  // 4 consecutive rows rb..rb+3
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmArgs g) {
                         float v = acc[a][b][gq * 4 + q];
                         if (EPI == EPI_NONE) {
                             v += bias;
-                            if (g.ea.aux_in != nullptr && blockIdx.z == 0) v += g.ea.aux_in[off];   // fused residual / branch add
+                            if (g.ea.aux_in != nullptr && bz == 0) v += g.ea.aux_in[off];   // fused residual / branch add
                         } else if (EPI == EPI_RELU_DROP) {
                             v = fmaxf(v + bias, 0.f) * mult[q];
                         } else if (EPI == EPI_DROP_GELU) {
@@ -288,11 +288,46 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmArgs g) {
                         } else if (EPI == EPI_GELU_BWD) {
                             v = v * gelu_grad_f(g.ea.aux_in[off]);
                         }
-                        g.C[(size_t)blockIdx.z * g.slab_stride + off] = v;
+                        g.C[(size_t)bz * g.slab_stride + off] = v;
                     }
                 }
             }
         }
+}
+
+template <int MODE, int BM, int BN, int BK, int EPI, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmArgs g) {
+    gemm_body<MODE, BM, BN, BK, EPI, WGM, WGN>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped weight-gradient GEMM: up to MAXP independent TN problems (the 4 weight gradients of every encoder layer of
+// a backward pass) in ONE launch.  A 100x100 or 300x100 gradient alone is a 100-block, latency-bound launch; grouped,
+// its workgroups fill the gaps between the 768-block ones and ~30 launch floors per pass disappear.
+constexpr int MAXP = 40;
+struct TnProblem {
+    const float* A; const float* B; float* C; float* colsum;
+    int lda, ldb, ldc, M, N, K, kchunk;
+    int tiles_n, tiles_mn;   // tiles along N, tiles_m * tiles_n
+    int block0;              // first workgroup of this problem
+};
+struct TnGroup {
+    TnProblem p[MAXP];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
+    int pi = 0;
+    const int b = blockIdx.x;
+#pragma unroll 1
+    for (int i = 1; i < grp.n; ++i)
+        if (b >= grp.p[i].block0) pi = i;
+    const TnProblem& q = grp.p[pi];
+    const int local = b - q.block0;
+    const int bz = local / q.tiles_mn, t2 = local - bz * q.tiles_mn;
+    GemmArgs g;
+    g.A = q.A; g.lda = q.lda; g.B = q.B; g.ldb = q.ldb; g.C = q.C; g.ldc = q.ldc; g.colsum = q.colsum;
+    g.M = q.M; g.N = q.N; g.K = q.K; g.kchunk = q.kchunk; g.slab_stride = 0;
+    gemm_body<MODE_TN, 64, 64, 16, EPI_NONE, 2, 2>(g, t2 % q.tiles_n, t2 / q.tiles_n, bz);
 }
 
 int g_gemm_tn_target = 0;
@@ -416,6 +451,44 @@ int launch_gemm_tn_acc(const float* At, int lda, const float* Bm, int ldb, float
     g.kchunk = kchunk;
     if (g_gemm_cfg == 2) return launch_cfg<MODE_TN, 64, 64, 32, EPI_NONE>(g, (int)splits, st);
     return launch_cfg<MODE_TN, 64, 64, 16, EPI_NONE>(g, (int)splits, st);
+}
+
+static void tn_plan(int M, int N, int K, long target_blocks, int* kchunk, int* splits) {
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    long s = (target_blocks + tiles - 1) / tiles;
+    const long maxs = (K + 63) / 64;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    *kchunk = (int)(((K + s - 1) / s + 63) / 64 * 64);
+    *splits = (K + *kchunk - 1) / *kchunk;
+}
+
+// dW_i[M_i x N_i] += At_i^T B_i for n problems in one launch (see gemm_tn_grouped_kernel)
+int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st) {
+    GF_CHECK_ARG(d && n >= 1 && n <= MAXP, "gemm_tn_grouped: n=%d out of [1,%d]", n, MAXP);
+    TnGroup grp;
+    grp.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        GF_TRY(check_common(d[i].At, d[i].lda, d[i].B, d[i].ldb, d[i].C, d[i].M, d[i].N, d[i].K));
+        GF_CHECK_ARG((d[i].M & 3) == 0 && (d[i].N & 3) == 0, "gemm_tn_grouped: M, N must be multiples of 4");
+        TnProblem& q = grp.p[i];
+        q.A = d[i].At; q.B = d[i].B; q.C = d[i].C; q.colsum = d[i].colsum;
+        q.lda = d[i].lda; q.ldb = d[i].ldb; q.ldc = d[i].ldc; q.M = d[i].M; q.N = d[i].N; q.K = d[i].K;
+        int splits;
+        // big problems alone would take ~768 workgroups; in a group the launch is already wide, so fewer, longer splits
+        // (less atomic traffic) are enough
+        tn_plan(d[i].M, d[i].N, d[i].K, g_gemm_tn_target > 0 ? g_gemm_tn_target : (n >= 8 ? 256 : 768), &q.kchunk, &splits);
+        const int tm = (d[i].M + 63) / 64;
+        q.tiles_n = (d[i].N + 63) / 64;
+        q.tiles_mn = tm * q.tiles_n;
+        q.block0 = total;
+        total += q.tiles_mn * splits;
+    }
+    constexpr size_t lds = Smem<MODE_TN, 64, 64, 16>::TOTAL * sizeof(float);
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(256), lds, st, grp);
+    GF_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace ganffn

@@ -192,6 +192,10 @@ int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const
                          uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, int train, void* stream);
 int ganffn_ffn_fused_bwd(const float* dy, const float* w1, const float* w2, const float* h, float* dh,
                          float* slabs, int T, int E, int F, float mscale, void* stream);
+/* n (<= 40) independent problems C_i[M_i x N_i] += At_i[K_i x M_i]^T B_i[K_i x N_i] (+ column sums) in ONE launch: the
+ * deferred weight-gradient GEMMs of all encoder layers of a backward pass (dense leading dimensions) */
+int ganffn_gemm_tn_grouped(int n, const float* const* At, const float* const* Bm, float* const* C,
+                           float* const* colsum, const int* M, const int* N, const int* K, void* stream);
 /* qkv [T x 3E] -> o [T x E]; site = dropout site id; p = 0 disables dropout */
 int ganffn_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p,
                          uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, void* stream);

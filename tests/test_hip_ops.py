@@ -267,3 +267,22 @@ def test_ffn_fused_fwd_bwd(lib, T, p):
     dx = slabs[:-rc - 1000].sum(0)
     assert rel_err(dh, dh_ref) < 2e-5
     assert rel_err(dx, x64.grad) < 3e-5
+
+
+def test_gemm_tn_grouped(lib):
+    """several weight-gradient GEMMs in one launch == each computed separately"""
+    probs = [(100, 2048, 330), (2048, 100, 330), (100, 100, 330), (300, 100, 330), (16, 64, 75), (512, 512, 128)]
+    g = torch.Generator().manual_seed(5)
+    At = [dev(torch.randn(k, m, generator=g)) for (m, n, k) in probs]
+    Bm = [dev(torch.randn(k, n, generator=g)) for (m, n, k) in probs]
+    C0 = [torch.randn(m, n, generator=g) for (m, n, k) in probs]
+    Cd = [dev(c.clone()) for c in C0]
+    Sd = [torch.zeros(m, device="cuda") for (m, n, k) in probs]
+    n = len(probs)
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    ints = lambda i: (C.c_int * n)(*[p[i] for p in probs])
+    lib.call("ganffn_gemm_tn_grouped", n, arr(At), arr(Bm), arr(Cd), arr(Sd), ints(0), ints(1), ints(2), stream())
+    for i, (m, nn, k) in enumerate(probs):
+        ref = C0[i].double() + At[i].double().cpu().T @ Bm[i].double().cpu()
+        assert rel_err(Cd[i], ref) < 3e-6 * max(1, k ** 0.5), probs[i]
+        assert rel_err(Sd[i], At[i].double().cpu().sum(0)) < 3e-6 * max(1, k ** 0.5)
