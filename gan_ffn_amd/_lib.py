@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libganffn.so")
+LIB_PATH = os.environ.get("GANFFN_LIB") or os.path.join(_HERE, "lib", "libganffn.so")   # GANFFN_LIB: tuning-lab builds only
 
 
 class EncCfg(C.Structure):

@@ -48,16 +48,17 @@ struct KcTile {
     static constexpr int TOTALV = ROWS * KV;
     static constexpr int NV = (TOTALV + NTH - 1) / NTH;
     float4 v[NV];
+    // Loads are UNCONDITIONAL (indices clamped into range, out-of-range lanes zeroed by a select afterwards): a load
+    // under a branch makes hipcc wait vmcnt(0) at the next use, which serialises the whole prefetch queue.
     __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int kend, int tid) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = tid + j * NTH;
+            const int i = min(tid + j * NTH, TOTALV - 1);
             const int row = i / KV, kc = (i % KV) << 2;
             const int gr = row0 + row, gk = k0 + kc;
-            if (i < TOTALV && gr < nrows && gk < kend)
-                v[j] = *reinterpret_cast<const float4*>(P + (size_t)gr * ld + gk);
-            else
-                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = (tid + j * NTH < TOTALV) && gr < nrows && gk < kend;
+            const float4 q = *reinterpret_cast<const float4*>(P + (size_t)min(gr, nrows - 1) * ld + max(min(gk, kend - 4), 0));
+            v[j] = ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
@@ -79,13 +80,12 @@ struct KmTile {
     __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int col0, int ncols, int k0, int kend, int tid) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = tid + j * NTH;
+            const int i = min(tid + j * NTH, TOTALV - 1);
             const int kr = i / (COLS / 4), c4 = (i % (COLS / 4)) << 2;
             const int gk = k0 + kr, gc = col0 + c4;
-            if (i < TOTALV && gk < kend && gc < ncols)
-                v[j] = *reinterpret_cast<const float4*>(P + (size_t)gk * ld + gc);
-            else
-                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = (tid + j * NTH < TOTALV) && gk < kend && gc < ncols;
+            const float4 q = *reinterpret_cast<const float4*>(P + (size_t)max(min(gk, kend - 1), 0) * ld + max(min(gc, ncols - 4), 0));
+            v[j] = ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
@@ -106,6 +106,59 @@ struct Smem {
     static constexpr int STAGE = A_FLOATS + B_FLOATS;
     static constexpr int TOTAL = 2 * STAGE;
 };
+
+// Output stage shared by the LDS-tiled and the register-direct kernels: accumulator register i of tile (a, b) holds
+// row mbase + 32a + (i&3) + 8(i>>2) + 4h, column nbase + 32b + r.
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void gemm_store_epilogue(const GemmArgs& g, floatx16 (&acc)[TM][TN], const int mbase, const int nbase,
+                                                    const int bz, const int r, const int h) {
+    DropCtx dc;
+    if (EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU || EPI == EPI_GELU_BWD_DROP)
+        dc = make_drop(g.ea.rng, g.ea.rng_add, g.ea.site, g.ea.p, g.ea.train);
+
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = nbase + b * 32 + r;
+            const bool colok = col < g.N;
+            float bias = 0.f;
+            if (EPI == EPI_NONE || EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU)
+                if (g.ea.bias != nullptr && colok && bz == 0) bias = g.ea.bias[col];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int rb = mbase + a * 32 + 8 * gq + 4 * h;  // 4 consecutive rows rb..rb+3
+                float mult[4] = {1.f, 1.f, 1.f, 1.f};
+                if (EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU || EPI == EPI_GELU_BWD_DROP)
+                    if (colok && rb < g.M) drop_mult4(dc, (uint32_t)(rb >> 2), (uint32_t)g.N, (uint32_t)col, mult);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = rb + q;
+                    if (row < g.M && colok) {
+                        const size_t off = (size_t)row * g.ldc + col;
+                        float v = acc[a][b][gq * 4 + q];
+                        if (EPI == EPI_NONE) {
+                            v += bias;
+                            if (g.ea.aux_in != nullptr && bz == 0) v += g.ea.aux_in[off];   // fused residual / branch add
+                        } else if (EPI == EPI_RELU_DROP) {
+                            v = fmaxf(v + bias, 0.f) * mult[q];
+                        } else if (EPI == EPI_DROP_GELU) {
+                            const float u = (v + bias) * mult[q];
+                            g.ea.aux_out[off] = u;
+                            v = gelu_f(u);
+                        } else if (EPI == EPI_MASK_POS) {
+                            v = (g.ea.aux_in[off] > 0.f) ? v * g.ea.mscale : 0.f;
+                        } else if (EPI == EPI_GELU_BWD_DROP) {
+                            v = v * mult[q] * gelu_grad_f(g.ea.aux_in[off]);
+                        } else if (EPI == EPI_GELU_BWD) {
+                            v = v * gelu_grad_f(g.ea.aux_in[off]);
+                        }
+                        g.C[(size_t)bz * g.slab_stride + off] = v;
+                    }
+                }
+            }
+        }
+}
 
 template <int MODE, int BM, int BN, int BK, int EPI, int WGM, int WGN>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz) {
@@ -247,52 +300,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
         return;
     }
 
-    DropCtx dc;
-    if (EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU || EPI == EPI_GELU_BWD_DROP)
-        dc = make_drop(g.ea.rng, g.ea.rng_add, g.ea.site, g.ea.p, g.ea.train);
-
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int col = n0 + wn * WN + b * 32 + r;
-            const bool colok = col < g.N;
-            float bias = 0.f;
-            if (EPI == EPI_NONE || EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU)
-                if (g.ea.bias != nullptr && colok && bz == 0) bias = g.ea.bias[col];
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int rb = m0 + wm * WM + a * 32 + 8 * gq + 4 * h;  // 4 consecutive rows rb..rb+3
-                float mult[4] = {1.f, 1.f, 1.f, 1.f};
-                if (EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU || EPI == EPI_GELU_BWD_DROP)
-                    if (colok && rb < g.M) drop_mult4(dc, (uint32_t)(rb >> 2), (uint32_t)g.N, (uint32_t)col, mult);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = rb + q;
-                    if (row < g.M && colok) {
-                        const size_t off = (size_t)row * g.ldc + col;
-                        float v = acc[a][b][gq * 4 + q];
-                        if (EPI == EPI_NONE) {
-                            v += bias;
-                            if (g.ea.aux_in != nullptr && bz == 0) v += g.ea.aux_in[off];   // fused residual / branch add
-                        } else if (EPI == EPI_RELU_DROP) {
-                            v = fmaxf(v + bias, 0.f) * mult[q];
-                        } else if (EPI == EPI_DROP_GELU) {
-                            const float u = (v + bias) * mult[q];
-                            g.ea.aux_out[off] = u;
-                            v = gelu_f(u);
-                        } else if (EPI == EPI_MASK_POS) {
-                            v = (g.ea.aux_in[off] > 0.f) ? v * g.ea.mscale : 0.f;
-                        } else if (EPI == EPI_GELU_BWD_DROP) {
-                            v = v * mult[q] * gelu_grad_f(g.ea.aux_in[off]);
-                        } else if (EPI == EPI_GELU_BWD) {
-                            v = v * gelu_grad_f(g.ea.aux_in[off]);
-                        }
-                        g.C[(size_t)bz * g.slab_stride + off] = v;
-                    }
-                }
-            }
-        }
+    gemm_store_epilogue<EPI, TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, bz, r, h);
 }
 
 template <int MODE, int BM, int BN, int BK, int EPI, int WGM = 2, int WGN = 2>

@@ -48,15 +48,28 @@ def bench(kind, M, N, K, cfgs, tn_targets=(0,)):
     print("%s M=%5d N=%5d K=%5d | %s" % (kind, M, N, K, " | ".join(out)), flush=True)
 
 
+def bench_torch(M, N, K, iters=50):
+    a = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda")
+    for _ in range(5):
+        torch.mm(a, w.t())
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        torch.mm(a, w.t())
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    print(f"torch.mm nt M={M:5d} N={N:5d} K={K:5d}: {us:7.1f}us {2.0 * M * N * K / us / 1e6:6.1f}TF", flush=True)
+
+
 if __name__ == "__main__":
-    cfgs = [0, 5, 6, 7, 8, 9]
-    for T in (3008, 6016):
-        for (N, K) in ((300, 100), (2048, 100)):
-            bench("nt", T, N, K, cfgs)
-    for (N, K) in ((1536, 512), (512, 512), (2048, 512), (512, 2048)):
+    cfgs = [1, 2, 7]
+    torch.backends.cuda.matmul.allow_tf32 = False
+    for (N, K) in ((2048, 512), (1536, 512), (512, 512), (512, 2048), (2048, 100)):
         bench("nt", 3008, N, K, cfgs)
-    for T in (3008, 6016):
-        for (N, K) in ((2048, 100),):
-            bench("nn", T, N, K, cfgs)
-    for (N, K) in ((2048, 512), (512, 2048), (512, 512), (512, 1536)):
+        bench_torch(3008, N, K)
+    bench("nt", 6016, 2048, 100, cfgs)
+    for (N, K) in ((2048, 512), (2048, 100), (512, 2048)):
         bench("nn", 3008, N, K, cfgs)
