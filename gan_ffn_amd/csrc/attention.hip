@@ -60,37 +60,75 @@ struct HeadSrc {
 };
 
 template <int NM>
-__device__ __forceinline__ void load_heads(const HeadSrc (&m)[NM], const AttnGeom& g, int b, int tid, int nthreads) {
+__device__ __forceinline__ void load_heads_generic(const HeadSrc (&m)[NM], const AttnGeom& g, int b, int tid, int nthreads) {
     constexpr int U = 8;
     const int hd2 = g.hd >> 1;
     const int per = g.NT * 32 * hd2;          // float2 items per matrix
-    const int total = per * NM;
-    for (int base = tid; base < total; base += nthreads * U) {
-        float2 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = base + u * nthreads;
-            v[u] = make_float2(0.f, 0.f);
-            if (i < total) {
-                const int mi = i / per, k = i - mi * per;
-                const int s = k / hd2, d = (k - s * hd2) * 2;
-                if (s < g.S) {
-                    const float* src = NM == 1 ? m[0].src : (mi == 0 ? m[0].src : (mi == 1 ? m[1 % NM].src : m[2 % NM].src));
-                    const int ld = NM == 1 ? m[0].ld_src : (mi == 0 ? m[0].ld_src : (mi == 1 ? m[1 % NM].ld_src : m[2 % NM].ld_src));
-                    v[u] = *reinterpret_cast<const float2*>(src + (size_t)(s * g.B + b) * ld + d);
+    for (int mi = 0; mi < NM; ++mi) {
+        for (int base = tid; base < per; base += nthreads * U) {
+            float2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = min(base + u * nthreads, per - 1);
+                const int s = i / hd2, d = (i - s * hd2) * 2;
+                const float2 q = *reinterpret_cast<const float2*>(m[mi].src + (size_t)(min(s, g.S - 1) * g.B + b) * m[mi].ld_src + d);
+                v[u] = s < g.S ? q : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * nthreads;
+                if (i < per) {
+                    const int s = i / hd2, d = (i - s * hd2) * 2;
+                    m[mi].dst[s * g.LDH + d] = v[u].x * m[mi].scale;
+                    m[mi].dst[s * g.LDH + d + 1] = v[u].y * m[mi].scale;
+                }
+            }
+        }
+    }
+}
+
+// Compile-time head_dim / tile count: every global load of all NM matrices is issued (from clamped addresses, zeroed
+// by a select for the padding rows) before the first LDS write, so the workgroup pays one memory round trip in all.
+template <int HD, int NT, int NM>
+__device__ __forceinline__ void load_heads(const HeadSrc (&m)[NM], const AttnGeom& g, int b, int tid) {
+    if constexpr (HD == 0) {
+        load_heads_generic<NM>(m, g, b, tid, 64 * NT);
+    } else {
+        constexpr int VEC = (HD % 4 == 0) ? 4 : 2;
+        constexpr int PR = HD / VEC;                  // items per row
+        constexpr int PER = NT * 32 * PR;             // items per matrix
+        constexpr int NTH = 64 * NT;
+        constexpr int U = (PER + NTH - 1) / NTH;      // items per thread per matrix
+        float v[NM][U][VEC];
+#pragma unroll
+        for (int mi = 0; mi < NM; ++mi) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = min(tid + u * NTH, PER - 1);
+                const int s = i / PR, d = (i - s * PR) * VEC;
+                const float* src = m[mi].src + (size_t)(min(s, g.S - 1) * g.B + b) * m[mi].ld_src + d;
+                const bool ok = s < g.S;
+                if constexpr (VEC == 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(src);
+                    v[mi][u][0] = ok ? q.x : 0.f; v[mi][u][1] = ok ? q.y : 0.f;
+                    v[mi][u][2] = ok ? q.z : 0.f; v[mi][u][3] = ok ? q.w : 0.f;
+                } else {
+                    const float2 q = *reinterpret_cast<const float2*>(src);
+                    v[mi][u][0] = ok ? q.x : 0.f; v[mi][u][1] = ok ? q.y : 0.f;
                 }
             }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = base + u * nthreads;
-            if (i < total) {
-                const int mi = i / per, k = i - mi * per;
-                const int s = k / hd2, d = (k - s * hd2) * 2;
-                float* dst = NM == 1 ? m[0].dst : (mi == 0 ? m[0].dst : (mi == 1 ? m[1 % NM].dst : m[2 % NM].dst));
-                const float sc = NM == 1 ? m[0].scale : (mi == 0 ? m[0].scale : (mi == 1 ? m[1 % NM].scale : m[2 % NM].scale));
-                dst[s * g.LDH + d] = v[u].x * sc;
-                dst[s * g.LDH + d + 1] = v[u].y * sc;
+        for (int mi = 0; mi < NM; ++mi) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = tid + u * NTH;
+                if (PER % NTH == 0 || i < PER) {
+                    const int s = i / PR, d = (i - s * PR) * VEC;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) m[mi].dst[s * g.LDH + d + e] = v[mi][u][e] * m[mi].scale;
+                }
             }
         }
     }
@@ -212,7 +250,6 @@ __global__ __launch_bounds__(64 * NT) void attention_fwd_kernel(const float* __r
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
     const int bh = blockIdx.x, b = bh / g.H, head = bh % g.H;
-    const int nth = 64 * NT;
     const size_t HM = (size_t)g.ROWS * g.LDH + 64;
     float* Qs = smem;
     float* Ks = Qs + HM;
@@ -222,7 +259,7 @@ __global__ __launch_bounds__(64 * NT) void attention_fwd_kernel(const float* __r
     {
         const HeadSrc m3[3] = {{Qs, qkv + head * g.hd, ld3, scale}, {Ks, qkv + g.E + head * g.hd, ld3, 1.f},
                                {Vs, qkv + 2 * g.E + head * g.hd, ld3, 1.f}};
-        load_heads<3>(m3, g, b, tid, nth);
+        load_heads<HD, NT, 3>(m3, g, b, tid);
     }
     __syncthreads();
 
@@ -277,19 +314,27 @@ __global__ __launch_bounds__(64 * NT) void attention_bwd_kernel(const float* __r
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
     const int bh = blockIdx.x, b = bh / g.H, head = bh % g.H;
-    const int nth = 64 * NT;
     const size_t HM = (size_t)g.ROWS * g.LDH + 64;
-    float* RA = smem;        // Q, later dO
-    float* RB = RA + HM;     // K
-    float* RC = RB + HM;     // V, later Q
-    float* SS = RC + HM;     // P~^T [key][query], later dS^T
+    // All four operand matrices stay resident in LDS when they fit (one global-load round trip, one barrier fewer);
+    // otherwise dO overwrites Q and the re-loaded Q overwrites V (ALIAS).  Same rule on the host: launch_attention_bwd().
+    constexpr bool ALIAS = (HD == 0) || (HD * NT > 192);
+    float* RA = smem;                        // scaled Q   (ALIAS: later dO)
+    float* RB = RA + HM;                     // K
+    float* RC = RB + HM;                     // V          (ALIAS: later scaled Q)
+    float* RD = ALIAS ? RA : RC + HM;        // dO
+    float* SS = (ALIAS ? RC : RD) + HM;      // P~^T [key][query], later dS^T
+    float* QS = ALIAS ? RC : RA;             // scaled Q as read by the dK product
     const int ld3 = 3 * g.E;
     const float scale = rsqrtf((float)g.hd);
 
-    {
+    if constexpr (ALIAS) {
         const HeadSrc m3[3] = {{RA, qkv + head * g.hd, ld3, scale}, {RB, qkv + g.E + head * g.hd, ld3, 1.f},
                                {RC, qkv + 2 * g.E + head * g.hd, ld3, 1.f}};
-        load_heads<3>(m3, g, b, tid, nth);
+        load_heads<HD, NT, 3>(m3, g, b, tid);
+    } else {
+        const HeadSrc m4[4] = {{RA, qkv + head * g.hd, ld3, scale}, {RB, qkv + g.E + head * g.hd, ld3, 1.f},
+                               {RC, qkv + 2 * g.E + head * g.hd, ld3, 1.f}, {RD, d_o + head * g.hd, g.E, 1.f}};
+        load_heads<HD, NT, 4>(m4, g, b, tid);
     }
     __syncthreads();
 
@@ -318,14 +363,14 @@ __global__ __launch_bounds__(64 * NT) void attention_bwd_kernel(const float* __r
         }
     }
     __syncthreads();                                           // all waves are done with Q; P~^T complete
-    {
+    if constexpr (ALIAS) {
         const HeadSrc m1[1] = {{RA, d_o + head * g.hd, g.E, 1.f}};   // dO over Q
-        load_heads<1>(m1, g, b, tid, nth);
+        load_heads<HD, NT, 1>(m1, g, b, tid);
+        __syncthreads();
     }
-    __syncthreads();
 
     // dP~^T = V dO^T (same structure as the scores)
-    scores_T<HD, NT>(dp, RC, RA, g.LDH, g.hd, 32 * w, r, h);
+    scores_T<HD, NT>(dp, RC, RD, g.LDH, g.hd, 32 * w, r, h);
     // D_i = sum_j dP_ij P_ij with dP = keep*scale*dP~ ;  dS = P * (dP - D)
     {
         float dsum = 0.f;
@@ -373,7 +418,7 @@ __global__ __launch_bounds__(64 * NT) void attention_bwd_kernel(const float* __r
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
         const float* pa = SS + (32 * w + r) * g.LDP + h;
-        const float* pb = RA + h * g.LDH + r;
+        const float* pb = RD + h * g.LDH + r;
         const int ks = (g.S + 1) >> 1;   // queries 0 .. S_even-1 (rows beyond S of dO / Q are zero)
 #pragma unroll 4
         for (int s = 0; s < ks; ++s) {
@@ -406,9 +451,9 @@ __global__ __launch_bounds__(64 * NT) void attention_bwd_kernel(const float* __r
             }
         }
     }
-    {
+    if constexpr (ALIAS) {
         const HeadSrc m1[1] = {{RC, qkv + head * g.hd, ld3, scale}};  // scaled Q over V
-        load_heads<1>(m1, g, b, tid, nth);
+        load_heads<HD, NT, 1>(m1, g, b, tid);
     }
     __syncthreads();
     // dK[j][d] = sum_i dS^T[j][i] (scale*Q)[i][d]
@@ -419,7 +464,7 @@ __global__ __launch_bounds__(64 * NT) void attention_bwd_kernel(const float* __r
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
         const float* pa = SS + (32 * w + r) * g.LDP + h;
-        const float* pb = RC + h * g.LDH + r;
+        const float* pb = QS + h * g.LDH + r;
         const int ks = (g.S + 1) >> 1;   // queries 0 .. S_even-1 (rows beyond S of dO / Q are zero)
 #pragma unroll 4
         for (int s = 0; s < ks; ++s) {
@@ -505,7 +550,9 @@ int launch_attention_bwd(const float* qkv, const float* d_o, float* d_qkv, int S
     GF_CHECK_ARG(qkv && d_o && d_qkv, "attention_bwd: null pointer");
     GF_CHECK_ARG(!(train && p > 0.f) || rng, "attention_bwd: rng required when dropout is active");
     const AttnGeom g = make_geom(S, B, E, H);
-    const size_t lds = (3 * hd_mat_floats(g) + ss_mat_floats(g)) * sizeof(float);
+    const int hdt = (g.hd == 10 || g.hd == 64) ? g.hd : 0;      // kernel template head_dim (0 = generic)
+    const bool alias = hdt == 0 || hdt * g.NT > 192;            // == attention_bwd_kernel::ALIAS
+    const size_t lds = ((alias ? 3 : 4) * hd_mat_floats(g) + ss_mat_floats(g)) * sizeof(float);
     GF_CHECK_ARG(lds <= 160 * 1024, "attention_bwd: LDS need %zu > 160 KiB", lds);
     if (g.hd == 10) { NT_SWITCH(launch_bwd_t, 10, qkv, d_o, d_qkv, g, lds, p, site, rng, add, train, st) }
     if (g.hd == 64) { NT_SWITCH(launch_bwd_t, 64, qkv, d_o, d_qkv, g, lds, p, site, rng, add, train, st) }

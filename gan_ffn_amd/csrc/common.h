@@ -87,10 +87,15 @@ __device__ __forceinline__ DropCtx make_drop(const uint64_t* rng, uint64_t add, 
 
 __device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                         uint32_t k1, uint32_t (&out)[4]) {
+    // one v_mad_u64_u32 per 32x32->64 product (hipcc would emit v_mul_hi_u32 + v_mul_lo_u32, both quarter-rate)
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint64_t p0, p1, cy0, cy1;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p0), "=s"(cy0) : "s"(M0), "v"(c0));
+        asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p1), "=s"(cy1) : "s"(M1), "v"(c2));
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0;
         const uint32_t n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
