@@ -32,6 +32,7 @@ SIGNATURES = {
     "ganffn_layer_param_count": (_L, [_I, _I]),
     "ganffn_layer_param_offsets": (_I, [_I, _I, C.POINTER(C.c_int64)]),
     "ganffn_encoder_saved_floats": (_L, [_PE]),
+    "ganffn_encoder_saved_hidden_offset": (_L, [_PE, _I]),
     "ganffn_encoder_workspace_floats": (_L, [_PE]),
     "ganffn_head_saved_floats": (_L, [_PH]),
     "ganffn_head_workspace_floats": (_L, [_PH]),

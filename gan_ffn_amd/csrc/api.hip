@@ -127,6 +127,11 @@ extern "C" int64_t ganffn_encoder_saved_floats(const ganffn_enc_cfg* c) {
     if (check_cfg(c) != 0) return -1;
     return saved_off(c).total;
 }
+extern "C" int64_t ganffn_encoder_saved_hidden_offset(const ganffn_enc_cfg* c, int layer) {
+    if (check_cfg(c) != 0 || layer < 0 || layer >= c->L) return -1;
+    const SavedOff so = saved_off(c);
+    return so.layers + (int64_t)layer * so.per_layer + so.h;
+}
 extern "C" int64_t ganffn_encoder_workspace_floats(const ganffn_enc_cfg* c) {
     if (check_cfg(c) != 0) return -1;
     return enc_ws_floats(c);

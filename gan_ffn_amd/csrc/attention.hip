@@ -141,15 +141,39 @@ __device__ __forceinline__ void load_heads(const HeadSrc (&m)[NM], const AttnGeo
 template <int HD, int NT>
 __device__ __forceinline__ void scores_T(floatx16 (&acc)[NT], const float* __restrict__ Km,
                                          const float* __restrict__ Qm, int LDH, int hd, int q0, int r, int h) {
-    const int steps = (HD ? HD : hd) >> 1;
     const float* pb = Qm + (q0 + r) * LDH + h;
     const float* pa = Km + r * LDH + h;
-#pragma unroll 4
-    for (int s = 0; s < steps; ++s) {
-        const float b = pb[2 * s];
+    if constexpr (HD != 0) {
+        // operands of a whole batch of k-steps are read from LDS before the first MFMA of the batch (left to itself
+        // hipcc reuses one register: ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, a full LDS latency per MFMA)
+        constexpr int STEPS = HD >> 1;
+        constexpr int BT = STEPS < 8 ? STEPS : 8;
+        static_assert(STEPS % BT == 0, "head_dim/2 must be a multiple of the batch");
 #pragma unroll
-        for (int c = 0; c < NT; ++c)
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c * 32 * LDH + 2 * s], b, acc[c], 0, 0, 0);
+        for (int s0 = 0; s0 < STEPS; s0 += BT) {
+            float bv[BT], av[BT][NT];
+#pragma unroll
+            for (int j = 0; j < BT; ++j) {
+                bv[j] = pb[2 * (s0 + j)];
+#pragma unroll
+                for (int c = 0; c < NT; ++c) av[j][c] = pa[c * 32 * LDH + 2 * (s0 + j)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < BT; ++j)
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][c], bv[j], acc[c], 0, 0, 0);
+        }
+    } else {
+        const int steps = hd >> 1;
+#pragma unroll 4
+        for (int s = 0; s < steps; ++s) {
+            const float b = pb[2 * s];
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c * 32 * LDH + 2 * s], b, acc[c], 0, 0, 0);
+        }
     }
 }
 
@@ -157,16 +181,56 @@ __device__ __forceinline__ void scores_T(floatx16 (&acc)[NT], const float* __res
 template <int NT, int NTD>
 __device__ __forceinline__ void apply_T(floatx16 (&out)[NTD], const floatx16 (&P)[NT],
                                         const float* __restrict__ Mm, int LDH, int r, int h) {
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
+    float av[2][16][NTD];
+    auto fetch = [&](int c, float (&dst)[16][NTD]) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const float* row = Mm + (32 * c + krow(s, h)) * LDH + r;
+#pragma unroll
+            for (int dt = 0; dt < NTD; ++dt) dst[s][dt] = row[32 * dt];
+        }
+    };
+    fetch(0, av[0]);
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        if (c + 1 < NT) fetch(c + 1, av[(c + 1) & 1]);   // next key tile's operands are in flight under this tile's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
             const float b = P[c][s];
 #pragma unroll
             for (int dt = 0; dt < NTD; ++dt)
-                out[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(row[32 * dt], b, out[dt], 0, 0, 0);
+                out[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][s][dt], b, out[dt], 0, 0, 0);
         }
+    }
+}
+
+// acc[t] (rows 32w + .., cols d) += sum_i A[row][i] * Bm[i][32t + r]  over i = 0 .. 2*ks-1, operands batched like above
+template <int NTD>
+__device__ __forceinline__ void rows_T(floatx16 (&acc)[NTD], const float* __restrict__ pa, const float* __restrict__ pb,
+                                       int LDH, int ks) {
+    constexpr int BT = 8;
+    int s = 0;
+    for (; s + BT <= ks; s += BT) {
+        float a[BT], bv[BT][NTD];
+#pragma unroll
+        for (int j = 0; j < BT; ++j) {
+            a[j] = pa[2 * (s + j)];
+#pragma unroll
+            for (int t = 0; t < NTD; ++t) bv[j][t] = pb[2 * (s + j) * LDH + 32 * t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < BT; ++j)
+#pragma unroll
+            for (int t = 0; t < NTD; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv[j][t], acc[t], 0, 0, 0);
+    }
+    for (; s < ks; ++s) {
+        const float a = pa[2 * s];
+#pragma unroll
+        for (int t = 0; t < NTD; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[2 * s * LDH + 32 * t], acc[t], 0, 0, 0);
     }
 }
 
@@ -420,13 +484,7 @@ __global__ __launch_bounds__(64 * NT) void attention_bwd_kernel(const float* __r
         const float* pa = SS + (32 * w + r) * g.LDP + h;
         const float* pb = RD + h * g.LDH + r;
         const int ks = (g.S + 1) >> 1;   // queries 0 .. S_even-1 (rows beyond S of dO / Q are zero)
-#pragma unroll 4
-        for (int s = 0; s < ks; ++s) {
-            const float a = pa[2 * s];
-#pragma unroll
-            for (int t = 0; t < NTD; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[2 * s * g.LDH + 32 * t], acc[t], 0, 0, 0);
-        }
+        rows_T<NTD>(acc, pa, pb, g.LDH, ks);
 #pragma unroll
         for (int t = 0; t < NTD; ++t) {
             const int d = 32 * t + r;
@@ -466,13 +524,7 @@ __global__ __launch_bounds__(64 * NT) void attention_bwd_kernel(const float* __r
         const float* pa = SS + (32 * w + r) * g.LDP + h;
         const float* pb = QS + h * g.LDH + r;
         const int ks = (g.S + 1) >> 1;   // queries 0 .. S_even-1 (rows beyond S of dO / Q are zero)
-#pragma unroll 4
-        for (int s = 0; s < ks; ++s) {
-            const float a = pa[2 * s];
-#pragma unroll
-            for (int t = 0; t < NTD; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[2 * s * g.LDH + 32 * t], acc[t], 0, 0, 0);
-        }
+        rows_T<NTD>(acc, pa, pb, g.LDH, ks);
 #pragma unroll
         for (int t = 0; t < NTD; ++t) {
             const int d = 32 * t + r;

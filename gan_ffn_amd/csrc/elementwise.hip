@@ -76,6 +76,10 @@ __global__ void add3_kernel(const float* __restrict__ a, const float* __restrict
 constexpr int LN_MAXC = 8;  // E <= 512
 constexpr int LN_MAXSLAB = 16;  // split-K / split-F slabs summed on the fly (api.hip MAX_SPLITS)
 
+// NC = column chunks of 64 per lane (E <= 64 NC); NSB = slabs loaded per batch.  Every global load is issued from a
+// clamped (always valid) address and masked afterwards by a select: a load under a branch makes hipcc wait for it
+// (s_waitcnt vmcnt(0)) before the next one is issued, which serialised ~100 loads per lane in the first version.
+template <int NC, int NSB>
 __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ w, const float* __restrict__ b,
                                                               float* __restrict__ out, float* __restrict__ xhat,
@@ -86,35 +90,54 @@ __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __res
     const int rg = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rg * 4 >= T) return;
     const DropCtx dc = make_drop(rng, add, site, p, train);
-    float z[LN_MAXC][4];
+    size_t off[NC][4];      // element offsets (clamped)
+    bool okc[NC], okr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) okr[q] = rg * 4 + q < T;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int c = lane + 64 * k;
+        okc[k] = c < E;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) off[k][q] = (size_t)min(rg * 4 + q, T - 1) * E + min(c, E - 1);
+    }
+    float xv[NC][4], yy[NC][4];
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            xv[k][q] = x[off[k][q]];
+            yy[k][q] = 0.f;
+        }
+    for (int s0 = 0; s0 < nslab; s0 += NSB) {
+        float v[NSB][NC][4];
+#pragma unroll
+        for (int j = 0; j < NSB; ++j) {
+            const float* ys = y + (size_t)min(s0 + j, nslab - 1) * slab_stride;
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[j][k][q] = ys[off[k][q]];
+        }
+#pragma unroll
+        for (int j = 0; j < NSB; ++j) {
+            const float m = (s0 + j < nslab) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) yy[k][q] += m * v[j][k][q];
+        }
+    }
+    float z[NC][4];
     float sum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < LN_MAXC; ++k) {
-        const int c = lane + 64 * k;
-        if (c < E) {
-            float mult[4];
-            drop_mult4(dc, (uint32_t)rg, (uint32_t)E, (uint32_t)c, mult);
+    for (int k = 0; k < NC; ++k) {
+        float mult[4];
+        drop_mult4(dc, (uint32_t)rg, (uint32_t)E, (uint32_t)(lane + 64 * k), mult);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int t = rg * 4 + q;
-                float v = 0.f;
-                if (t < T) {
-                    // all slab loads are issued before the first add (a runtime-bounded loop would serialise them)
-                    float ys[LN_MAXSLAB];
-#pragma unroll
-                    for (int sl = 0; sl < LN_MAXSLAB; ++sl)
-                        ys[sl] = (sl < nslab) ? y[(size_t)sl * slab_stride + (size_t)t * E + c] : 0.f;
-                    float yy = ys[0];
-#pragma unroll
-                    for (int sl = 1; sl < LN_MAXSLAB; ++sl) yy += ys[sl];
-                    v = x[(size_t)t * E + c] + yy * mult[q];
-                }
-                z[k][q] = v;
-                sum[q] += v;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) z[k][q] = 0.f;
+        for (int q = 0; q < 4; ++q) {
+            z[k][q] = (okc[k] && okr[q]) ? xv[k][q] + yy[k][q] * mult[q] : 0.f;
+            sum[q] += z[k][q];
         }
     }
     const float invE = 1.0f / (float)E;
@@ -123,31 +146,25 @@ __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __res
     for (int q = 0; q < 4; ++q) mean[q] = wave_sum(sum[q]) * invE;
     float var[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < LN_MAXC; ++k) {
-        const int c = lane + 64 * k;
-        if (c < E) {
+    for (int k = 0; k < NC; ++k) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float d = z[k][q] - mean[q];
-                var[q] += d * d;
-            }
+        for (int q = 0; q < 4; ++q) {
+            const float d = okc[k] ? z[k][q] - mean[q] : 0.f;
+            var[q] += d * d;
         }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) rs[q] = rsqrtf(wave_sum(var[q]) * invE + eps);
 #pragma unroll
-    for (int k = 0; k < LN_MAXC; ++k) {
-        const int c = lane + 64 * k;
-        if (c < E) {
-            const float ww = w[c], bb = b[c];
+    for (int k = 0; k < NC; ++k) {
+        const int c = min(lane + 64 * k, E - 1);
+        const float ww = w[c], bb = b[c];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int t = rg * 4 + q;
-                if (t < T) {
-                    const float xh = (z[k][q] - mean[q]) * rs[q];
-                    if (xhat) xhat[(size_t)t * E + c] = xh;
-                    out[(size_t)t * E + c] = xh * ww + bb;
-                }
+        for (int q = 0; q < 4; ++q) {
+            if (okc[k] && okr[q]) {
+                const float xh = (z[k][q] - mean[q]) * rs[q];
+                if (xhat) xhat[off[k][q]] = xh;
+                out[off[k][q]] = xh * ww + bb;
             }
         }
     }
@@ -156,6 +173,7 @@ __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __res
 
 // backward: g = d_out * w; dz = rstd * (g - mean(g) - xhat * mean(g * xhat)); dy = dz * dropmult
 // gw += sum_t d_out * xhat, gb += sum_t d_out   (per-block partial sums in registers -> LDS -> atomics)
+template <int NC, int NSB>
 __global__ __launch_bounds__(256) void add_drop_ln_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ xhat,
                                                               const float* __restrict__ rstd, const float* __restrict__ w,
                                                               float* __restrict__ dz, float* __restrict__ dy,
@@ -163,76 +181,99 @@ __global__ __launch_bounds__(256) void add_drop_ln_bwd_kernel(const float* __res
                                                               float p, uint32_t site, const uint64_t* __restrict__ rng,
                                                               uint64_t add, int train, int nslab, long slab_stride,
                                                               const float* __restrict__ addend) {
-    __shared__ float red[2][4][64 * LN_MAXC];
+    __shared__ float red[2][4][64 * NC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const DropCtx dc = make_drop(rng, add, site, p, train);
     const int G = (T + 3) >> 2;
     const float invE = 1.0f / (float)E;
-    float aw[LN_MAXC], ab[LN_MAXC], wreg[LN_MAXC];
+    float aw[NC], ab[NC], wreg[NC];
+    bool okc[NC];
 #pragma unroll
-    for (int k = 0; k < LN_MAXC; ++k) {
+    for (int k = 0; k < NC; ++k) {
         aw[k] = 0.f; ab[k] = 0.f;
         const int c = lane + 64 * k;
-        wreg[k] = (c < E) ? w[c] : 0.f;
+        okc[k] = c < E;
+        wreg[k] = w[min(c, E - 1)];
     }
     for (int rg = blockIdx.x * 4 + wv; rg < G; rg += gridDim.x * 4) {
-        float g[LN_MAXC][4], xh[LN_MAXC][4];
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        size_t off[NC][4];
+        bool okr[4];
+        float rs[4];
 #pragma unroll
-        for (int k = 0; k < LN_MAXC; ++k) {
-            const int c = lane + 64 * k;
+        for (int q = 0; q < 4; ++q) {
+            okr[q] = rg * 4 + q < T;
+            rs[q] = rstd[min(rg * 4 + q, T - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) off[k][q] = (size_t)min(rg * 4 + q, T - 1) * E + min(lane + 64 * k, E - 1);
+        float d[NC][4], xh[NC][4];
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int t = rg * 4 + q;
-                float d = 0.f, h = 0.f;
-                if (c < E && t < T) {
-                    float ds[LN_MAXSLAB];
+                xh[k][q] = xhat[off[k][q]];
+                d[k][q] = addend ? addend[off[k][q]] : 0.f;
+            }
+        for (int s0 = 0; s0 < nslab; s0 += NSB) {
+            float v[NSB][NC][4];
 #pragma unroll
-                    for (int sl = 0; sl < LN_MAXSLAB; ++sl)
-                        ds[sl] = (sl < nslab) ? d_out[(size_t)sl * slab_stride + (size_t)t * E + c] : 0.f;
-                    const float ad = addend ? addend[(size_t)t * E + c] : 0.f;
-                    h = xhat[(size_t)t * E + c];
-                    d = ds[0] + ad;
+            for (int j = 0; j < NSB; ++j) {
+                const float* ds = d_out + (size_t)min(s0 + j, nslab - 1) * slab_stride;
 #pragma unroll
-                    for (int sl = 1; sl < LN_MAXSLAB; ++sl) d += ds[sl];
-                }
-                aw[k] += d * h;
-                ab[k] += d;
-                g[k][q] = d * wreg[k];
+                for (int k = 0; k < NC; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[j][k][q] = ds[off[k][q]];
+            }
+#pragma unroll
+            for (int j = 0; j < NSB; ++j) {
+                const float m = (s0 + j < nslab) ? 1.f : 0.f;
+#pragma unroll
+                for (int k = 0; k < NC; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) d[k][q] += m * v[j][k][q];
+            }
+        }
+        float g[NC][4];
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool ok = okc[k] && okr[q];
+                const float dd = ok ? d[k][q] : 0.f, h = ok ? xh[k][q] : 0.f;
                 xh[k][q] = h;
+                aw[k] += dd * h;
+                ab[k] += dd;
+                g[k][q] = dd * wreg[k];
                 s1[q] += g[k][q];
                 s2[q] += g[k][q] * h;
             }
         }
-        float c1[4], c2[4], rs[4];
+        float c1[4], c2[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             c1[q] = wave_sum(s1[q]) * invE;
             c2[q] = wave_sum(s2[q]) * invE;
-            const int t = rg * 4 + q;
-            rs[q] = (t < T) ? rstd[t] : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < LN_MAXC; ++k) {
-            const int c = lane + 64 * k;
-            if (c < E) {
-                float mult[4] = {1.f, 1.f, 1.f, 1.f};
-                if (dy) drop_mult4(dc, (uint32_t)rg, (uint32_t)E, (uint32_t)c, mult);
+        for (int k = 0; k < NC; ++k) {
+            float mult[4] = {1.f, 1.f, 1.f, 1.f};
+            if (dy) drop_mult4(dc, (uint32_t)rg, (uint32_t)E, (uint32_t)(lane + 64 * k), mult);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int t = rg * 4 + q;
-                    if (t < T) {
-                        const float v = rs[q] * (g[k][q] - c1[q] - xh[k][q] * c2[q]);
-                        dz[(size_t)t * E + c] = v;
-                        if (dy) dy[(size_t)t * E + c] = v * mult[q];
-                    }
+            for (int q = 0; q < 4; ++q) {
+                if (okc[k] && okr[q]) {
+                    const float v = rs[q] * (g[k][q] - c1[q] - xh[k][q] * c2[q]);
+                    dz[off[k][q]] = v;
+                    if (dy) dy[off[k][q]] = v * mult[q];
                 }
             }
         }
     }
     if (gw == nullptr) return;
 #pragma unroll
-    for (int k = 0; k < LN_MAXC; ++k) {
+    for (int k = 0; k < NC; ++k) {
         red[0][wv][lane + 64 * k] = aw[k];
         red[1][wv][lane + 64 * k] = ab[k];
     }
@@ -514,8 +555,15 @@ int launch_add_drop_ln_fwd(const float* x, const float* y, const float* w, const
     GF_CHECK_ARG(E <= 64 * LN_MAXC, "layernorm: E=%d > %d", E, 64 * LN_MAXC);
     GF_CHECK_ARG(nslab >= 1 && nslab <= LN_MAXSLAB, "layernorm: nslab=%d out of [1,%d]", nslab, LN_MAXSLAB);
     const int G = (T + 3) / 4;
-    hipLaunchKernelGGL(add_drop_ln_fwd_kernel, dim3((G + 3) / 4), dim3(256), 0, st, x, y, w, b, out, xhat, rstd, T, E, eps, p,
-                       site, rng, add, train, nslab, slab_stride);
+    const dim3 grid((G + 3) / 4), blk(256);
+#define GF_LN_FWD(NC, NSB)                                                                                              \
+    hipLaunchKernelGGL((add_drop_ln_fwd_kernel<NC, NSB>), grid, blk, 0, st, x, y, w, b, out, xhat, rstd, T, E, eps, p, \
+                       site, rng, add, train, nslab, slab_stride)
+    if (E <= 64) GF_LN_FWD(1, 8);
+    else if (E <= 128) GF_LN_FWD(2, 8);
+    else if (E <= 256) GF_LN_FWD(4, 4);
+    else GF_LN_FWD(8, 2);
+#undef GF_LN_FWD
     GF_LAUNCH_CHECK();
     return 0;
 }
@@ -529,8 +577,15 @@ int launch_add_drop_ln_bwd(const float* d_out, const float* xhat, const float* r
     const int G = (T + 3) / 4;
     int blocks = (G + 3) / 4;
     if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(add_drop_ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, d_out, xhat, rstd, w, dz, dy, gw, gb, T, E, p,
-                       site, rng, add, train, nslab, slab_stride, addend);
+    const dim3 grid(blocks), blk(256);
+#define GF_LN_BWD(NC, NSB)                                                                                            \
+    hipLaunchKernelGGL((add_drop_ln_bwd_kernel<NC, NSB>), grid, blk, 0, st, d_out, xhat, rstd, w, dz, dy, gw, gb, T, \
+                       E, p, site, rng, add, train, nslab, slab_stride, addend)
+    if (E <= 64) GF_LN_BWD(1, 8);
+    else if (E <= 128) GF_LN_BWD(2, 8);
+    else if (E <= 256) GF_LN_BWD(4, 4);
+    else GF_LN_BWD(8, 2);
+#undef GF_LN_BWD
     GF_LAUNCH_CHECK();
     return 0;
 }

@@ -79,6 +79,9 @@ int ganffn_layer_param_offsets(int E, int F, int64_t* offsets12);
 /* ---- sizes the caller must allocate ------------------------------------------------ */
 int64_t ganffn_encoder_saved_floats(const ganffn_enc_cfg* cfg);     /* saved-for-backward */
 int64_t ganffn_encoder_workspace_floats(const ganffn_enc_cfg* cfg); /* scratch, fwd or bwd */
+/* float offset, inside `saved`, of layer `layer`'s FFN hidden activation h = drop(relu(x1 W1^T + b1)) [T x F]
+ * (inspection hook: tests read the ReLU pattern the forward pass actually took); -1 on a bad cfg / layer */
+int64_t ganffn_encoder_saved_hidden_offset(const ganffn_enc_cfg* cfg, int layer);
 int64_t ganffn_head_saved_floats(const ganffn_head_cfg* cfg);
 int64_t ganffn_head_workspace_floats(const ganffn_head_cfg* cfg);
 

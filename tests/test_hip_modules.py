@@ -74,7 +74,21 @@ def test_train_mode_matches_oracle_with_same_masks(cls_name, din, S, B):
     xin = xo
     if has_obj and din == 512:
         xin = xo @ onet.P["object.weight"].T + onet.P["object.bias"]
-    h = O.encoder_stack(xin, onet.P, H, O.Rng(seed, 0, True))
+    # The oracle takes the ReLU pattern the HIP forward pass actually took (read back from its saved hidden
+    # activations): of ~6M hidden units per pass a few sit within fp32 rounding of zero, and which side they land on
+    # is implementation noise that would otherwise show up as a one-token gradient difference.
+    import ctypes as C
+    from gan_ffn_amd import _lib
+    enc_node = y.grad_fn.next_functions[0][0]
+    T_, F_hid = S * B, int(enc_node.cfg.F)
+    masks = []
+    for l in range(8):
+        off = int(_lib.load().ganffn_encoder_saved_hidden_offset(C.byref(enc_node.cfg), l))
+        assert off >= 0
+        hsav = enc_node.saved[off:off + T_ * F_hid].view(S, B, F_hid)
+        # dropped units read 0 here; their gradient is 0 whatever the pattern says
+        masks.append((hsav != 0).double().cpu())
+    h = O.encoder_stack(xin, onet.P, H, O.Rng(seed, 0, True), relu_masks=masks)
     r1 = O.Rng(seed, 1, True)
     if kind == "gen":
         t = O._drop(O.gelu(h), 0.2, O.SITE_HEAD0, r1)
