@@ -116,6 +116,35 @@ __device__ __forceinline__ void gemm_store_epilogue(const GemmArgs& g, floatx16 
     if (EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU || EPI == EPI_GELU_BWD_DROP)
         dc = make_drop(g.ea.rng, g.ea.rng_add, g.ea.site, g.ea.p, g.ea.train);
 
+    // Epilogue operand (residual / saved activation): ALL loads of the wave tile are issued first, from clamped
+    // (always valid) offsets — a load under the per-element bounds test makes hipcc wait for it before the next
+    // one is issued (16 serialised round trips per tile in the first version of this epilogue).
+    constexpr bool HAS_AUX = EPI == EPI_NONE || EPI == EPI_MASK_POS || EPI == EPI_GELU_BWD_DROP || EPI == EPI_GELU_BWD;
+    float aux[TM][TN][16];
+    if (HAS_AUX) {
+        const bool want = (EPI == EPI_NONE) ? (g.ea.aux_in != nullptr && bz == 0) : true;   // wave-uniform
+        if (want) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int col = min(nbase + b * 32 + r, g.N - 1);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = min(mbase + a * 32 + 8 * (i >> 2) + 4 * h + (i & 3), g.M - 1);
+                        aux[a][b][i] = g.ea.aux_in[(size_t)row * g.ldc + col];
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) aux[a][b][i] = 0.f;
+        }
+    }
+
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -124,35 +153,37 @@ __device__ __forceinline__ void gemm_store_epilogue(const GemmArgs& g, floatx16 
             const bool colok = col < g.N;
             float bias = 0.f;
             if (EPI == EPI_NONE || EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU)
-                if (g.ea.bias != nullptr && colok && bz == 0) bias = g.ea.bias[col];
+                if (g.ea.bias != nullptr && bz == 0) bias = g.ea.bias[min(col, g.N - 1)];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int rb = mbase + a * 32 + 8 * gq + 4 * h;  // 4 consecutive rows rb..rb+3
                 float mult[4] = {1.f, 1.f, 1.f, 1.f};
                 if (EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU || EPI == EPI_GELU_BWD_DROP)
-                    if (colok && rb < g.M) drop_mult4(dc, (uint32_t)(rb >> 2), (uint32_t)g.N, (uint32_t)col, mult);
+                    drop_mult4(dc, (uint32_t)(rb >> 2), (uint32_t)g.N, (uint32_t)col, mult);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = rb + q;
+                    const size_t off = (size_t)row * g.ldc + col;
+                    float v = acc[a][b][gq * 4 + q];
+                    float u = 0.f;
+                    const float ax = HAS_AUX ? aux[a][b][gq * 4 + q] : 0.f;
+                    if (EPI == EPI_NONE) {
+                        v += bias;
+                        v += ax;                                   // fused residual / branch add (0 when absent)
+                    } else if (EPI == EPI_RELU_DROP) {
+                        v = fmaxf(v + bias, 0.f) * mult[q];
+                    } else if (EPI == EPI_DROP_GELU) {
+                        u = (v + bias) * mult[q];
+                        v = gelu_f(u);
+                    } else if (EPI == EPI_MASK_POS) {
+                        v = (ax > 0.f) ? v * g.ea.mscale : 0.f;
+                    } else if (EPI == EPI_GELU_BWD_DROP) {
+                        v = v * mult[q] * gelu_grad_f(ax);
+                    } else if (EPI == EPI_GELU_BWD) {
+                        v = v * gelu_grad_f(ax);
+                    }
                     if (row < g.M && colok) {
-                        const size_t off = (size_t)row * g.ldc + col;
-                        float v = acc[a][b][gq * 4 + q];
-                        if (EPI == EPI_NONE) {
-                            v += bias;
-                            if (g.ea.aux_in != nullptr && bz == 0) v += g.ea.aux_in[off];   // fused residual / branch add
-                        } else if (EPI == EPI_RELU_DROP) {
-                            v = fmaxf(v + bias, 0.f) * mult[q];
-                        } else if (EPI == EPI_DROP_GELU) {
-                            const float u = (v + bias) * mult[q];
-                            g.ea.aux_out[off] = u;
-                            v = gelu_f(u);
-                        } else if (EPI == EPI_MASK_POS) {
-                            v = (g.ea.aux_in[off] > 0.f) ? v * g.ea.mscale : 0.f;
-                        } else if (EPI == EPI_GELU_BWD_DROP) {
-                            v = v * mult[q] * gelu_grad_f(g.ea.aux_in[off]);
-                        } else if (EPI == EPI_GELU_BWD) {
-                            v = v * gelu_grad_f(g.ea.aux_in[off]);
-                        }
+                        if (EPI == EPI_DROP_GELU) g.ea.aux_out[off] = u;
                         g.C[(size_t)bz * g.slab_stride + off] = v;
                     }
                 }
