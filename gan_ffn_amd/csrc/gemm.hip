@@ -41,6 +41,13 @@ struct GemmArgs {
     EpiArgs ea;
 };
 
+// Operand tile loaders.  Every global load is UNCONDITIONAL and comes from a clamped (always valid) address:
+//  * rows / columns beyond the matrix edge are clamped onto the last valid one — they only ever feed output rows /
+//    columns that are never stored, so their values do not matter;
+//  * k beyond kend must contribute zero: the loaded vector is multiplied by a 0/1 factor.  (A select would do, but
+//    hipcc turns "select(ok, load, 0)" back into a load under an exec-mask branch, and a load under a branch splits
+//    the K loop into small basic blocks with a wait at each one.)  The clamped address reads finite data of the same
+//    operand row, so 0 * x = 0 unless the operand itself holds Inf/NaN, in which case the product does anyway.
 template <int ROWS, int BK, int NTH>  // K-contiguous operand tile: ROWS x BK floats -> regs (ROWS*BK/4/NTH float4 per thread)
 struct KcTile {
     static constexpr int KV = BK / 4;
@@ -48,17 +55,15 @@ struct KcTile {
     static constexpr int TOTALV = ROWS * KV;
     static constexpr int NV = (TOTALV + NTH - 1) / NTH;
     float4 v[NV];
-    // Loads are UNCONDITIONAL (indices clamped into range, out-of-range lanes zeroed by a select afterwards): a load
-    // under a branch makes hipcc wait vmcnt(0) at the next use, which serialises the whole prefetch queue.
+    float f[NV];   // 0/1 factor, applied when the tile is written to LDS (the load must not be waited for here)
     __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int kend, int tid) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i = min(tid + j * NTH, TOTALV - 1);
             const int row = i / KV, kc = (i % KV) << 2;
-            const int gr = row0 + row, gk = k0 + kc;
-            const bool ok = (tid + j * NTH < TOTALV) && gr < nrows && gk < kend;
-            const float4 q = *reinterpret_cast<const float4*>(P + (size_t)min(gr, nrows - 1) * ld + max(min(gk, kend - 4), 0));
-            v[j] = ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int gk = k0 + kc;                       // K % 4 == 0: a float4 never straddles kend
+            f[j] = gk < kend ? 1.f : 0.f;
+            v[j] = *reinterpret_cast<const float4*>(P + (size_t)min(row0 + row, nrows - 1) * ld + max(min(gk, kend - 4), 0));
         }
     }
     __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
@@ -66,7 +71,8 @@ struct KcTile {
         for (int j = 0; j < NV; ++j) {
             const int i = tid + j * NTH;
             const int row = i / KV, kc = (i % KV) << 2;
-            if (i < TOTALV) *reinterpret_cast<float4*>(S + row * LDK + kc) = v[j];
+            if (TOTALV % NTH == 0 || i < TOTALV)
+                *reinterpret_cast<float4*>(S + row * LDK + kc) = make_float4(v[j].x * f[j], v[j].y * f[j], v[j].z * f[j], v[j].w * f[j]);
         }
     }
 };
@@ -77,15 +83,15 @@ struct KmTile {
     static constexpr int NV = (TOTALV + NTH - 1) / NTH;
     static constexpr int LD = COLS + 4;
     float4 v[NV];
+    float f[NV];
     __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int col0, int ncols, int k0, int kend, int tid) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i = min(tid + j * NTH, TOTALV - 1);
             const int kr = i / (COLS / 4), c4 = (i % (COLS / 4)) << 2;
-            const int gk = k0 + kr, gc = col0 + c4;
-            const bool ok = (tid + j * NTH < TOTALV) && gk < kend && gc < ncols;
-            const float4 q = *reinterpret_cast<const float4*>(P + (size_t)max(min(gk, kend - 1), 0) * ld + max(min(gc, ncols - 4), 0));
-            v[j] = ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int gk = k0 + kr;
+            f[j] = gk < kend ? 1.f : 0.f;
+            v[j] = *reinterpret_cast<const float4*>(P + (size_t)max(min(gk, kend - 1), 0) * ld + max(min(col0 + c4, ncols - 4), 0));
         }
     }
     __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
@@ -93,7 +99,8 @@ struct KmTile {
         for (int j = 0; j < NV; ++j) {
             const int i = tid + j * NTH;
             const int kr = i / (COLS / 4), c4 = (i % (COLS / 4)) << 2;
-            if (i < TOTALV) *reinterpret_cast<float4*>(S + kr * LD + c4) = v[j];
+            if (TOTALV % NTH == 0 || i < TOTALV)
+                *reinterpret_cast<float4*>(S + kr * LD + c4) = make_float4(v[j].x * f[j], v[j].y * f[j], v[j].z * f[j], v[j].w * f[j]);
         }
     }
 };
@@ -244,41 +251,35 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 
     float colsum_acc = 0.f;  // TN: thread tid < BM sums column (m0+tid) of At over k
 
-    auto compute = [&](int buf, int t) {
+    // One K tile: ALL operand fragments of the tile are read from LDS first (BK/8 groups x (TM + TN) reads), then the
+    // BK/2 x TM x TN MFMAs run back to back.  No run-time condition in here: a K tail is zero-filled by the loaders.
+    auto compute = [&](int buf) {
         const float* sa = smem + buf * SM::STAGE;
         const float* sb = sa + SM::A_FLOATS;
-        const int kvalid = min(BK, kend - (kbeg + t * BK));
+        constexpr int NG = BK / 8;
+        float af[NG][TM][4], bf[NG][TN][4];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 8) {
-            if (kk < kvalid) {
-                float af[TM][4], bf[TN][4];
+        for (int gk = 0; gk < NG; ++gk) {
+            const int kk = 8 * gk;
 #pragma unroll
-                for (int a = 0; a < TM; ++a) {
-                    if (MODE == MODE_TN) {
+            for (int a = 0; a < TM; ++a) {
+                if (MODE == MODE_TN) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) af[a][j] = sa[(kk + 4 * h + j) * (BM + 4) + wm * WM + a * 32 + r];
-                    } else {
-                        const float4 q = *reinterpret_cast<const float4*>(sa + (wm * WM + a * 32 + r) * LDK + kk + 4 * h);
-                        af[a][0] = q.x; af[a][1] = q.y; af[a][2] = q.z; af[a][3] = q.w;
-                    }
+                    for (int j = 0; j < 4; ++j) af[gk][a][j] = sa[(kk + 4 * h + j) * (BM + 4) + wm * WM + a * 32 + r];
+                } else {
+                    const float4 q = *reinterpret_cast<const float4*>(sa + (wm * WM + a * 32 + r) * LDK + kk + 4 * h);
+                    af[gk][a][0] = q.x; af[gk][a][1] = q.y; af[gk][a][2] = q.z; af[gk][a][3] = q.w;
                 }
+            }
 #pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    if (MODE == MODE_NT) {
-                        const float4 q = *reinterpret_cast<const float4*>(sb + (wn * WN + b * 32 + r) * LDK + kk + 4 * h);
-                        bf[b][0] = q.x; bf[b][1] = q.y; bf[b][2] = q.z; bf[b][3] = q.w;
-                    } else {
+            for (int b = 0; b < TN; ++b) {
+                if (MODE == MODE_NT) {
+                    const float4 q = *reinterpret_cast<const float4*>(sb + (wn * WN + b * 32 + r) * LDK + kk + 4 * h);
+                    bf[gk][b][0] = q.x; bf[gk][b][1] = q.y; bf[gk][b][2] = q.z; bf[gk][b][3] = q.w;
+                } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) bf[b][j] = sb[(kk + 4 * h + j) * (BN + 4) + wn * WN + b * 32 + r];
-                    }
+                    for (int j = 0; j < 4; ++j) bf[gk][b][j] = sb[(kk + 4 * h + j) * (BN + 4) + wn * WN + b * 32 + r];
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int a = 0; a < TM; ++a)
-#pragma unroll
-                        for (int b = 0; b < TN; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
             }
         }
         if (MODE == MODE_TN) {
@@ -287,6 +288,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
                 for (int k = 0; k < BK; ++k) colsum_acc += sa[k * (BM + 4) + tid];  // zero-filled beyond kend
             }
         }
+        // MFMA order: consecutive instructions share one operand register wherever the wave tile allows it (a
+        // boustrophedon walk over the TM x TN accumulators) — measured on MFMA-only loops (tools/lab/mfma_peak.hip):
+        // an fp32 32x32x2 MFMA whose A AND B both differ from its predecessor's issues ~20 % slower.
+#pragma unroll
+        for (int gk = 0; gk < NG; ++gk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < TN; ++bb) {
+                        const int b = (a & 1) ? TN - 1 - bb : bb;
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gk][a][j], bf[gk][b][j], acc[a][b], 0, 0, 0);
+                    }
     };
 
     // prologue: PD tiles in flight, tile 0 to LDS
@@ -297,12 +312,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     sstore(std::integral_constant<int, 0>{}, 0);
     __syncthreads();
 
+    // Steady state, iteration t: issue the global loads of tile t+PD, run tile t from LDS stage t&1, write tile t+1
+    // (loaded PD-1 iterations ago) to the other stage, barrier.  The step body is straight-line code; the only branch
+    // is the wave-uniform "is there a tile t" around a whole step.  Tiles at or beyond nt load as zeros.
 #define GF_STEP(U)                                                                      \
     if (t0 + U < nt) {                                                                  \
-        const int t = t0 + U;                                                           \
-        gload(std::integral_constant<int, U>{}, t + PD);        /* slot U is free */    \
-        compute(U & 1, t);                                                              \
-        if (t + 1 < nt) sstore(std::integral_constant<int, (U + 1) % PD>{}, (U + 1) & 1); \
+        gload(std::integral_constant<int, U>{}, t0 + U + PD);   /* slot U is free */    \
+        compute(U & 1);                                                                 \
+        sstore(std::integral_constant<int, (U + 1) % PD>{}, (U + 1) & 1);               \
         __syncthreads();                                                                \
     }
     for (int t0 = 0; t0 < nt; t0 += PD) {
@@ -391,22 +408,12 @@ static int launch_pick(const GemmArgs& g, int splits, hipStream_t st) {
     switch (g_gemm_cfg) {
         case 1: return launch_cfg<MODE, 64, 64, 16, EPI>(g, splits, st);
         case 2: return launch_cfg<MODE, 64, 64, 32, EPI>(g, splits, st);
-        case 4: return launch_cfg<MODE, 128, 128, 16, EPI>(g, splits, st);
-        case 5: return launch_cfg<MODE, 128, 128, 16, EPI, 4, 2>(g, splits, st);   // 8 waves, wave tile 32 x 64
-        case 6: return launch_cfg<MODE, 128, 128, 32, EPI, 4, 2>(g, splits, st);
         case 7: return launch_cfg<MODE, 128, 64, 16, EPI, 4, 1>(g, splits, st);    // 4 waves, wave tile 32 x 64
-        case 8: return launch_cfg<MODE, 128, 64, 32, EPI, 4, 1>(g, splits, st);
-        case 9: return launch_cfg<MODE, 128, 128, 16, EPI, 4, 4>(g, splits, st);   // 16 waves, wave tile 32 x 32
         default: break;
     }
-    // measured on MI355X (tools/gemm_bench.py): 64x64 tiles win at every shape of this workload except the
-    // largest M*N (>= 512 tiles of 128x128); BK = 32 wins for long K with few output tiles.
-    // (tools/gemm_bench.py, MI355X) at this workload's sizes (M = 3008/6016) the 4-wave 64x64 block is never beaten
-    // by more than ~5 % by 128x64 / 128x128 blocks with 4, 8 or 16 waves and wins clearly whenever N <= 512;
-    // the one exception kept is the 128x64 block for wide outputs with long K.
-    const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    if (tiles128 * splits >= 350 && g.kchunk >= 512) return launch_cfg<MODE, 128, 64, 16, EPI, 4, 1>(g, splits, st);
-    if (g.kchunk >= 512) return launch_cfg<MODE, 64, 64, 32, EPI>(g, splits, st);
+    // measured on MI355X (tools/gemm_bench.py, M = 3008 / 6016, N = 100 .. 2048, K = 100 .. 2048): with the
+    // straight-line K loop the 4-wave 64x64x16 block is the fastest or within 2 % of the fastest of every block /
+    // wave-tile shape tried (64x64x32, 128x64, 64x128, 128x128 with 2, 4, 8 or 16 waves), so it is the only one used.
     return launch_cfg<MODE, 64, 64, 16, EPI>(g, splits, st);
 }
 

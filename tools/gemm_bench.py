@@ -65,8 +65,15 @@ def bench_torch(M, N, K, iters=50):
 
 
 if __name__ == "__main__":
-    cfgs = [1, 2, 7]
+    cfgs = [int(c) for c in os.environ.get('CFGS', '1,2,7').split(',')]
     torch.backends.cuda.matmul.allow_tf32 = False
+    if len(sys.argv) > 1 and sys.argv[1] == "small":
+        for M in (3008, 6016):
+            for (N, K) in ((100, 100), (300, 100)):
+                bench("nt", M, N, K, cfgs)
+            for (N, K) in ((100, 100), (100, 300)):
+                bench("nn", M, N, K, cfgs)
+        sys.exit(0)
     for (N, K) in ((2048, 512), (1536, 512), (512, 512), (512, 2048), (2048, 100)):
         bench("nt", 3008, N, K, cfgs)
         bench_torch(3008, N, K)
