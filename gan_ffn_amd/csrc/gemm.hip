@@ -94,6 +94,16 @@ struct KmTile {
             v[j] = *reinterpret_cast<const float4*>(P + (size_t)max(min(gk, kend - 1), 0) * ld + max(min(col0 + c4, ncols - 4), 0));
         }
     }
+    // column sums of the tile, per thread: thread tid's vectors all cover columns 4 * (tid % (COLS/4)) .. +3
+    // when NTH % (COLS/4) == 0 (true for every instantiation: 256 % 16)
+    __device__ __forceinline__ void add_to(float4& s4, int tid) const {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (TOTALV % NTH == 0 || tid + j * NTH < TOTALV) {
+                s4.x += v[j].x * f[j]; s4.y += v[j].y * f[j]; s4.z += v[j].z * f[j]; s4.w += v[j].w * f[j];
+            }
+        }
+    }
     __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -233,6 +243,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     KcTile<BN, BK, NTH> tb_kc[PD];
     KmTile<BN, BK, NTH> tb_km[PD];
 
+    // TN bias gradient: column sums of At over k, taken from the registers on their way to LDS (workgroups bx == 0)
+    const bool want_colsum = MODE == MODE_TN && g.colsum != nullptr && bx == 0;
+    float4 colsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    static_assert(MODE != MODE_TN || (NTH % (BM / 4) == 0), "colsum: a thread's vectors must share their columns");
+
     auto gload = [&](auto slot, int t) {
         constexpr int u = decltype(slot)::value;
         const int k0 = kbeg + t * BK;     // beyond kend -> the tile loads zeros (no memory access)
@@ -245,11 +260,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
         constexpr int u = decltype(slot)::value;
         float* sa = smem + buf * SM::STAGE;
         float* sb = sa + SM::A_FLOATS;
-        if (MODE == MODE_TN) ta_km[u].store(sa, tid); else ta_kc[u].store(sa, tid);
+        if (MODE == MODE_TN) {
+            ta_km[u].store(sa, tid);
+            if (want_colsum) ta_km[u].add_to(colsum4, tid);   // every tile passes here exactly once
+        } else {
+            ta_kc[u].store(sa, tid);
+        }
         if (MODE == MODE_NT) tb_kc[u].store(sb, tid); else tb_km[u].store(sb, tid);
     };
 
-    float colsum_acc = 0.f;  // TN: thread tid < BM sums column (m0+tid) of At over k
 
     // One K tile: ALL operand fragments of the tile are read from LDS first (BK/8 groups x (TM + TN) reads), then the
     // BK/2 x TM x TN MFMAs run back to back.  No run-time condition in here: a K tail is zero-filled by the loaders.
@@ -280,12 +299,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 #pragma unroll
                     for (int j = 0; j < 4; ++j) bf[gk][b][j] = sb[(kk + 4 * h + j) * (BN + 4) + wn * WN + b * 32 + r];
                 }
-            }
-        }
-        if (MODE == MODE_TN) {
-            if (g.colsum != nullptr && bx == 0 && tid < BM) {
-#pragma unroll
-                for (int k = 0; k < BK; ++k) colsum_acc += sa[k * (BM + 4) + tid];  // zero-filled beyond kend
             }
         }
         // MFMA order: consecutive instructions share one operand register wherever the wave tile allows it (a
@@ -343,8 +356,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
                     if (row < g.M && col < g.N) atomicAdd(g.C + (size_t)row * g.ldc + col, acc[a][b][i]);
                 }
             }
-        if (g.colsum != nullptr && bx == 0 && tid < BM && (m0 + tid) < g.M)
-            atomicAdd(g.colsum + m0 + tid, colsum_acc);
+        if (want_colsum) {   // wave-uniform; smem is free: the K loop ended with a barrier
+            constexpr int NR = NTH / (BM / 4);              // threads per column group (fixed summation order)
+            static_assert(NR * BM <= SM::TOTAL, "colsum scratch must fit the tile buffers");
+            *reinterpret_cast<float4*>(smem + (tid / (BM / 4)) * BM + ((tid % (BM / 4)) << 2)) = colsum4;
+            __syncthreads();
+            if (tid < BM) {
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < NR; ++i) sum += smem[i * BM + tid];
+                if (m0 + tid < g.M) atomicAdd(g.colsum + m0 + tid, sum);
+            }
+        }
         return;
     }
 

