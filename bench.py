@@ -58,6 +58,32 @@ def wgrad_groups(S, B):
             (2, [(m, n, T1) for _ in range(8) for (m, n) in e512])]
 
 
+TRAFFIC_FILE = "profiles/r01_wgrad_traffic.json"
+
+
+def wgrad_algorithmic_bytes(S, B):
+    """average compulsory bytes of one launch: every dY and X operand read once, every dW (and db) written once"""
+    tot, n = 0.0, 0
+    for cnt, probs in wgrad_groups(S, B):
+        b = sum(4.0 * (k * m + k * n_ + m * n_ + m) for (m, n_, k) in probs)
+        tot += cnt * b
+        n += cnt
+    return tot / n
+
+
+def committed_traffic(S, B):
+    """HBM-side bytes per launch of the roofline kernel from the committed PMC passes (tools/traffic_pmc.sh), or None
+    when the file is absent or was taken at another problem size"""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), TRAFFIC_FILE)
+    try:
+        d = json.load(open(path))
+        if d.get("seq_len") == S and d.get("dialogues_per_gpu") == B:
+            return d["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def time_dominant_kernel(S, B, reps=3):
     """Live HIP-event timing, on the stream the kernel is launched on (torch's current stream), of one iteration's
     launches of the dominant kernel (see wgrad_groups), replayed back to back in isolation.
@@ -153,6 +179,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams running independent sub-steps concurrently")
     ap.add_argument("--cpu-sample-batch", type=int, default=16)
+    ap.add_argument("--replay-dominant-only", action="store_true",
+                    help="only replay the roofline kernel's launch mix once (the command tools/traffic_pmc.sh profiles "
+                         "with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,6 +202,10 @@ def main():
         pg = dist.group.WORLD
 
     from gan_ffn_amd import _lib, engine, ops
+    if args.replay_dominant_only:
+        kt, kflop, klaunch = time_dominant_kernel(args.seq, args.batch, reps=1)
+        print(json.dumps({"avg_kernel_us": kt * 1e6, "launches": klaunch}), flush=True)
+        return
     from gan_ffn_amd import data as D
     _lib.load()
     if os.environ.get("GANFFN_TN_TARGET"):
@@ -228,6 +261,7 @@ def main():
 
     if rank == 0:
         kt, kflop, klaunch = time_dominant_kernel(S, B)
+        traffic = committed_traffic(S, B)
         fpt = flops_per_token(S)
         step_tflops = fpt * S * B * world * args.steps / dt / 1e12
         out = {
@@ -246,7 +280,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_tn_grouped_kernel (all 32 weight-gradient GEMMs of one encoder backward pass in one "
                                                      "launch, split-K + fp32 atomics); %d launches per iteration, largest share of GPU time" % klaunch,
                          "achieved": round(kflop / kt / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": round(kflop / kt / FP32_MFMA_PEAK, 4), "traffic": None,
+                         "frac": round(kflop / kt / FP32_MFMA_PEAK, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per launch (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE, separate "
+                                         "rocprofv3 --pmc passes: " + TRAFFIC_FILE + ")" if traffic is not None else None,
+                         "algorithmic_bytes_per_launch": round(wgrad_algorithmic_bytes(S, B)),
                          "avg_kernel_us": round(kt * 1e6, 2), "avg_gflop_per_launch": round(kflop / 1e9, 4),
                          "how": "HIP events around one iteration's launch mix of this kernel replayed in isolation on the launch stream"},
         }

@@ -395,8 +395,13 @@ struct TnGroup {
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
+    // XCD-aware workgroup order: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (private
+    // 4 MiB L2 each), so tiles that share an operand panel would all miss in different L2s (measured, rocprofv3
+    // FETCH_SIZE: 3x the compulsory bytes on the d=512 launches).  Bijective remap (also when gridDim % 8 != 0): the
+    // workgroups that share an XCD get one contiguous range of the logical (problem, k-split, tile) list.
     int pi = 0;
-    const int b = blockIdx.x;
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xl = blockIdx.x & 7;
+    const int b = (xl < r8 ? xl * (q8 + 1) : r8 * (q8 + 1) + (xl - r8) * q8) + (blockIdx.x >> 3);
 #pragma unroll 1
     for (int i = 1; i < grp.n; ++i)
         if (b >= grp.p[i].block0) pi = i;
@@ -406,7 +411,14 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
     GemmArgs g;
     g.A = q.A; g.lda = q.lda; g.B = q.B; g.ldb = q.ldb; g.C = q.C; g.ldc = q.ldc; g.colsum = q.colsum;
     g.M = q.M; g.N = q.N; g.K = q.K; g.kchunk = q.kchunk; g.slab_stride = 0;
-    gemm_body<MODE_TN, 64, 64, 16, EPI_NONE, 2, 2>(g, t2 % q.tiles_n, t2 / q.tiles_n, bz);
+    // tiles in panels of 8 along N (n fastest inside a panel, then m, then the next panel): an XCD's contiguous
+    // range of ~32 tiles is then a 4 x 8 patch — 12 operand panels instead of the 33 of a 1 x 32 strip
+    constexpr int PW = 8;
+    const int tiles_m = q.tiles_mn / q.tiles_n;
+    const int panel = t2 / (PW * tiles_m), rem = t2 - panel * PW * tiles_m;
+    const int pw = min(PW, q.tiles_n - panel * PW);
+    const int mt = rem / pw, nt = panel * PW + rem - mt * pw;
+    gemm_body<MODE_TN, 64, 64, 16, EPI_NONE, 2, 2>(g, nt, mt, bz);
 }
 
 int g_gemm_tn_target = 0;
