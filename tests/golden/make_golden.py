@@ -195,9 +195,71 @@ def misc():
     return out
 
 
+def artifacts():
+    """N3 fixtures: the reference's dataset / collate on a seeded synthetic pickle, its GAN_loss.csv writer, and the
+    report text its __main__ assembles (train_IEMOCAP.py:733-752, restated here with the same sklearn calls)."""
+    import tempfile
+    import pandas as pd
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from gan_ffn_amd.data import write_synthetic_iemocap_pickle     # writes the INPUT pickle only
+    import dataloader as ref_dl                                     # the reference
+    import train_IEMOCAP as ref_tr
+    out = {}
+    tmp = tempfile.mkdtemp()
+    for tag, dt in (("f64", np.float64), ("f32", np.float32)):
+        pk = os.path.join(tmp, "syn_%s.pkl" % tag)
+        write_synthetic_iemocap_pickle(pk, n_train=12, n_test=5, seed=3407, dtype=dt)
+        for split, train in (("train", True), ("test", False)):
+            ds = ref_dl.IEMOCAPDataset(pk, train=train)
+            out["ds/%s/%s/len" % (tag, split)] = np.array(len(ds))
+            batch = ds.collate_fn([ds[i] for i in range(3)])
+            for name, t in zip(("text", "visual", "audio", "qmask", "umask", "label"), batch[:6]):
+                out["ds/%s/%s/%s" % (tag, split, name)] = t.numpy()
+            out["ds/%s/%s/vids" % (tag, split)] = np.array(batch[6])
+    # sampler split (indices only; the order inside is random by design)
+    ds = ref_dl.IEMOCAPDataset(os.path.join(tmp, "syn_f64.pkl"), train=True)
+    tr, va = ref_tr.get_train_valid_sampler(ds, 0.2)
+    out["sampler/train"], out["sampler/valid"] = np.array(sorted(tr.indices)), np.array(sorted(va.indices))
+    # GAN_loss.csv: the frame built the way train_GAN builds it, written by the reference's save_GAN_loss
+    cols = ["epoch", "acoustic_G_loss", "visual_G_loss", "text_G_loss", "visual_D_loss", "text_D_loss", "acoustic_D_loss"]
+    df = pd.DataFrame(columns=cols)
+    vals = np.array(F_.formula_tensor("artifacts.losses", (3, 6)), dtype=np.float32) + 0.7
+    for e in range(3):
+        loss = {"epoch": e}
+        for j, c in enumerate(cols[1:]):
+            loss[c] = np.asarray(vals[e, j])          # train_disc returns a 0-d float32 ndarray
+        df = pd.concat([df, pd.DataFrame(loss, index=[0])], axis=0, ignore_index=True)
+    path = os.path.join(tmp, "out", "GAN_loss.csv")
+    ref_tr.save_GAN_loss(df, path)
+    out["csv/values"] = vals
+    out["csv/text"] = np.array(open(path).read())
+    more = pd.concat([pd.DataFrame(pd.read_csv(path)), df.iloc[:1]], axis=0)      # continue-training concat, :558
+    ref_tr.save_GAN_loss(more, path)
+    out["csv/text_continued"] = np.array(open(path).read())
+    # report text
+    from sklearn.metrics import f1_score, classification_report, confusion_matrix, accuracy_score
+    rng = np.random.default_rng(11)
+    labels = rng.integers(0, 6, 200)
+    preds = np.where(rng.random(200) < 0.6, labels, rng.integers(0, 6, 200))
+    masks = (rng.random(200) < 0.85).astype(np.float32)
+    best_loss = 1.2345
+    f1 = round(f1_score(labels, preds, sample_weight=masks, average="weighted") * 100, 2)
+    text = "Loss {} F1-score {}".format(best_loss, f1)
+    text += str(classification_report(labels, preds, sample_weight=masks, digits=4))
+    text += str(confusion_matrix(labels, preds, sample_weight=masks))
+    out["report/labels"], out["report/preds"], out["report/masks"] = labels, preds, masks
+    out["report/best_loss"], out["report/f1"], out["report/text"] = np.array(best_loss), np.array(f1), np.array(text)
+    out["report/acc"] = np.array(round(accuracy_score(labels, preds, sample_weight=masks) * 100, 2))
+    return out
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "artifacts":
+        np.savez_compressed(os.path.join(HERE, "artifacts.npz"), **artifacts())
+        sys.exit(0)
     torch.manual_seed(0)
     np.savez_compressed(os.path.join(HERE, "misc.npz"), **misc())
     np.savez_compressed(os.path.join(HERE, "modules.npz"), **module_cases())
     np.savez_compressed(os.path.join(HERE, "gan_steps.npz"), **gan_steps())
+    np.savez_compressed(os.path.join(HERE, "artifacts.npz"), **artifacts())
     print("golden fixtures written to", HERE)
