@@ -1,0 +1,227 @@
+"""DialogueRNN head for configuration 5: `GAN_FFN_DialogueRNN` = the three HIP generators feeding a
+bidirectional DialogueRNN classifier.
+
+Mirrors the module interface of /root/reference/model.py:134-194 (MatchingAttention, SimpleAttention), :828-1062
+(DialogueRNNCell, DialogueRNN, BiModel) and :1465-1528 (GAN_FFN_DialogueRNN): same constructor arguments, same
+parameter names and shapes (reference state_dicts load), same forward signatures and return tuples.
+
+Round-1 form: the recurrence runs on PyTorch-ROCm device ops (GRU cells are rocBLAS GEMMs + pointwise kernels, S
+sequential steps per direction); the pieces with no sequential dependence are batched instead of looped:
+  * party selection is a gather, sequence reversal one index gather per tensor (the reference loops over dialogues),
+  * BiModel's second attention — one masked `general2` MatchingAttention query per time step in the reference — is ONE
+    batched masked attention over all (dialogue, query step) pairs (`general2_all_queries`).
+The generators underneath are the HIP path; there is no CPU route through them.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class SimpleAttention(nn.Module):
+    """softmax over time of a learned scalar score; pooled memory (model.py:117-131)"""
+
+    def __init__(self, input_dim):
+        super().__init__()
+        self.input_dim = input_dim
+        self.scalar = nn.Linear(input_dim, 1, bias=False)
+
+    def forward(self, M, x=None):
+        alpha = F.softmax(self.scalar(M), dim=0).permute(1, 2, 0)            # (B, 1, S)
+        return torch.bmm(alpha, M.transpose(0, 1))[:, 0, :], alpha
+
+
+def general2_scores(xt, M, mask):
+    """masked `general2` attention weights for queries xt (B, Q, D) over memory M (S, B, D), mask (B, S):
+    softmax_j tanh(m_j * <x, m_j * M_j>), zeroed at masked positions and re-normalised (model.py:169-182)."""
+    Mb = M.transpose(0, 1) * mask.unsqueeze(2)                               # (B, S, D), masked memory
+    a = torch.tanh(torch.bmm(xt, Mb.transpose(1, 2)) * mask.unsqueeze(1))    # (B, Q, S)
+    a = F.softmax(a, dim=2) * mask.unsqueeze(1)
+    return a / a.sum(dim=2, keepdim=True)
+
+
+class MatchingAttention(nn.Module):
+    """attention of one candidate vector over a memory sequence; att_type in dot / general / general2 / concat
+    (model.py:134-194)"""
+
+    def __init__(self, mem_dim, cand_dim, alpha_dim=None, att_type="general2"):
+        super().__init__()
+        assert att_type != "concat" or alpha_dim is not None
+        assert att_type != "dot" or mem_dim == cand_dim
+        self.mem_dim, self.cand_dim, self.att_type = mem_dim, cand_dim, att_type
+        if att_type == "general":
+            self.transform = nn.Linear(cand_dim, mem_dim, bias=False)
+        if att_type == "general2":
+            self.transform = nn.Linear(cand_dim, mem_dim, bias=True)
+            nn.init.normal_(self.transform.weight, std=0.01)
+        elif att_type == "concat":
+            self.transform = nn.Linear(cand_dim + mem_dim, alpha_dim, bias=False)
+            self.vector_prod = nn.Linear(alpha_dim, 1, bias=False)
+
+    def forward(self, M, x, mask=None):
+        """M (S, B, mem_dim), x (B, cand_dim), mask (B, S) -> pooled (B, mem_dim), alpha (B, 1, S)"""
+        if mask is None:
+            mask = torch.ones(M.size(1), M.size(0), dtype=M.dtype, device=M.device)
+        if self.att_type == "dot":
+            alpha = F.softmax(torch.bmm(x.unsqueeze(1), M.permute(1, 2, 0)), dim=2)
+        elif self.att_type == "general":
+            alpha = F.softmax(torch.bmm(self.transform(x).unsqueeze(1), M.permute(1, 2, 0)), dim=2)
+        elif self.att_type == "general2":
+            alpha = general2_scores(self.transform(x).unsqueeze(1), M, mask)
+        else:
+            Mb = M.transpose(0, 1)
+            cat = torch.cat([Mb, x.unsqueeze(1).expand(-1, M.size(0), -1)], 2)
+            alpha = F.softmax(self.vector_prod(torch.tanh(self.transform(cat))), 1).transpose(1, 2)
+        return torch.bmm(alpha, M.transpose(0, 1))[:, 0, :], alpha
+
+    def general2_all_queries(self, M, mask):
+        """every time step of M as the candidate, at once: -> pooled (S, B, D), alpha (B, S_query, S_memory).
+        Equals [self(M, M[t], mask) for t in range(S)] (what BiModel.forward loops over, model.py:1043-1049)."""
+        assert self.att_type == "general2"
+        alpha = general2_scores(self.transform(M).transpose(0, 1), M, mask)          # (B, S, S)
+        return torch.bmm(alpha, M.transpose(0, 1)).transpose(0, 1), alpha
+
+
+def _select_party(X, idx):
+    """X (B, P, D), idx (B) -> X[b, idx[b]] (B, D)"""
+    return X.gather(1, idx.view(-1, 1, 1).expand(-1, 1, X.size(2)))[:, 0, :]
+
+
+class DialogueRNNCell(nn.Module):
+    """one utterance step: global GRU, context attention over the global history, party GRU (speaker update, optional
+    listener update), emotion GRU (model.py:828-926)"""
+
+    def __init__(self, D_m, D_g, D_p, D_e, listener_state=False, context_attention="simple", D_a=100, dropout=0.5):
+        super().__init__()
+        self.D_m, self.D_g, self.D_p, self.D_e = D_m, D_g, D_p, D_e
+        self.listener_state = listener_state
+        self.g_cell = nn.GRUCell(D_m + D_p, D_g)
+        self.p_cell = nn.GRUCell(D_m + D_g, D_p)
+        self.e_cell = nn.GRUCell(D_p, D_e)
+        if listener_state:
+            self.l_cell = nn.GRUCell(D_m + D_p, D_p)
+        self.dropout = nn.Dropout(dropout)
+        if context_attention == "simple":
+            self.attention = SimpleAttention(D_g)
+        else:
+            self.attention = MatchingAttention(D_g, D_m, D_a, context_attention)
+
+    def forward(self, U, qmask, g_hist, q0, e0):
+        """U (B, D_m), qmask (B, P) one-hot speaker, g_hist (t, B, D_g) or empty, q0 (B, P, D_p), e0 (B, D_e) or empty"""
+        B, P = qmask.shape
+        spk = torch.argmax(qmask, 1)
+        first = g_hist.size(0) == 0
+        g_prev = U.new_zeros(B, self.D_g) if first else g_hist[-1]
+        g_ = self.dropout(self.g_cell(torch.cat([U, _select_party(q0, spk)], dim=1), g_prev))
+        if first:
+            c_, alpha = U.new_zeros(B, self.D_g), None
+        else:
+            c_, alpha = self.attention(g_hist, U)
+        Uc = torch.cat([U, c_], dim=1).unsqueeze(1).expand(-1, P, -1).reshape(B * P, self.D_m + self.D_g)
+        qs_ = self.dropout(self.p_cell(Uc, q0.reshape(B * P, self.D_p)).view(B, P, self.D_p))
+        if self.listener_state:
+            Ue = U.unsqueeze(1).expand(-1, P, -1).reshape(B * P, self.D_m)
+            ss = _select_party(qs_, spk).unsqueeze(1).expand(-1, P, -1).reshape(B * P, self.D_p)
+            ql_ = self.dropout(self.l_cell(torch.cat([Ue, ss], 1), q0.reshape(B * P, self.D_p)).view(B, P, self.D_p))
+        else:
+            ql_ = q0
+        qm = qmask.unsqueeze(2)
+        q_ = ql_ * (1 - qm) + qs_ * qm
+        e_prev = U.new_zeros(B, self.D_e) if e0.size(0) == 0 else e0
+        e_ = self.dropout(self.e_cell(_select_party(q_, spk), e_prev))
+        return g_, q_, e_, alpha
+
+
+class DialogueRNN(nn.Module):
+    """the cell unrolled over a dialogue (model.py:929-972)"""
+
+    def __init__(self, D_m, D_g, D_p, D_e, listener_state=False, context_attention="simple", D_a=100, dropout=0.5):
+        super().__init__()
+        self.D_m, self.D_g, self.D_p, self.D_e = D_m, D_g, D_p, D_e
+        self.dropout = nn.Dropout(dropout)
+        self.dialogue_cell = DialogueRNNCell(D_m, D_g, D_p, D_e, listener_state, context_attention, D_a, dropout)
+
+    def forward(self, U, qmask):
+        """U (S, B, D_m), qmask (S, B, P) -> emotions (S, B, D_e), [alpha_t (B, t)] for t >= 1"""
+        S, B, P = qmask.shape
+        g_steps, e_steps, alpha = [], [], []
+        q_ = U.new_zeros(B, P, self.D_p)
+        e_ = U.new_zeros(0)
+        for t in range(S):
+            g_hist = torch.stack(g_steps, 0) if g_steps else U.new_zeros(0)
+            g_, q_, e_, a_ = self.dialogue_cell(U[t], qmask[t], g_hist, q_, e_)
+            g_steps.append(g_)
+            e_steps.append(e_)
+            if a_ is not None:
+                alpha.append(a_[:, 0, :])
+        return torch.stack(e_steps, 0), alpha
+
+
+def reverse_valid_prefix(X, mask):
+    """X (S, B, D), mask (B, S): reverse each dialogue's first len_b = sum(mask_b) steps, zero the rest; the result is
+    trimmed to max len_b like pad_sequence does (model.py:1008-1021)"""
+    S, B = X.shape[0], X.shape[1]
+    lens = mask.sum(1).to(torch.long)                                    # (B)
+    Smax = int(lens.max())
+    t = torch.arange(Smax, device=X.device).unsqueeze(1)                 # (Smax, 1)
+    src = (lens.unsqueeze(0) - 1 - t).clamp(min=0)                       # (Smax, B)
+    valid = (t < lens.unsqueeze(0)).to(X.dtype).unsqueeze(2)
+    idx = src.unsqueeze(2).expand(-1, -1, X.shape[2])
+    return X.gather(0, idx) * valid
+
+
+class BiModel(nn.Module):
+    """forward and backward DialogueRNN, concatenated, second (masked general2) attention over the emotion sequence,
+    linear + relu + dropout, class log-probabilities (model.py:975-1062)"""
+
+    def __init__(self, D_m, D_g, D_p, D_e, D_h, n_classes=7, listener_state=False, context_attention="simple", D_a=100,
+                 dropout_rec=0.5, dropout=0.5):
+        super().__init__()
+        self.D_m, self.D_g, self.D_p, self.D_e, self.D_h, self.n_classes = D_m, D_g, D_p, D_e, D_h, n_classes
+        self.dropout = nn.Dropout(dropout)
+        self.dropout_rec = nn.Dropout(dropout + 0.15)
+        self.dialog_rnn_f = DialogueRNN(D_m, D_g, D_p, D_e, listener_state, context_attention, D_a, dropout_rec)
+        self.dialog_rnn_r = DialogueRNN(D_m, D_g, D_p, D_e, listener_state, context_attention, D_a, dropout_rec)
+        self.linear = nn.Linear(2 * D_e, 2 * D_h)
+        self.smax_fc = nn.Linear(2 * D_h, n_classes)
+        self.matchatt = MatchingAttention(2 * D_e, 2 * D_e, att_type="general2")
+
+    def _reverse_seq(self, X, mask):
+        return reverse_valid_prefix(X, mask)
+
+    def forward(self, U, qmask, umask, att2=True):
+        emotions_f, alpha_f = self.dialog_rnn_f(U, qmask)
+        emotions_f = self.dropout_rec(emotions_f)
+        emotions_b, alpha_b = self.dialog_rnn_r(self._reverse_seq(U, umask), self._reverse_seq(qmask, umask))
+        emotions_b = self.dropout_rec(self._reverse_seq(emotions_b, umask))
+        emotions = torch.cat([emotions_f, emotions_b], dim=-1)
+        if att2:
+            att, a = self.matchatt.general2_all_queries(emotions, umask)
+            alpha = [a[:, t, :] for t in range(a.size(1))]
+            hidden = F.relu(self.linear(att))
+        else:
+            alpha = []
+            hidden = F.relu(self.linear(emotions))
+        hidden = self.dropout(hidden)
+        return F.log_softmax(self.smax_fc(hidden), 2), alpha, alpha_f, alpha_b
+
+
+class GAN_FFN_DialogueRNN(nn.Module):
+    """fusion = G_a(acoustic) + G_v(visual) + G_t(text) -> BiModel (model.py:1465-1528).  `gelu`, `relu`, `dropout`
+    and `fc1` exist on the reference object without taking part in forward; they are kept so state_dicts match."""
+
+    def __init__(self, acoustic_generator, visual_generator, text_generator, D_m, D_g, D_p, D_e, D_h, D_a, n_classes,
+                 listener_state, context_attention, dropout_rec, dropout):
+        super().__init__()
+        self.n_classes = n_classes
+        self.acoustic_generator = acoustic_generator
+        self.visual_generator = visual_generator
+        self.text_generator = text_generator
+        self.gelu, self.relu, self.dropout = nn.GELU(), nn.ReLU(), nn.Dropout(dropout)
+        self.bi_model = BiModel(D_m=D_m, D_g=D_g, D_p=D_p, D_e=D_e, D_h=D_h, n_classes=n_classes,
+                                listener_state=listener_state, context_attention=context_attention, D_a=D_a,
+                                dropout_rec=dropout_rec, dropout=dropout)
+        self.fc1 = nn.Linear(100, n_classes)
+
+    def forward(self, acoustic, visual, text, qmask, umask):
+        fusion = self.acoustic_generator(acoustic) + self.visual_generator(visual) + self.text_generator(text)
+        return self.bi_model(fusion, qmask, umask)

@@ -253,7 +253,63 @@ def artifacts():
     return out
 
 
+DRNN_CASES = {"general": dict(context_attention="general", listener_state=False),
+              "simple_listener": dict(context_attention="simple", listener_state=True)}
+DRNN_DIMS = dict(D_m=100, D_g=500, D_p=500, D_e=100, D_h=100, n_classes=6, D_a=100, dropout_rec=0.1, dropout=0.6)
+DRNN_LENS = [7, 4, 6]
+
+
+def drnn_inputs():
+    S, B = max(DRNN_LENS), len(DRNN_LENS)
+    U = F_.formula_input("drnn.U", S, B, 100)
+    umask = np.zeros((B, S), np.float32)
+    for b, L in enumerate(DRNN_LENS):
+        umask[b, :L] = 1
+        U[L:, b] = 0
+    spk = (np.arange(S)[:, None] * 3 + np.arange(B)[None, :] * 2 + (np.arange(S)[:, None] // 3)) % 2
+    qmask = np.stack([1 - spk, spk], -1).astype(np.float32) * umask.T[:, :, None]
+    return U, qmask, umask
+
+
+def dialogue_rnn():
+    """N2 fixtures: the reference's BiModel (eval mode: torch's CPU dropout stream is not reproducible), formula
+    weights, ragged dialogues: log-probabilities, the three attention maps, input gradient, parameter gradients."""
+    out = {}
+    U, qmask, umask = drnn_inputs()
+    for tag, kw in DRNN_CASES.items():
+        torch.manual_seed(0)
+        m = ref.BiModel(**DRNN_DIMS, **kw).eval()
+        sd = F_.formula_state_dict({k: v for k, v in m.state_dict().items()})
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        Ut = torch.from_numpy(U).requires_grad_(True)
+        lp, alpha, alpha_f, alpha_b = m(Ut, torch.from_numpy(qmask), torch.from_numpy(umask))
+        gy = torch.from_numpy(F_.formula_input("drnn.grad", lp.shape[0], lp.shape[1], lp.shape[2])) - 0.5
+        (lp * gy).sum().backward()
+        out["%s/log_prob" % tag] = lp.detach().numpy()
+        out["%s/alpha" % tag] = torch.stack(alpha, 0).detach().numpy()                     # (S, B, S)
+        for name, al in (("alpha_f", alpha_f), ("alpha_b", alpha_b)):
+            for t, a in enumerate(al):
+                out["%s/%s/%d" % (tag, name, t)] = a.detach().numpy()
+            out["%s/%s/n" % (tag, name)] = np.array(len(al))
+        out["%s/dU" % tag] = Ut.grad.numpy()
+        for k, p_ in m.named_parameters():
+            if p_.grad is not None:
+                out["%s/grad/%s" % (tag, k)] = p_.grad.numpy() if p_.grad.numel() <= 4096 else \
+                    p_.grad.reshape(-1)[F_.sample_indices(p_.grad.numel())].numpy()
+    # MatchingAttention general2 alone, with a mask (the A12 parity target, model.py:169-182)
+    att = ref.MatchingAttention(200, 200, att_type="general2").eval()
+    sd = F_.formula_state_dict(att.state_dict())
+    att.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    M = torch.from_numpy(F_.formula_input("drnn.M", 7, 3, 200)) - 0.5
+    pool, al = att(M, M[2], mask=torch.from_numpy(umask))
+    out["general2/pool"], out["general2/alpha"] = pool.detach().numpy(), al.detach().numpy()
+    return out
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "dialogue_rnn":
+        np.savez_compressed(os.path.join(HERE, "dialogue_rnn.npz"), **dialogue_rnn())
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "artifacts":
         np.savez_compressed(os.path.join(HERE, "artifacts.npz"), **artifacts())
         sys.exit(0)
@@ -262,4 +318,5 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "modules.npz"), **module_cases())
     np.savez_compressed(os.path.join(HERE, "gan_steps.npz"), **gan_steps())
     np.savez_compressed(os.path.join(HERE, "artifacts.npz"), **artifacts())
+    np.savez_compressed(os.path.join(HERE, "dialogue_rnn.npz"), **dialogue_rnn())
     print("golden fixtures written to", HERE)

@@ -1,0 +1,97 @@
+"""N2: the DialogueRNN head against fixtures produced by the reference's own BiModel /
+MatchingAttention (tests/golden/make_golden.py dialogue_rnn).  The head is device-agnostic torch code (the HIP
+generators are not involved here), so this parity check runs on the CPU."""
+import numpy as np
+import pytest
+import torch
+
+import formula as F_
+from util import golden
+
+DIMS = dict(D_m=100, D_g=500, D_p=500, D_e=100, D_h=100, n_classes=6, D_a=100, dropout_rec=0.1, dropout=0.6)
+CASES = {"general": dict(context_attention="general", listener_state=False),
+         "simple_listener": dict(context_attention="simple", listener_state=True)}
+LENS = [7, 4, 6]
+
+
+def inputs():
+    S, B = max(LENS), len(LENS)
+    U = F_.formula_input("drnn.U", S, B, 100)
+    umask = np.zeros((B, S), np.float32)
+    for b, L in enumerate(LENS):
+        umask[b, :L] = 1
+        U[L:, b] = 0
+    spk = (np.arange(S)[:, None] * 3 + np.arange(B)[None, :] * 2 + (np.arange(S)[:, None] // 3)) % 2
+    qmask = np.stack([1 - spk, spk], -1).astype(np.float32) * umask.T[:, :, None]
+    return U, qmask, umask
+
+
+def close(a, ref, rtol, what):
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    scale = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(a - ref).max()
+    assert a.shape == ref.shape and err <= rtol * scale, "%s: max err %.3e vs scale %.3e" % (what, err, scale)
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_bimodel_matches_reference_fixture(tag):
+    from gan_ffn_amd import dialogue_rnn as DR
+    g = golden("dialogue_rnn")
+    torch.manual_seed(1)
+    m = DR.BiModel(**DIMS, **CASES[tag]).eval()
+    sd = F_.formula_state_dict(m.state_dict())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})          # same keys and shapes as the reference
+    U, qmask, umask = inputs()
+    Ut = torch.from_numpy(U).requires_grad_(True)
+    lp, alpha, alpha_f, alpha_b = m(Ut, torch.from_numpy(qmask), torch.from_numpy(umask))
+    close(lp.detach().numpy(), g["%s/log_prob" % tag], 2e-5, "log_prob")
+    close(torch.stack(alpha, 0).detach().numpy(), g["%s/alpha" % tag], 2e-5, "alpha")
+    for name, al in (("alpha_f", alpha_f), ("alpha_b", alpha_b)):
+        assert len(al) == int(g["%s/%s/n" % (tag, name)])
+        for t, a in enumerate(al):
+            close(a.detach().numpy(), g["%s/%s/%d" % (tag, name, t)], 2e-5, "%s[%d]" % (name, t))
+    gy = torch.from_numpy(F_.formula_input("drnn.grad", lp.shape[0], lp.shape[1], lp.shape[2])) - 0.5
+    (lp * gy).sum().backward()
+    close(Ut.grad.numpy(), g["%s/dU" % tag], 1e-4, "dU")
+    n = 0
+    for k, p in m.named_parameters():
+        key = "%s/grad/%s" % (tag, k)
+        if p.grad is None:
+            assert key not in g.files, k
+            continue
+        got = p.grad.numpy() if p.grad.numel() <= 4096 else p.grad.reshape(-1)[F_.sample_indices(p.grad.numel())].numpy()
+        close(got, g[key], 2e-4, "grad " + k)
+        n += 1
+    assert n >= 20
+
+
+def test_general2_attention_single_query_and_batched_agree_with_reference():
+    from gan_ffn_amd import dialogue_rnn as DR
+    g = golden("dialogue_rnn")
+    att = DR.MatchingAttention(200, 200, att_type="general2").eval()
+    sd = F_.formula_state_dict(att.state_dict())
+    att.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    _, _, umask = inputs()
+    M = torch.from_numpy(F_.formula_input("drnn.M", 7, 3, 200)) - 0.5
+    mask = torch.from_numpy(umask)
+    pool, al = att(M, M[2], mask=mask)
+    close(pool.detach().numpy(), g["general2/pool"], 2e-6, "pool")
+    close(al.detach().numpy(), g["general2/alpha"], 2e-6, "alpha")
+    # masked positions get exactly zero weight, the rest sums to one
+    assert float((al[:, 0, :] * (1 - mask)).abs().max()) == 0.0 and torch.allclose(al.sum(2), torch.ones(3, 1), atol=1e-6)
+    # batched form == one query per step
+    allp, alla = att.general2_all_queries(M, mask)
+    close(allp[2].detach().numpy(), pool.detach().numpy(), 1e-6, "batched pool")
+    close(alla[:, 2, :].detach().numpy(), al[:, 0, :].detach().numpy(), 1e-6, "batched alpha")
+
+
+def test_reverse_valid_prefix():
+    from gan_ffn_amd import dialogue_rnn as DR
+    X = torch.arange(7 * 3 * 2, dtype=torch.float32).view(7, 3, 2)
+    mask = torch.from_numpy(inputs()[2])
+    R = DR.reverse_valid_prefix(X, mask)
+    assert R.shape == (7, 3, 2)
+    for b, L in enumerate(LENS):
+        assert torch.equal(R[:L, b], X[:L, b].flip(0)) and float(R[L:, b].abs().sum()) == 0
+    # trimmed to the longest valid length, like pad_sequence
+    assert DR.reverse_valid_prefix(X, mask[:, :7] * torch.tensor([[1.] * 5 + [0.] * 2])).shape[0] == 5
