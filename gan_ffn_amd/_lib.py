@@ -64,6 +64,8 @@ SIGNATURES = {
     "ganffn_add_dropout_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U32, _P, _U64, _P]),
     "ganffn_add_dropout_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U32, _P, _U64, _P]),
     "ganffn_debug_set_gemm_cfg": (_I, [_I, _I]),
+    "ganffn_general2_attention_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ganffn_general2_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ganffn_debug_set_ffn_mode": (_I, [_I]),
     "ganffn_dropout": (_I, [_P, _P, _I, _I, _F, _U32, _P, _U64, _P]),
 }

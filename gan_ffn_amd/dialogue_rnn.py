@@ -77,6 +77,9 @@ class MatchingAttention(nn.Module):
         """every time step of M as the candidate, at once: -> pooled (S, B, D), alpha (B, S_query, S_memory).
         Equals [self(M, M[t], mask) for t in range(S)] (what BiModel.forward loops over, model.py:1043-1049)."""
         assert self.att_type == "general2"
+        if M.is_cuda and M.size(0) <= 128 and M.size(2) <= 256:
+            from . import ops                      # one HIP kernel per direction instead of ~10 torch ops on (B,S,S)
+            return ops.General2AttnFn.apply(self.transform(M), M, mask)
         alpha = general2_scores(self.transform(M).transpose(0, 1), M, mask)          # (B, S, S)
         return torch.bmm(alpha, M.transpose(0, 1)).transpose(0, 1), alpha
 

@@ -372,3 +372,34 @@ class LogSoftmaxFn(torch.autograd.Function):
     def backward(ctx, d):
         (lp,) = ctx.saved_tensors
         return d - torch.exp(lp) * d.sum(-1, keepdim=True)
+
+
+class General2AttnFn(torch.autograd.Function):
+    """masked general2 matching attention with every time step as the query (include/ganffn.h, N2):
+    (x = transform(mem) (S,B,D), mem (S,B,D), mask (B,S)) -> (att (S,B,D), alpha (B,S,S)); alpha is an inspection
+    output (the reference returns it to the caller, nothing differentiates through it)."""
+
+    @staticmethod
+    def forward(ctx, x, mem, mask):
+        _need_gpu(x, mem)
+        xc, mc, kc = _f32c(x), _f32c(mem), _f32c(mask)
+        S, B, D = mc.shape
+        att = torch.empty_like(mc)
+        alpha = torch.empty(B, S, S, device=mc.device, dtype=torch.float32)
+        ts = torch.empty(B, S, S, device=mc.device, dtype=torch.float32)
+        _lib.call("ganffn_general2_attention_fwd", _ptr(xc), _ptr(mc), _ptr(kc), _ptr(att), _ptr(alpha), _ptr(ts), S, B, D,
+                  _stream())
+        ctx.save_for_backward(xc, mc, kc, alpha, ts)
+        ctx.mark_non_differentiable(alpha)
+        return att, alpha
+
+    @staticmethod
+    def backward(ctx, d_att, _d_alpha):
+        xc, mc, kc, alpha, ts = ctx.saved_tensors
+        S, B, D = mc.shape
+        g = _f32c(d_att)
+        du = torch.empty_like(alpha)
+        dx, dm = torch.empty_like(mc), torch.empty_like(mc)
+        _lib.call("ganffn_general2_attention_bwd", _ptr(g), _ptr(xc), _ptr(mc), _ptr(kc), _ptr(alpha), _ptr(ts), _ptr(du),
+                  _ptr(dx), _ptr(dm), S, B, D, _stream())
+        return dx, dm, None

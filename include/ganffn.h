@@ -173,6 +173,19 @@ int ganffn_logsoftmax_nll(const float* logits, const int64_t* labels, const floa
                           const float* class_w, float* log_prob, float* loss_out, float* dlogits,
                           float* workspace2, int S, int B, int C, void* stream);
 
+/* ---- N2 (config 5): masked "general2" matching attention, all time steps as queries ---- */
+/* Replaces BiModel.forward's loop over MatchingAttention(att_type="general2") (model.py:1043-1049 -> :169-182,
+ * :193).  x = transform(mem) [S x B x D] (caller's linear), mem [S x B x D], mask [B x S] (umask).  Outputs:
+ * att [S x B x D] pooled memory per query step, alpha [B x S x S] (dialogue, query step, memory step) — the
+ * reference's per-step alpha lists stacked —, tanh_s [B x S x S] saved for backward.  S <= 128, D <= 256. */
+int ganffn_general2_attention_fwd(const float* x, const float* mem, const float* mask, float* att,
+                                  float* alpha, float* tanh_s, int S, int B, int D, void* stream);
+/* d_att [S x B x D] -> dx, dmem [S x B x D] (dmem = pooling path + score path; the gradient through
+ * x = transform(mem) is the caller's linear backward).  du_ws: workspace of B*S*S floats. */
+int ganffn_general2_attention_bwd(const float* d_att, const float* x, const float* mem, const float* mask,
+                                  const float* alpha, const float* tanh_s, float* du_ws, float* dx,
+                                  float* dmem, int S, int B, int D, void* stream);
+
 /* ---- building blocks exported for unit tests ----------------------------------------- */
 /* C[M x N] = A[M x K] * W[N x K]^T + bias (bias may be NULL) */
 int ganffn_gemm_nt(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,

@@ -62,3 +62,55 @@ def test_one_training_step_updates_generators_and_head():
               "bi_model.matchatt.transform.weight", "bi_model.smax_fc.bias"):
         assert moved[k] > 0, k
     assert moved["fc1.weight"] == 0           # present on the object, unused by forward (as in the reference)
+
+
+@pytest.mark.parametrize("S,B,D", [(7, 3, 200), (94, 30, 200), (128, 2, 256), (1, 1, 4)])
+def test_general2_attention_kernel_vs_fp64_torch(S, B, D):
+    """HIP kernel (fwd + bwd) against the torch restatement of model.py:169-182,193 in fp64"""
+    from gan_ffn_amd import dialogue_rnn as DR, ops
+    g = torch.Generator().manual_seed(S * 1000 + D)
+    M = (torch.rand(S, B, D, generator=g) - 0.5)
+    X = (torch.rand(S, B, D, generator=g) - 0.5) * 0.7
+    lens = torch.randint(1, S + 1, (B,), generator=g)
+    lens[0] = S
+    mask = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).float()
+    gy = torch.rand(S, B, D, generator=g) - 0.5
+    M64, X64 = M.double().requires_grad_(True), X.double().requires_grad_(True)
+    a64 = DR.general2_scores(X64.transpose(0, 1), M64, mask.double())
+    att64 = torch.bmm(a64, M64.transpose(0, 1)).transpose(0, 1)
+    (att64 * gy.double()).sum().backward()
+    Md, Xd = M.cuda().requires_grad_(True), X.cuda().requires_grad_(True)
+    att, alpha = ops.General2AttnFn.apply(Xd, Md, mask.cuda())
+    (att * gy.cuda()).sum().backward()
+
+    def rel(a, b):
+        return float((a.detach().cpu().double() - b.detach()).abs().max() / b.detach().abs().max().clamp_min(1e-30))
+    assert rel(alpha, a64) < 5e-6 and rel(att, att64) < 5e-6
+    assert rel(Xd.grad, X64.grad) < 2e-5 and rel(Md.grad, M64.grad) < 2e-5
+    assert float((alpha.cpu() * (1 - mask).unsqueeze(1)).abs().max()) == 0.0          # masked steps: exactly zero weight
+
+
+@pytest.mark.parametrize("tag", ["general", "simple_listener"])
+def test_bimodel_on_gpu_matches_reference_fixture(tag):
+    """the same reference fixture as tests/test_dialogue_rnn_cpu.py, with the head on the GPU (HIP general2 kernel)"""
+    import test_dialogue_rnn_cpu as T
+    import formula as F_
+    from util import golden
+    from gan_ffn_amd import dialogue_rnn as DR
+    g = golden("dialogue_rnn")
+    m = DR.BiModel(**T.DIMS, **T.CASES[tag]).eval()
+    sd = F_.formula_state_dict(m.state_dict())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.cuda()
+    U, qmask, umask = T.inputs()
+    Ut = torch.from_numpy(U).cuda().requires_grad_(True)
+    lp, alpha, alpha_f, alpha_b = m(Ut, torch.from_numpy(qmask).cuda(), torch.from_numpy(umask).cuda())
+    T.close(lp.detach().cpu().numpy(), g["%s/log_prob" % tag], 5e-5, "log_prob")
+    T.close(torch.stack(alpha, 0).detach().cpu().numpy(), g["%s/alpha" % tag], 5e-5, "alpha")
+    gy = torch.from_numpy(F_.formula_input("drnn.grad", lp.shape[0], lp.shape[1], lp.shape[2])) - 0.5
+    (lp * gy.cuda()).sum().backward()
+    T.close(Ut.grad.cpu().numpy(), g["%s/dU" % tag], 2e-4, "dU")
+    for k in ("matchatt.transform.weight", "matchatt.transform.bias", "linear.weight", "dialog_rnn_f.dialogue_cell.g_cell.weight_ih"):
+        p = dict(m.named_parameters())[k]
+        got = p.grad.cpu().numpy() if p.grad.numel() <= 4096 else p.grad.cpu().reshape(-1)[F_.sample_indices(p.grad.numel())].numpy()
+        T.close(got, g["%s/grad/%s" % (tag, k)], 5e-4, "grad " + k)
