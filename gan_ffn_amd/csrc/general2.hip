@@ -7,14 +7,14 @@
 //     a_j = softmax_j(s)_j * m_j / sum_k softmax_k(s)_k * m_k  =  e^{s_j} m_j / sum_k e^{s_k} m_k
 //     att_t = sum_j a_j M_j
 // s is bounded by tanh, so no max-subtraction is needed; a dialogue with no valid step yields 0/0 = NaN as the
-// reference does.  One workgroup per (query step, dialogue); S <= 128, D <= 256 (D = 2 D_e = 200 in config 5).
+// reference does.  One workgroup per (query step, dialogue); S <= 128, D <= 1024 (D = 2 D_e = 200 in config 5, 600 in the MELD classifier).
 // HBM-bound: M[b] (S x D floats) is re-read by the S workgroups of a dialogue out of L2.
 #include "common.h"
 
 namespace ganffn {
 
 constexpr int G2_MAXS = 128;
-constexpr int G2_MAXD = 256;
+constexpr int G2_MAXD = 1024;
 
 __global__ __launch_bounds__(256) void general2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mem,
                                                            const float* __restrict__ mask, float* __restrict__ att,

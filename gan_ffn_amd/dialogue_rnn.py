@@ -77,7 +77,7 @@ class MatchingAttention(nn.Module):
         """every time step of M as the candidate, at once: -> pooled (S, B, D), alpha (B, S_query, S_memory).
         Equals [self(M, M[t], mask) for t in range(S)] (what BiModel.forward loops over, model.py:1043-1049)."""
         assert self.att_type == "general2"
-        if M.is_cuda and M.size(0) <= 128 and M.size(2) <= 256:
+        if M.is_cuda and M.size(0) <= 128 and M.size(2) <= 1024:
             from . import ops                      # one HIP kernel per direction instead of ~10 torch ops on (B,S,S)
             return ops.General2AttnFn.apply(self.transform(M), M, mask)
         alpha = general2_scores(self.transform(M).transpose(0, 1), M, mask)          # (B, S, S)
@@ -228,3 +228,31 @@ class GAN_FFN_DialogueRNN(nn.Module):
     def forward(self, acoustic, visual, text, qmask, umask):
         fusion = self.acoustic_generator(acoustic) + self.visual_generator(visual) + self.text_generator(text)
         return self.bi_model(fusion, qmask, umask)
+
+
+class MELDLSTMModel(nn.Module):
+    """MELD classifier (/root/reference/model.py:520-562, train_MELD.py:147-151): 4-layer
+    bidirectional LSTM over the utterance features, masked general2 attention of every step over the sequence,
+    hardswish(emotions + hardswish(attended)), class log-probabilities.  `linear` and `dropout` serve the att2=False
+    branch / exist on the reference object.  The LSTM is the device library's (MIOpen on the MI355X); the attention is
+    the batched general2 kernel used by BiModel."""
+
+    def __init__(self, D_m, D_e, D_h, n_classes=7, dropout=0.5):
+        super().__init__()
+        self.n_classes = n_classes
+        self.dropout = nn.Dropout(dropout)
+        self.lstm = nn.LSTM(input_size=D_m, hidden_size=D_e, num_layers=4, bidirectional=True, dropout=dropout)
+        self.matchatt = MatchingAttention(2 * D_e, 2 * D_e, att_type="general2")
+        self.linear = nn.Linear(2 * D_e, D_h)
+        self.smax_fc = nn.Linear(D_h, n_classes)
+
+    def forward(self, U, qmask, umask, visuf=None, att2=True):
+        emotions, _ = self.lstm(U)
+        alpha, alpha_f, alpha_b = [], [], []
+        if att2:
+            att, a = self.matchatt.general2_all_queries(emotions, umask)
+            alpha = [a[:, t, :] for t in range(a.size(1))]
+            hidden = F.hardswish(emotions + F.hardswish(att))
+        else:
+            hidden = F.gelu(self.linear(emotions))
+        return F.log_softmax(self.smax_fc(hidden), 2), alpha, alpha_f, alpha_b

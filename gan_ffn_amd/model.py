@@ -277,4 +277,4 @@ class GAN_FFN(nn.Module):
 # configuration 5 (train_IEMOCAP_DialogueRNN.py:705-720): the DialogueRNN head lives in dialogue_rnn.py; re-exported so
 # that `from model import GAN_FFN_DialogueRNN, BiModel, ...` keeps working for code written against the reference
 from .dialogue_rnn import (BiModel, DialogueRNN, DialogueRNNCell, GAN_FFN_DialogueRNN, MatchingAttention,  # noqa: E402,F401
-                           SimpleAttention)
+                           MELDLSTMModel, SimpleAttention)

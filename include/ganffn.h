@@ -177,7 +177,8 @@ int ganffn_logsoftmax_nll(const float* logits, const int64_t* labels, const floa
 /* Replaces BiModel.forward's loop over MatchingAttention(att_type="general2") (model.py:1043-1049 -> :169-182,
  * :193).  x = transform(mem) [S x B x D] (caller's linear), mem [S x B x D], mask [B x S] (umask).  Outputs:
  * att [S x B x D] pooled memory per query step, alpha [B x S x S] (dialogue, query step, memory step) — the
- * reference's per-step alpha lists stacked —, tanh_s [B x S x S] saved for backward.  S <= 128, D <= 256. */
+ * reference's per-step alpha lists stacked —, tanh_s [B x S x S] saved for backward.  S <= 128, D <= 1024.
+ * Also the attention of MELDLSTMModel.forward (model.py:547-552). */
 int ganffn_general2_attention_fwd(const float* x, const float* mem, const float* mask, float* att,
                                   float* alpha, float* tanh_s, int S, int B, int D, void* stream);
 /* d_att [S x B x D] -> dx, dmem [S x B x D] (dmem = pooling path + score path; the gradient through

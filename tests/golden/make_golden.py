@@ -296,6 +296,19 @@ def dialogue_rnn():
             if p_.grad is not None:
                 out["%s/grad/%s" % (tag, k)] = p_.grad.numpy() if p_.grad.numel() <= 4096 else \
                     p_.grad.reshape(-1)[F_.sample_indices(p_.grad.numel())].numpy()
+    # N4: the reference's MELDLSTMModel (eval), real dims of train_MELD.py:143-151
+    torch.manual_seed(0)
+    mm = ref.MELDLSTMModel(600, 300, 600, n_classes=7, dropout=0.5).eval()
+    sd = F_.formula_state_dict(mm.state_dict())
+    mm.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    Um = torch.from_numpy(F_.formula_input("meld.U", 7, 3, 600)).requires_grad_(True)
+    lp, alpha, _, _ = mm(Um, None, torch.from_numpy(umask))
+    gy = torch.from_numpy(F_.formula_input("meld.grad", 7, 3, 7)) - 0.5
+    (lp * gy).sum().backward()
+    out["meld/log_prob"], out["meld/alpha"], out["meld/dU"] = lp.detach().numpy(), torch.stack(alpha, 0).detach().numpy(), Um.grad.numpy()
+    for k in ("lstm.weight_ih_l0", "lstm.weight_hh_l3_reverse", "lstm.bias_ih_l2", "matchatt.transform.weight", "smax_fc.weight"):
+        gk = dict(mm.named_parameters())[k].grad
+        out["meld/grad/" + k] = gk.numpy() if gk.numel() <= 4096 else gk.reshape(-1)[F_.sample_indices(gk.numel())].numpy()
     # MatchingAttention general2 alone, with a mask (the A12 parity target, model.py:169-182)
     att = ref.MatchingAttention(200, 200, att_type="general2").eval()
     sd = F_.formula_state_dict(att.state_dict())

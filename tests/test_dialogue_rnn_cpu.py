@@ -95,3 +95,35 @@ def test_reverse_valid_prefix():
         assert torch.equal(R[:L, b], X[:L, b].flip(0)) and float(R[L:, b].abs().sum()) == 0
     # trimmed to the longest valid length, like pad_sequence
     assert DR.reverse_valid_prefix(X, mask[:, :7] * torch.tensor([[1.] * 5 + [0.] * 2])).shape[0] == 5
+
+
+def _meld_model(dropout=0.5):
+    from gan_ffn_amd import dialogue_rnn as DR
+    torch.manual_seed(2)
+    m = DR.MELDLSTMModel(600, 300, 600, n_classes=7, dropout=dropout).eval()
+    sd = F_.formula_state_dict(m.state_dict())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m
+
+
+def check_meld(m, dev):
+    g = golden("dialogue_rnn")
+    _, _, umask = inputs()
+    Um = torch.from_numpy(F_.formula_input("meld.U", 7, 3, 600)).to(dev).requires_grad_(True)
+    lp, alpha, af, ab = m(Um, None, torch.from_numpy(umask).to(dev))
+    assert af == [] and ab == []
+    close(lp.detach().cpu().numpy(), g["meld/log_prob"], 5e-5, "log_prob")
+    close(torch.stack(alpha, 0).detach().cpu().numpy(), g["meld/alpha"], 5e-5, "alpha")
+    gy = torch.from_numpy(F_.formula_input("meld.grad", 7, 3, 7)) - 0.5
+    (lp * gy.to(dev)).sum().backward()
+    close(Um.grad.cpu().numpy(), g["meld/dU"], 3e-4, "dU")
+    P = dict(m.named_parameters())
+    for k in ("lstm.weight_ih_l0", "lstm.weight_hh_l3_reverse", "lstm.bias_ih_l2", "matchatt.transform.weight", "smax_fc.weight"):
+        gk = P[k].grad.cpu()
+        got = gk.numpy() if gk.numel() <= 4096 else gk.reshape(-1)[F_.sample_indices(gk.numel())].numpy()
+        close(got, g["meld/grad/" + k], 5e-4, "grad " + k)
+
+
+def test_meld_lstm_model_matches_reference_fixture():
+    """N4: MELDLSTMModel (model.py:520-562) — eval mode, formula weights, ragged mask"""
+    check_meld(_meld_model(), "cpu")

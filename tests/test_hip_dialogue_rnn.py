@@ -114,3 +114,10 @@ def test_bimodel_on_gpu_matches_reference_fixture(tag):
         p = dict(m.named_parameters())[k]
         got = p.grad.cpu().numpy() if p.grad.numel() <= 4096 else p.grad.cpu().reshape(-1)[F_.sample_indices(p.grad.numel())].numpy()
         T.close(got, g["%s/grad/%s" % (tag, k)], 5e-4, "grad " + k)
+
+
+def test_meld_lstm_model_on_gpu_matches_reference_fixture():
+    """N4 on the device: MIOpen LSTM + the HIP general2 kernel (D = 600) against the reference's fixture"""
+    import test_dialogue_rnn_cpu as T
+    # MIOpen's RNN backward exists only in training mode: dropout 0 + train() is the same arithmetic as eval()
+    T.check_meld(T._meld_model(dropout=0.0).cuda().train(), "cuda")

@@ -27,14 +27,17 @@ def timeit(fn, reps=20):
 def bench(kind, M, N, K, cfgs, tn_targets=(0,)):
     st = ops._stream()
     out = []
+    # operand distribution matters (MFMA power / clocks): zero-mean data like the real activations and weights by
+    # default, DIST=rand for uniform [0,1)
+    rnd = torch.rand if os.environ.get("DIST", "randn") == "rand" else torch.randn
     if kind == "nt":
-        a, w, b, c = torch.rand(M, K, device="cuda"), torch.rand(N, K, device="cuda"), torch.rand(N, device="cuda"), torch.empty(M, N, device="cuda")
+        a, w, b, c = rnd(M, K, device="cuda"), rnd(N, K, device="cuda"), torch.rand(N, device="cuda"), torch.empty(M, N, device="cuda")
         fn = lambda: _lib.call("ganffn_gemm_nt", ops._ptr(a), ops._ptr(w), ops._ptr(b), ops._ptr(c), M, N, K, st)
     elif kind == "nn":
-        a, w, c = torch.rand(M, K, device="cuda"), torch.rand(K, N, device="cuda"), torch.empty(M, N, device="cuda")
+        a, w, c = rnd(M, K, device="cuda"), rnd(K, N, device="cuda"), torch.empty(M, N, device="cuda")
         fn = lambda: _lib.call("ganffn_gemm_nn", ops._ptr(a), ops._ptr(w), ops._ptr(c), M, N, K, st)
     else:
-        a, w, c, s = torch.rand(K, M, device="cuda"), torch.rand(K, N, device="cuda"), torch.zeros(M, N, device="cuda"), torch.zeros(M, device="cuda")
+        a, w, c, s = rnd(K, M, device="cuda"), rnd(K, N, device="cuda"), torch.zeros(M, N, device="cuda"), torch.zeros(M, device="cuda")
         fn = lambda: _lib.call("ganffn_gemm_tn_acc", ops._ptr(a), ops._ptr(w), ops._ptr(c), ops._ptr(s), M, N, K, st)
     for cfg in cfgs:
         for tt in (tn_targets if kind == "tn" else (0,)):
@@ -49,8 +52,9 @@ def bench(kind, M, N, K, cfgs, tn_targets=(0,)):
 
 
 def bench_torch(M, N, K, iters=50):
-    a = torch.randn(M, K, device="cuda")
-    w = torch.randn(N, K, device="cuda")
+    rnd = torch.rand if os.environ.get("DIST", "randn") == "rand" else torch.randn
+    a = rnd(M, K, device="cuda")
+    w = rnd(N, K, device="cuda")
     for _ in range(5):
         torch.mm(a, w.t())
     torch.cuda.synchronize()

@@ -5,7 +5,7 @@ lib = _lib.load()
 M, N, K = 3008, 2048, 512
 a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda"); b = torch.rand(N, device="cuda"); c = torch.empty(M, N, device="cuda")
 st = ops._stream()
-for cfg in (1, 7):
+for cfg in [int(c) for c in os.environ.get("CFGS", "1,7").split(",")]:
     lib.ganffn_debug_set_gemm_cfg(cfg, 0)
     for _ in range(5):
         _lib.call("ganffn_gemm_nt", ops._ptr(a), ops._ptr(w), ops._ptr(b), ops._ptr(c), M, N, K, st)
