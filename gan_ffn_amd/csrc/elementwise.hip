@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < NC; ++k)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) yy[k][q] += m * v[j][k][q];
+                for (int q = 0; q < 4; ++q) yy[k][q] = __fmaf_rn(m, v[j][k][q], yy[k][q]);
         }
     }
     float z[NC][4];
@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __res
         drop_mult4(dc, (uint32_t)rg, (uint32_t)E, (uint32_t)(lane + 64 * k), mult);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            z[k][q] = (okc[k] && okr[q]) ? xv[k][q] + yy[k][q] * mult[q] : 0.f;
+            // explicit fma / separate roundings below: left to -ffp-contract the compiler fuses some of the four row
+            // slots and not others (packed-math pairs), which makes a row's bits depend on its position in the batch
+            z[k][q] = (okc[k] && okr[q]) ? __fmaf_rn(yy[k][q], mult[q], xv[k][q]) : 0.f;
             sum[q] += z[k][q];
         }
     }
@@ -149,8 +151,8 @@ __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __res
     for (int k = 0; k < NC; ++k) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float d = okc[k] ? z[k][q] - mean[q] : 0.f;
-            var[q] += d * d;
+            const float d = okc[k] ? __fsub_rn(z[k][q], mean[q]) : 0.f;
+            var[q] = __fmaf_rn(d, d, var[q]);
         }
     }
 #pragma unroll
@@ -162,9 +164,9 @@ __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __res
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (okc[k] && okr[q]) {
-                const float xh = (z[k][q] - mean[q]) * rs[q];
+                const float xh = __fmul_rn(__fsub_rn(z[k][q], mean[q]), rs[q]);
                 if (xhat) xhat[off[k][q]] = xh;
-                out[off[k][q]] = xh * ww + bb;
+                out[off[k][q]] = __fmaf_rn(xh, ww, bb);
             }
         }
     }

@@ -117,7 +117,7 @@ def test_multi_stream_schedule_matches_sequential(n_streams, use_graph):
         # a full lr and the loss by ~1e-4 — run to run, also on one stream.
         d = np.abs(a[0][0] - b[0][0])
         assert d[:9].max() < 5e-5 and d[9:].max() < 2e-3, d
-        assert np.abs(a[0][1] - b[0][1]).max() < 5e-2
+        assert np.abs(a[0][1] - b[0][1]).max() < 0.15      # second iteration: same bound as GAN_LOSS_TOL[12:] (Adam chaos)
     else:
         assert np.isfinite(b[0]).all()
 
