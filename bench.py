@@ -128,16 +128,25 @@ def time_dominant_kernel(S, B, reps=3):
     return e0.elapsed_time(e1) * 1e-3 / (reps * n), flops, n
 
 
-def cpu_baseline(S, B_sample, threads):
+def cpu_baseline(S, B_sample, threads, dropout=True):
     """Stock-PyTorch CPU execution (oracle/stock_modules.py: nn.TransformerEncoder stacks, train-mode dropout,
     the reference's sub-step logic) of ONE full 12-sub-step iteration on a bounded sample: B_sample dialogues of
-    the same S.  Returns (utterances/s, seconds, real utterances)."""
+    the same S.  dropout=False: every dropout probability 0 (the CPU run is dominated by bernoulli_ mask generation,
+    SURVEY.md §6 — the dropout-free time keeps the speed-up from being overstated).
+    Returns (utterances/s, seconds, real utterances)."""
     from gan_ffn_amd import data as D
     from oracle import stock_modules as SM
     from oracle.ganffn_oracle import SCHEDULE
     torch.set_num_threads(threads)
     torch.manual_seed(3407)
     gens, discs, opts = SM.build_stock()
+    if not dropout:
+        for m in list(gens.values()) + list(discs.values()):
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+                if isinstance(mod, torch.nn.MultiheadAttention):
+                    mod.dropout = 0.0
     batch = D.synthetic_batch(B=B_sample, S_max=S, seed=3407, device="cpu")
     # tiny warm-up (thread pools, allocator): one D sub-step on 2 dialogues
     wb = {k: batch[k][:, :2].contiguous() for k in ("text", "visual", "acoustic")}
@@ -145,7 +154,7 @@ def cpu_baseline(S, B_sample, threads):
     t0 = time.perf_counter()
     for i, step in enumerate(SCHEDULE):            # one sub-step at a time so progress is visible
         SM.stock_gan_iteration(gens, discs, opts, batch, [step])
-        print("[bench] cpu_baseline sub-step %d/12 done at %.1f s" % (i + 1, time.perf_counter() - t0), file=sys.stderr, flush=True)
+        print("[bench] cpu_baseline%s sub-step %d/12 done at %.1f s" % ("" if dropout else " (dropout-free)", i + 1, time.perf_counter() - t0), file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
     utts = float(batch["umask"].sum())
     return utts / dt, dt, utts
@@ -296,6 +305,10 @@ def main():
                                              "padded to S=%d (%d real utterances), %.1f s" %
                                              (args.cpu_sample_batch, S, int(cutts), cdt)}
             out["config"]["gpu_over_cpu"] = round(value / cv, 1)
+            cv0, cdt0, _ = cpu_baseline(S, args.cpu_sample_batch, threads, dropout=False)
+            out["cpu_baseline"]["dropout_free_value"] = round(cv0, 2)     # same sample, every dropout p = 0
+            out["cpu_baseline"]["dropout_free_seconds"] = round(cdt0, 1)
+            out["config"]["gpu_over_cpu_dropout_free"] = round(value / cv0, 1)
         print(json.dumps(out), flush=True)
     if pg is not None:
         import torch.distributed as dist
