@@ -309,6 +309,10 @@ def main():
             out["cpu_baseline"]["dropout_free_value"] = round(cv0, 2)     # same sample, every dropout p = 0
             out["cpu_baseline"]["dropout_free_seconds"] = round(cdt0, 1)
             out["config"]["gpu_over_cpu_dropout_free"] = round(value / cv0, 1)
+            if threads > 8:       # an 8-thread figure, comparable with the survey's 8-core measurement
+                cv8, cdt8, _ = cpu_baseline(S, max(4, args.cpu_sample_batch // 2), 8)
+                out["cpu_baseline"]["value_8_threads"] = round(cv8, 2)
+                out["cpu_baseline"]["seconds_8_threads"] = round(cdt8, 1)
         print(json.dumps(out), flush=True)
     if pg is not None:
         import torch.distributed as dist

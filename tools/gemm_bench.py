@@ -71,6 +71,12 @@ def bench_torch(M, N, K, iters=50):
 if __name__ == "__main__":
     cfgs = [int(c) for c in os.environ.get('CFGS', '1,2,7').split(',')]
     torch.backends.cuda.matmul.allow_tf32 = False
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        for (N, K) in ((2048, 100), (2048, 512), (512, 2048), (1536, 512)):
+            bench("nt", 6016, N, K, cfgs)
+        bench("nn", 6016, 2048, 100, cfgs)
+        bench("nn", 6016, 100, 2048, cfgs)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "small":
         for M in (3008, 6016):
             for (N, K) in ((100, 100), (300, 100)):
