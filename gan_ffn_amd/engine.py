@@ -211,6 +211,10 @@ class GanEngine(_Runner):
     def _prepare(self, S, B):
         if self._shape == (S, B):
             return
+        if self._shape is not None and self.n_streams > 1:
+            # the buffers about to be dropped may still be in use by sub-steps queued on the side streams (eager
+            # iterations overlap); the caching allocator only tracks the allocating stream
+            torch.cuda.synchronize(self.dev)
         self._shape = (S, B)
         self._graph = None
         dev = self.dev
@@ -403,6 +407,11 @@ class GanEngine(_Runner):
             smap = self.stream_map
             for st in self.streams:
                 st.wait_event(fork)
+                # the caller may drop this batch as soon as we return while the side streams still read it: tell the
+                # caching allocator, so the memory is not handed out again before those streams are done with it
+                for k in ("text", "visual", "acoustic"):
+                    if batch[k].is_cuda:
+                        batch[k].record_stream(st)
             for i, (kind, who, partner) in enumerate(SCHEDULE):
                 st = self.streams[smap[i]]
                 trained = (kind, who)

@@ -176,3 +176,29 @@ def test_phase2_training_reduces_loss():
     for _ in range(25):
         last = float(eng.step(batch)[0])
     assert np.isfinite(last) and last < first
+
+
+def test_multi_stream_with_fresh_batches_of_changing_length():
+    """real loaders hand over a NEW batch (new tensors, new S) every iteration and drop the old one while the side
+    streams may still be working on it: buffers are re-made per shape and batch tensors are recorded on the side
+    streams.  Same data through 1 and 3 streams: first iteration equal, everything finite."""
+    from gan_ffn_amd import engine
+    outs = {}
+    for ns in (1, 3):
+        gens, discs = build_all(zero_dropout=True)
+        eng = engine.GanEngine(gens, discs, n_streams=ns)
+        ls = []
+        for it, S in enumerate((11, 7, 13, 7)):
+            batch = gan_batch(S=S, B=2)                       # fresh tensors each time
+            batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+            eng.iteration(batch)
+            del batch
+            junk = torch.full((1 << 20,), float("nan"), device="cuda")   # try to grab the freed memory right away
+            del junk
+            ls.append(eng.loss_dict())
+        outs[ns] = ls
+    for a, b in zip(outs[1], outs[3]):
+        for k in a:
+            assert np.isfinite(a[k]) and np.isfinite(b[k])
+    for k in outs[1][0]:
+        assert abs(outs[1][0][k] - outs[3][0][k]) < 2e-3, k
