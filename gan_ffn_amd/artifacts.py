@@ -176,7 +176,8 @@ def run_training(dataset_path, g_epochs=150, n_epochs=160, lr=1e-4, l2=0.008, ba
     from . import data as D, engine as E, model as M
     gens, discs = E.build_networks(100, 0.2, device, seed)
     train_loader, _, _ = D.get_IEMOCAP_loaders(dataset_path, batch_size=32, valid=0.1)
-    rows = E.train_GAN(gens, discs, _DeviceBatches(train_loader, device), epochs=g_epochs, lr=1e-4, b1=0.5, b2=0.6)
+    rows = E.train_GAN(gens, discs, _DeviceBatches(train_loader, device), epochs=g_epochs, lr=1e-4, b1=0.5, b2=0.6,
+                       reserve_S=110)
     df = loss_table(rows)
     save_GAN_loss(df, os.path.join(out_dir, "GAN_loss.csv"))
     if not os.path.exists(model_save_path):

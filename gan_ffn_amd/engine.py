@@ -117,24 +117,44 @@ def bucket_ranges(enc_floats, obj_floats, total, layer_floats, L, n_buckets):
 
 
 class _Pass:
-    """Buffers of one forward(+backward) pass of one network at a fixed (S, B)."""
+    """Buffers of one forward(+backward) pass of one network for B dialogues and up to `S_cap` steps.  Storage is flat
+    and sized for S_cap; `resize(S)` re-derives the configs and the shaped views for a shorter batch without touching
+    the allocator (real loaders deliver a different S every iteration)."""
 
-    def __init__(self, net, S, B, dev, need_bwd):
-        self.S, self.B, self.T = S, B, S * B
+    def __init__(self, net, S, B, dev, need_bwd, S_cap=None):
+        self.net, self.B, self.dev, self.need_bwd = net, B, dev, need_bwd
+        self.S_cap = max(S, S_cap or 0)
         E = net.E
+        cfg = ops.enc_cfg(self.S_cap, B, E, net.H, net.L, train=True, p_pe=net.p_pe, p_enc=net.p_enc)
+        n_saved, n_ws = ops.enc_sizes(cfg)
+        h_saved, h_ws = ops.head_sizes(HeadCfg(self.S_cap * B, E, net.D1, net.D2, net.kind, net.p_head, 1))
+        f32 = dict(device=dev, dtype=torch.float32)
+        Tc = self.S_cap * B
+        self._enc_out = torch.empty(Tc * E, **f32)
+        self._saved = torch.empty(n_saved, **f32) if need_bwd else None
+        self._hsaved = torch.empty(h_saved, **f32)
+        self._out = torch.empty(Tc * (net.D2 if net.kind == 0 else 1), **f32)
+        self._dx = torch.empty(Tc * E, **f32) if need_bwd else None
+        self.n_ws = max(n_ws, h_ws)          # at capacity: workspace needs grow with S
+        self.resize(S)
+
+    def resize(self, S):
+        assert S <= self.S_cap
+        net, B = self.net, self.B
+        E = net.E
+        self.S, self.T = S, S * B
         self.cfg_train = ops.enc_cfg(S, B, E, net.H, net.L, train=True, p_pe=net.p_pe, p_enc=net.p_enc)
         self.cfg_eval = ops.enc_cfg(S, B, E, net.H, net.L, train=False, p_pe=net.p_pe, p_enc=net.p_enc)
-        n_saved, n_ws = ops.enc_sizes(self.cfg_train)
+        n_saved, _ = ops.enc_sizes(self.cfg_train)
         self.hcfg_train = HeadCfg(self.T, E, net.D1, net.D2, net.kind, net.p_head, 1)
         self.hcfg_eval = HeadCfg(self.T, E, net.D1, net.D2, net.kind, net.p_head, 0)
-        h_saved, h_ws = ops.head_sizes(self.hcfg_train)
-        f32 = dict(device=dev, dtype=torch.float32)
-        self.enc_out = torch.empty(S, B, E, **f32)
-        self.saved = torch.empty(n_saved, **f32) if need_bwd else None
-        self.hsaved = torch.empty(h_saved, **f32)
-        self.out = torch.empty(S, B, net.D2 if net.kind == 0 else 1, **f32)
-        self.dx = torch.empty(S, B, E, **f32) if need_bwd else None
-        self.n_ws = max(n_ws, h_ws)
+        h_saved, _ = ops.head_sizes(self.hcfg_train)
+        Do = net.D2 if net.kind == 0 else 1
+        self.enc_out = self._enc_out[:self.T * E].view(S, B, E)
+        self.saved = self._saved[:n_saved] if self.need_bwd else None
+        self.hsaved = self._hsaved[:h_saved]
+        self.out = self._out[:self.T * Do].view(S, B, Do)
+        self.dx = self._dx[:self.T * E].view(S, B, E) if self.need_bwd else None
 
 
 class _Res:
@@ -211,11 +231,22 @@ class GanEngine(_Runner):
     def _prepare(self, S, B):
         if self._shape == (S, B):
             return
+        if self._shape is not None and self._shape[1] == B and S <= self._cap_S:
+            # same dialogue count, no longer than what the buffers were sized for: new views, no allocation, no sync
+            for d in (self.pass_G_nosave, self.pass_G, self.pass_D2, self.pass_D1):
+                for p_ in d.values():
+                    p_.resize(S)
+            self._shape = (S, B)
+            self._graph = None
+            self.static_batch = None
+            self._view_scratch(S, B)
+            return
         if self._shape is not None and self.n_streams > 1:
             # the buffers about to be dropped may still be in use by sub-steps queued on the side streams (eager
             # iterations overlap); the caching allocator only tracks the allocating stream
             torch.cuda.synchronize(self.dev)
         self._shape = (S, B)
+        self._cap_S = S
         self._graph = None
         dev = self.dev
         self.pass_G_nosave = {k: _Pass(n, S, B, dev, False) for k, n in self.G.items()}
@@ -224,16 +255,23 @@ class GanEngine(_Runner):
         self.pass_D1 = {k: _Pass(n, S, B, dev, True) for k, n in self.D.items()}       # frozen D in train_gen
         n_ws = max(p.n_ws for d in (self.pass_G, self.pass_D2, self.pass_D1, self.pass_G_nosave) for p in d.values())
         f32 = dict(device=dev, dtype=torch.float32)
-        # scratch is per stream (sub-steps on different streams run concurrently)
-        self.scratch = [dict(ws=torch.empty(n_ws, **f32), x_cat=torch.empty(S, 2 * B, 100, **f32),
-                             obj_out=torch.empty(S, B, 100, **f32), dprob2=torch.empty(S, 2 * B, 1, **f32),
-                             dprob1=torch.empty(S, B, 1, **f32), d_real=torch.empty(S, B, 100, **f32))
-                        for _ in range(self.n_streams)]
-        self._use_scratch(0)
+        # scratch is per stream (sub-steps on different streams run concurrently); flat, viewed per (S, B)
+        self._scratch_flat = [dict(ws=torch.empty(n_ws, **f32), x_cat=torch.empty(S * 2 * B * 100, **f32),
+                                   obj_out=torch.empty(S * B * 100, **f32), dprob2=torch.empty(S * 2 * B, **f32),
+                                   dprob1=torch.empty(S * B, **f32), d_real=torch.empty(S * B * 100, **f32))
+                              for _ in range(self.n_streams)]
+        self._view_scratch(S, B)
         if self.n_streams > 1 and self.streams is None:
             self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
         self._res = {}
         self.static_batch = None
+
+    def _view_scratch(self, S, B):
+        self.scratch = [dict(ws=f["ws"], x_cat=f["x_cat"][:S * 2 * B * 100].view(S, 2 * B, 100),
+                             obj_out=f["obj_out"][:S * B * 100].view(S, B, 100),
+                             dprob2=f["dprob2"][:S * 2 * B].view(S, 2 * B, 1), dprob1=f["dprob1"][:S * B].view(S, B, 1),
+                             d_real=f["d_real"][:S * B * 100].view(S, B, 100)) for f in self._scratch_flat]
+        self._use_scratch(0)
 
     def _use_scratch(self, i):
         sc = self.scratch[i]
@@ -502,14 +540,20 @@ def build_networks(D_h=100, dropout=0.2, device="cuda", seed=None):
     return gens, discs
 
 
-def train_GAN(gens, discs, batches, epochs=1, lr=1e-4, b1=0.5, b2=0.6, process_group=None, use_graph=False, log=None):
+def train_GAN(gens, discs, batches, epochs=1, lr=1e-4, b1=0.5, b2=0.6, process_group=None, use_graph=False, log=None,
+              n_streams=3, reserve_S=None):
     """Counterpart of train_GAN (train_IEMOCAP.py:255-393) over an iterable of batches per epoch.
-    Returns rows of the GAN_loss table (columns train_IEMOCAP.py:308-316): last batch of each epoch."""
-    eng = GanEngine(gens, discs, lr, b1, b2, process_group, use_graph=use_graph)
+    Returns rows of the GAN_loss table (columns train_IEMOCAP.py:308-316): last batch of each epoch.
+    reserve_S: size the step buffers once for dialogues up to this length (PositionalEncoding allows 110), so that
+    batches of varying length never re-allocate."""
+    eng = GanEngine(gens, discs, lr, b1, b2, process_group, use_graph=use_graph, n_streams=n_streams)
     rows = []
     for epoch in range(epochs):
         last = None
         for batch in batches:
+            if reserve_S and eng._shape is None:
+                S0, B0 = batch["text"].shape[:2]
+                eng._prepare(max(reserve_S, S0), B0)
             eng.iteration(batch)
             last = eng.loss_dict()
             if log:

@@ -202,3 +202,24 @@ def test_multi_stream_with_fresh_batches_of_changing_length():
             assert np.isfinite(a[k]) and np.isfinite(b[k])
     for k in outs[1][0]:
         assert abs(outs[1][0][k] - outs[3][0][k]) < 2e-3, k
+
+
+def test_buffers_are_reused_for_shorter_batches():
+    """capacity sizing: a shorter batch re-views the same storage (no allocation), a longer one re-allocates; results
+    do not depend on the capacity the buffers happen to have"""
+    from gan_ffn_amd import engine
+    res = {}
+    for cap in (None, 21):
+        gens, discs = build_all(zero_dropout=True)
+        eng = engine.GanEngine(gens, discs, n_streams=1)
+        if cap:
+            eng._prepare(cap, 2)
+            ptr0 = eng.pass_G["text"]._saved.data_ptr()
+        eng.iteration(gan_batch(S=9, B=2))
+        if cap:
+            assert eng.pass_G["text"]._saved.data_ptr() == ptr0 and eng._cap_S == 21 and eng._shape == (9, 2)
+        res[cap] = eng.loss_dict()
+        eng.iteration(gan_batch(S=13, B=2))
+        assert eng._cap_S == (21 if cap else 13)
+    for k in res[None]:
+        assert abs(res[None][k] - res[21][k]) < 2e-3, k
