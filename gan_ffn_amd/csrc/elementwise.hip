@@ -378,23 +378,43 @@ __global__ void bce_bwd_kernel(const float* __restrict__ prob, float target_a, f
 // ------------------------------------------------------------------------------------------
 // A10: Adam, flat slab.  t = *step + 1 (the counter is bumped by adam_step_inc afterwards)
 // ------------------------------------------------------------------------------------------
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            const int32_t* __restrict__ step, long n, float lr, float b1, float b2, float eps, float wd,
-                            float gscale) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& vi, float lr_bc1, float rs_bc2, float b1,
+                                         float b2, float eps, float wd, float gscale) {
+    gi *= gscale;
+    if (wd != 0.f) gi += wd * pi;
+    mi = b1 * mi + (1.0f - b1) * gi;
+    vi = b2 * vi + (1.0f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / rs_bc2 + eps;
+    pi = pi - lr_bc1 * (mi / denom);
+}
+
+// VEC = 4: one float4 of p, g, m, v per thread (the slabs are 16-byte aligned); the n % 4 tail goes to a VEC = 1 launch.
+// HBM-bound: 28 B per parameter (read p, g, m, v; write p, m, v).
+template <int VEC>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, const int32_t* __restrict__ step, long n, float lr,
+                                                   float b1, float b2, float eps, float wd, float gscale) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (i >= n) return;
     const float t = (float)(*step + 1);
     const float bc1 = 1.0f - powf(b1, t);
     const float bc2 = 1.0f - powf(b2, t);
-    float gi = g[i] * gscale;
-    const float pi = p[i];
-    if (wd != 0.f) gi += wd * pi;
-    const float mi = b1 * m[i] + (1.0f - b1) * gi;
-    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-    p[i] = pi - (lr / bc1) * (mi / denom);
+    const float lr_bc1 = lr / bc1, rs_bc2 = sqrtf(bc2);
+    if (VEC == 4) {
+        float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+        const float4 gg = *reinterpret_cast<const float4*>(g + i);
+        adam_one(pp.x, gg.x, mm.x, vv.x, lr_bc1, rs_bc2, b1, b2, eps, wd, gscale);
+        adam_one(pp.y, gg.y, mm.y, vv.y, lr_bc1, rs_bc2, b1, b2, eps, wd, gscale);
+        adam_one(pp.z, gg.z, mm.z, vv.z, lr_bc1, rs_bc2, b1, b2, eps, wd, gscale);
+        adam_one(pp.w, gg.w, mm.w, vv.w, lr_bc1, rs_bc2, b1, b2, eps, wd, gscale);
+        *reinterpret_cast<float4*>(m + i) = mm;
+        *reinterpret_cast<float4*>(v + i) = vv;
+        *reinterpret_cast<float4*>(p + i) = pp;
+    } else {
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_one(pi, g[i], mi, vi, lr_bc1, rs_bc2, b1, b2, eps, wd, gscale);
+        m[i] = mi; v[i] = vi; p[i] = pi;
+    }
 }
 __global__ void adam_step_inc(int32_t* step) { *step += 1; }
 
@@ -684,9 +704,19 @@ extern "C" int ganffn_adam_step(float* params, const float* grads, float* exp_av
                                 float grad_scale, void* stream) {
     GF_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && step && n > 0, "adam_step: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq,
-                       (const int32_t*)step, (long)n, lr, beta1, beta2, eps, weight_decay, grad_scale);
-    GF_LAUNCH_CHECK();
+    const bool vec = aligned16(params) && aligned16(grads) && aligned16(exp_avg) && aligned16(exp_avg_sq);
+    const long n4 = vec ? ((long)n & ~3L) : 0;
+    if (n4 > 0) {
+        hipLaunchKernelGGL(adam_kernel<4>, dim3((unsigned)((n4 / 4 + 255) / 256)), dim3(256), 0, st, params, grads, exp_avg,
+                           exp_avg_sq, (const int32_t*)step, n4, lr, beta1, beta2, eps, weight_decay, grad_scale);
+        GF_LAUNCH_CHECK();
+    }
+    if (n4 < n) {
+        hipLaunchKernelGGL(adam_kernel<1>, dim3((unsigned)((n - n4 + 255) / 256)), dim3(256), 0, st, params + n4, grads + n4,
+                           exp_avg + n4, exp_avg_sq + n4, (const int32_t*)step, (long)n - n4, lr, beta1, beta2, eps,
+                           weight_decay, grad_scale);
+        GF_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(adam_step_inc, dim3(1), dim3(1), 0, st, step);
     GF_LAUNCH_CHECK();
     return 0;
