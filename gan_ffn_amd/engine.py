@@ -222,6 +222,15 @@ class GanEngine(_Runner):
         self.streams = None
         self._res = {}
         self._base_add = 0
+        # One communicator per sub-step stream: a process group runs its collectives in issue order on ONE internal
+        # stream, so with a single group the all-reduces of a sub-step that is still computing would hold back those
+        # of sub-steps on the other streams that are already done (every rank creates the groups in the same order).
+        self.pgs = [process_group]
+        if process_group is not None and self.n_streams > 1:
+            import torch.distributed as dist
+            ranks = list(range(dist.get_world_size(process_group)))
+            self.pgs += [dist.new_group(ranks=ranks) for _ in range(self.n_streams - 1)]
+        self._cur_pg = process_group
         self._shape = None
         self._graph = None
         self.losses = torch.zeros(12, device=self.dev)
@@ -368,7 +377,7 @@ class GanEngine(_Runner):
         overlapping the rest of backward; Adam divides by world (grad_scale)."""
         if self.pg is None:
             return None, (lambda: None)
-        red = GradReducer(self.pg)
+        red = GradReducer(getattr(self, "_cur_pg", None) or self.pg)
 
         def cb(lo, hi, last):
             red.reduce_async(net.grad[lo:hi])
@@ -461,12 +470,14 @@ class GanEngine(_Runner):
                     bufs = [("buf", "G", who), ("buf", "D1", partner)]
                 self._use_scratch(smap[i])
                 self._cur_stream = st
+                self._cur_pg = self.pgs[smap[i]] if len(self.pgs) > 1 else self.pg
                 with torch.cuda.stream(st):
                     self._wait_writers(st, [trained, other] + bufs)
                     self._wait_readers(st, bufs)
                     (self.train_disc if kind == "D" else self.train_gen)(who, partner, batch, i)
                     self._done(st, reads=[other], writes=[trained] + bufs)
                 self._cur_stream = None
+            self._cur_pg = self.pg
             self._use_scratch(0)
             if device_rng_advance:
                 # graph mode: join everything (the device-side offset bump below must follow every kernel)
