@@ -222,11 +222,13 @@ class GanEngine(_Runner):
         self.streams = None
         self._res = {}
         self._base_add = 0
-        # One communicator per sub-step stream: a process group runs its collectives in issue order on ONE internal
-        # stream, so with a single group the all-reduces of a sub-step that is still computing would hold back those
-        # of sub-steps on the other streams that are already done (every rank creates the groups in the same order).
+        # Optional (GANFFN_COMM_PER_STREAM=1): one communicator per sub-step stream.  A process group runs its collectives
+        # in issue order on ONE internal stream, so with a single group the all-reduces of a sub-step that is still
+        # computing hold back those of sub-steps on the other streams that are already done.  Off by default: collectives
+        # of different communicators in flight at once rely on their kernels being co-resident on every rank, which
+        # could not be exercised on the one-GPU development box.
         self.pgs = [process_group]
-        if process_group is not None and self.n_streams > 1:
+        if process_group is not None and self.n_streams > 1 and os.environ.get("GANFFN_COMM_PER_STREAM", "0") == "1":
             import torch.distributed as dist
             ranks = list(range(dist.get_world_size(process_group)))
             self.pgs += [dist.new_group(ranks=ranks) for _ in range(self.n_streams - 1)]

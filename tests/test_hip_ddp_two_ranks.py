@@ -29,7 +29,7 @@ def _run(world, tmp, n_streams, tag):
     procs, outs = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", GANFFN_COMM_PER_STREAM="1" if n_streams > 1 else "0")
         out = os.path.join(tmp, "%s_r%d.pt" % (tag, r))
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "ddp_gpu_worker.py"), out, str(n_streams)], env=env))
