@@ -164,7 +164,9 @@ def reverse_valid_prefix(X, mask):
     trimmed to max len_b like pad_sequence does (model.py:1008-1021)"""
     S, B = X.shape[0], X.shape[1]
     lens = mask.sum(1).to(torch.long)                                    # (B)
-    Smax = int(lens.max())
+    # pad-collate makes the longest dialogue exactly S long, so max(lens) == S; reading it back would cost a host
+    # sync per call (and forbid graph capture).  Only CPU callers (tests) may pass a mask with trailing all-zero steps.
+    Smax = S if X.is_cuda else int(lens.max())
     t = torch.arange(Smax, device=X.device).unsqueeze(1)                 # (Smax, 1)
     src = (lens.unsqueeze(0) - 1 - t).clamp(min=0)                       # (Smax, B)
     valid = (t < lens.unsqueeze(0)).to(X.dtype).unsqueeze(2)
