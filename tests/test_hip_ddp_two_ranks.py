@@ -29,7 +29,7 @@ def _run(world, tmp, n_streams, tag):
     procs, outs = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", GANFFN_COMM_PER_STREAM="1" if n_streams > 1 else "0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", GANFFN_COMM_PER_STREAM="1" if (n_streams > 1 and world == 2) else "0")
         out = os.path.join(tmp, "%s_r%d.pt" % (tag, r))
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "ddp_gpu_worker.py"), out, str(n_streams)], env=env))
@@ -57,3 +57,16 @@ def test_two_ranks_match_single_process_global_batch(tmp_path, n_streams):
         assert float(delta) <= 4.5e-4, (k, float(delta))
     moved = max(float((two[0]["sd"][k] - v).abs().max()) for k, v in one["sd"].items())
     assert np.isfinite(moved)
+
+
+@pytest.mark.timeout(600)
+def test_four_ranks_one_dialogue_each(tmp_path):
+    """world 4 (one dialogue per rank), 3 sub-step streams, default single communicator"""
+    four = _run(4, str(tmp_path), 3, "w4")
+    one = _run(1, str(tmp_path), 3, "w1")[0]
+    for r in range(1, 4):
+        for k in four[0]["sd"]:
+            assert torch.equal(four[0]["sd"][k], four[r]["sd"][k]), (r, k)
+    l4 = sum(f["losses"] for f in four) / 4
+    d = (l4 - one["losses"]).abs().numpy()
+    assert d[:2].max() < 2e-6 and d[:9].max() < 1e-4 and d.max() < 5e-3, d
