@@ -187,6 +187,7 @@ def run_training(dataset_path, g_epochs=150, n_epochs=160, lr=1e-4, l2=0.008, ba
         m.eval()
     net = M.GAN_FFN(gens["acoustic"], gens["visual"], gens["text"], n_classes=6).to(device)
     eng = E.Phase2Engine(net, lr=lr, weight_decay=l2)
+    eng.reserve(110, batch_size)                     # PositionalEncoding caps a dialogue at 110 utterances
     train_loader, valid_loader, test_loader = D.get_IEMOCAP_loaders(dataset_path, batch_size=batch_size, valid=0.1)
     best = None
     for e in range(n_epochs):

@@ -57,10 +57,10 @@ static LayerOff layer_off(int E, int F) {
 // ------------------------------------------------------------------------------------------
 // saved-for-backward layout of one encoder stack
 //   X[0..L]      (L+1) * T*E     X[0] = PE output, X[l+1] = output of layer l
-//   per layer:   qkv 3TE | attn_o TE | x1 TE | xhat1 TE | xhat2 TE | h TF | rstd1 T4 | rstd2 T4
+//   per layer:   qkv 3TE | attn_o TE | x1 TE | xhat1 TE | xhat2 TE | h TF | rstd1 T4 | rstd2 T4 | lse (T H)4
 // ------------------------------------------------------------------------------------------
 struct SavedOff {
-    int64_t X, layers, per_layer, qkv, attn_o, x1, xhat1, xhat2, h, rstd1, rstd2, total;
+    int64_t X, layers, per_layer, qkv, attn_o, x1, xhat1, xhat2, h, rstd1, rstd2, lse, total;
 };
 static SavedOff saved_off(const ganffn_enc_cfg* c) {
     SavedOff s;
@@ -76,6 +76,7 @@ static SavedOff saved_off(const ganffn_enc_cfg* c) {
     s.h = p; p += TF;
     s.rstd1 = p; p += T4;
     s.rstd2 = p; p += T4;
+    s.lse = p; p += (T * c->H + 3) & ~int64_t(3);     // attention log-sum-exp [B*H x S]
     s.per_layer = p;
     s.total = s.layers + (int64_t)c->L * s.per_layer;
     return s;
@@ -85,7 +86,7 @@ static int check_cfg(const ganffn_enc_cfg* c) {
     GF_CHECK_ARG(c, "null cfg");
     GF_CHECK_ARG(c->S >= 1 && c->S <= 110, "S=%d out of range [1,110] (PositionalEncoding max_len, model.py:1179)", c->S);
     GF_CHECK_ARG(c->B >= 1, "B=%d", c->B);
-    GF_CHECK_ARG(c->E >= 4 && (c->E & 3) == 0 && c->E <= 512, "E=%d must be a multiple of 4 and <= 512", c->E);
+    GF_CHECK_ARG(c->E >= 4 && (c->E & 3) == 0 && c->E <= 640, "E=%d must be a multiple of 4 and <= 640", c->E);
     GF_CHECK_ARG(c->H >= 1 && c->E % c->H == 0, "E=%d not divisible by H=%d", c->E, c->H);
     GF_CHECK_ARG(c->F >= 4 && (c->F & 3) == 0, "F=%d must be a multiple of 4", c->F);
     GF_CHECK_ARG(c->L >= 1 && c->L <= 64, "L=%d", c->L);
@@ -178,7 +179,7 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
         ea.bias = P + lo.in_b;
         GF_TRY(launch_gemm_nt(Xcur, E, P + lo.in_w, E, sv + so.qkv, 3 * E, T, 3 * E, E, EPI_NONE, ea, st));
         // attention core
-        GF_TRY(launch_attention_fwd(sv + so.qkv, sv + so.attn_o, S, B, E, H, c->p_enc, site + 0, rng, add, train, st));
+        GF_TRY(launch_attention_fwd(sv + so.qkv, sv + so.attn_o, sv + so.lse, S, B, E, H, c->p_enc, site + 0, rng, add, train, st));
         // out-proj, residual + dropout + LN1
         ea.bias = P + lo.out_b;
         GF_TRY(launch_gemm_nt(sv + so.attn_o, E, P + lo.out_w, E, tmp, E, T, E, E, EPI_NONE, ea, st));
@@ -331,7 +332,8 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
         else if (G) GF_TRY(launch_gemm_tn_acc(dyB, E, sv + so.attn_o, E, G + lo.out_w, E, G + lo.out_b, E, E, T, ax));
         GF_TRY(launch_gemm_nn(dyB, E, P + lo.out_w, E, d_attn, E, T, E, E, EPI_NONE, none, st));
         // attention core backward
-        GF_TRY(launch_attention_bwd(sv + so.qkv, d_attn, d_qkv, S, B, E, H, c->p_enc, site + 0, rng, add, train, st));
+        GF_TRY(launch_attention_bwd(sv + so.qkv, sv + so.attn_o, sv + so.lse, d_attn, d_qkv, S, B, E, H, c->p_enc, site + 0, rng,
+                                    add, train, st));
         if (use_aux) { GF_HIP(hipEventRecord(ev[3], st)); GF_HIP(hipStreamWaitEvent(ax, ev[3], 0)); }
         // in-proj wgrad + dgrad; dX[l] = d_qkv W_in + dz1
         if (G && grouped) tn[ntn++] = TnDesc{d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T};
@@ -545,11 +547,12 @@ extern "C" int ganffn_gemm_tn_grouped(int n, const float* const* At, const float
     for (int i = 0; i < n; ++i) d[i] = TnDesc{At[i], M[i], Bm[i], N[i], C[i], N[i], colsum ? colsum[i] : nullptr, M[i], N[i], K[i]};
     return launch_gemm_tn_grouped(d, n, (hipStream_t)stream);
 }
-extern "C" int ganffn_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p, uint32_t site,
+extern "C" int ganffn_attention_fwd(const float* qkv, float* o, float* lse, int S, int B, int E, int H, float p, uint32_t site,
                                     const uint64_t* rng, uint64_t add, void* stream) {
-    return launch_attention_fwd(qkv, o, S, B, E, H, p, site, rng, add, 1, (hipStream_t)stream);
+    return launch_attention_fwd(qkv, o, lse, S, B, E, H, p, site, rng, add, 1, (hipStream_t)stream);
 }
-extern "C" int ganffn_attention_bwd(const float* qkv, const float* d_o, float* d_qkv, int S, int B, int E, int H, float p,
-                                    uint32_t site, const uint64_t* rng, uint64_t add, void* stream) {
-    return launch_attention_bwd(qkv, d_o, d_qkv, S, B, E, H, p, site, rng, add, 1, (hipStream_t)stream);
+extern "C" int ganffn_attention_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv, int S,
+                                    int B, int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add,
+                                    void* stream) {
+    return launch_attention_bwd(qkv, o, lse, d_o, d_qkv, S, B, E, H, p, site, rng, add, 1, (hipStream_t)stream);
 }

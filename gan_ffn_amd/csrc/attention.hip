@@ -147,8 +147,8 @@ __device__ __forceinline__ void scores_T(floatx16 (&acc)[NT], const float* __res
         // operands of a whole batch of k-steps are read from LDS before the first MFMA of the batch (left to itself
         // hipcc reuses one register: ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, a full LDS latency per MFMA)
         constexpr int STEPS = HD >> 1;
-        constexpr int BT = STEPS < 8 ? STEPS : 8;
-        static_assert(STEPS % BT == 0, "head_dim/2 must be a multiple of the batch");
+        constexpr int BT = STEPS < 8 ? STEPS : (STEPS % 8 == 0 ? 8 : (STEPS % 6 == 0 ? 6 : (STEPS % 5 == 0 ? 5 : 1)));
+        static_assert(STEPS % BT == 0 && BT > 1, "head_dim/2 must be a multiple of the batch");
 #pragma unroll
         for (int s0 = 0; s0 < STEPS; s0 += BT) {
             float bv[BT], av[BT][NT];
@@ -548,19 +548,10 @@ static int check_attn(int S, int B, int E, int H) {
     return 0;
 }
 
-template <typename K>
-static int set_lds(K kern, size_t lds, const char* what) {
-    if (lds > 48 * 1024) {  // opt in to large dynamic LDS (per device, so done per launch; host-only call)
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
-    }
-    return 0;
-}
-
 template <int HD, int NT>
 static int launch_fwd_t(const float* qkv, float* o, const AttnGeom& g, size_t lds, float p, uint32_t site, const uint64_t* rng,
                         uint64_t add, int train, hipStream_t st) {
-    GF_TRY(set_lds(attention_fwd_kernel<HD, NT>, lds, "attention_fwd"));
+    GF_TRY((lds_optin<attention_fwd_kernel<HD, NT>>(lds, "attention_fwd")));
     hipLaunchKernelGGL((attention_fwd_kernel<HD, NT>), dim3(g.B * g.H), dim3(64 * NT), lds, st, qkv, o, g, p, site, rng, add, train);
     GF_LAUNCH_CHECK();
     return 0;
@@ -568,7 +559,7 @@ static int launch_fwd_t(const float* qkv, float* o, const AttnGeom& g, size_t ld
 template <int HD, int NT>
 static int launch_bwd_t(const float* qkv, const float* d_o, float* d_qkv, const AttnGeom& g, size_t lds, float p, uint32_t site,
                         const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
-    GF_TRY(set_lds(attention_bwd_kernel<HD, NT>, lds, "attention_bwd"));
+    GF_TRY((lds_optin<attention_bwd_kernel<HD, NT>>(lds, "attention_bwd")));
     hipLaunchKernelGGL((attention_bwd_kernel<HD, NT>), dim3(g.B * g.H), dim3(64 * NT), lds, st, qkv, d_o, d_qkv, g, p, site, rng,
                        add, train);
     GF_LAUNCH_CHECK();
@@ -583,31 +574,33 @@ static int launch_bwd_t(const float* qkv, const float* d_o, float* d_qkv, const 
         default: return FN<HD, 4>(__VA_ARGS__);                 \
     }
 
-int launch_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p, uint32_t site,
+int launch_attention_fwd(const float* qkv, float* o, float* lse, int S, int B, int E, int H, float p, uint32_t site,
                          const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
     GF_TRY(check_attn(S, B, E, H));
     GF_CHECK_ARG(qkv && o, "attention_fwd: null pointer");
     GF_CHECK_ARG(!(train && p > 0.f) || rng, "attention_fwd: rng required when dropout is active");
+    if (attn16_supported(E, H)) return launch_attn16_fwd(qkv, o, lse, S, B, E, H, p, site, rng, add, train, st);
     const AttnGeom g = make_geom(S, B, E, H);
     const size_t lds = 3 * hd_mat_floats(g) * sizeof(float);
     GF_CHECK_ARG(lds <= 160 * 1024, "attention_fwd: LDS need %zu > 160 KiB", lds);
-    if (g.hd == 10) { NT_SWITCH(launch_fwd_t, 10, qkv, o, g, lds, p, site, rng, add, train, st) }
     if (g.hd == 64) { NT_SWITCH(launch_fwd_t, 64, qkv, o, g, lds, p, site, rng, add, train, st) }
+    if (g.hd == 60) { NT_SWITCH(launch_fwd_t, 60, qkv, o, g, lds, p, site, rng, add, train, st) }
     NT_SWITCH(launch_fwd_t, 0, qkv, o, g, lds, p, site, rng, add, train, st)
 }
 
-int launch_attention_bwd(const float* qkv, const float* d_o, float* d_qkv, int S, int B, int E, int H, float p,
-                         uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
+int launch_attention_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv, int S, int B,
+                         int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
     GF_TRY(check_attn(S, B, E, H));
     GF_CHECK_ARG(qkv && d_o && d_qkv, "attention_bwd: null pointer");
     GF_CHECK_ARG(!(train && p > 0.f) || rng, "attention_bwd: rng required when dropout is active");
+    if (attn16_supported(E, H)) return launch_attn16_bwd(qkv, o, lse, d_o, d_qkv, S, B, E, H, p, site, rng, add, train, st);
     const AttnGeom g = make_geom(S, B, E, H);
-    const int hdt = (g.hd == 10 || g.hd == 64) ? g.hd : 0;      // kernel template head_dim (0 = generic)
+    const int hdt = (g.hd == 60 || g.hd == 64) ? g.hd : 0;      // kernel template head_dim (0 = generic)
     const bool alias = hdt == 0 || hdt * g.NT > 192;            // == attention_bwd_kernel::ALIAS
     const size_t lds = ((alias ? 3 : 4) * hd_mat_floats(g) + ss_mat_floats(g)) * sizeof(float);
     GF_CHECK_ARG(lds <= 160 * 1024, "attention_bwd: LDS need %zu > 160 KiB", lds);
-    if (g.hd == 10) { NT_SWITCH(launch_bwd_t, 10, qkv, d_o, d_qkv, g, lds, p, site, rng, add, train, st) }
     if (g.hd == 64) { NT_SWITCH(launch_bwd_t, 64, qkv, d_o, d_qkv, g, lds, p, site, rng, add, train, st) }
+    if (g.hd == 60) { NT_SWITCH(launch_bwd_t, 60, qkv, d_o, d_qkv, g, lds, p, site, rng, add, train, st) }
     NT_SWITCH(launch_bwd_t, 0, qkv, d_o, d_qkv, g, lds, p, site, rng, add, train, st)
 }
 

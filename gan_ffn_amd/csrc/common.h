@@ -36,6 +36,22 @@ int fail(int code, const char* fmt, ...);
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// Opt a kernel in to more than 48 KiB of dynamic LDS: once per (kernel, device, host thread), not on every launch.
+// KERN is the kernel itself (a non-type template argument), so every instantiation has its own flag word.
+template <auto KERN>
+static inline int lds_optin(size_t lds, const char* what) {
+    if (lds <= 48 * 1024) return 0;
+    static thread_local uint64_t done_mask = 0;       // one bit per device ordinal
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return ::ganffn::fail((int)e, "%s: hipGetDevice failed: %s", what, hipGetErrorString(e));
+    if (dev < 64 && ((done_mask >> dev) & 1u)) return 0;
+    e = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return ::ganffn::fail((int)e, "%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
+    if (dev < 64) done_mask |= uint64_t(1) << dev;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // dropout sites (mirror of oracle/ganffn_oracle.py SITE_*)
 // ---------------------------------------------------------------------------------------
@@ -203,10 +219,18 @@ struct TnDesc {
 };
 int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st);
 
-int launch_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p, uint32_t site,
+// lse [B*H x S]: log-sum-exp of every score row, written by the forward (may be NULL: not kept) and, together with the
+// forward's output o, read by the backward of the small-head kernels (attention16.hip); the head_dim 60/64 kernels
+// (attention.hip) recompute the softmax statistics and ignore both.
+int launch_attention_fwd(const float* qkv, float* o, float* lse, int S, int B, int E, int H, float p, uint32_t site,
                          const uint64_t* rng, uint64_t add, int train, hipStream_t st);
-int launch_attention_bwd(const float* qkv, const float* d_o, float* d_qkv, int S, int B, int E, int H, float p,
-                         uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+int launch_attention_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv, int S, int B,
+                         int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+bool attn16_supported(int E, int H);
+int launch_attn16_fwd(const float* qkv, float* o, float* lse, int S, int B, int E, int H, float p, uint32_t site,
+                      const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+int launch_attn16_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv, int S, int B, int E,
+                      int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st);
 
 int launch_pe_dropout(const float* x, const float* pe, float* out, int S, int B, int E, float p,
                       const uint64_t* rng, uint64_t add, int train, hipStream_t st);

@@ -73,7 +73,7 @@ __global__ void add3_kernel(const float* __restrict__ a, const float* __restrict
 // z = x + dropout(y); xhat = (z - mean) * rstd; out = xhat * w + b        (norm1 / norm2, post-LN)
 // one wave per group of 4 rows; lane covers columns lane, lane+64, ...  (E <= 64*MAXC)
 // ------------------------------------------------------------------------------------------
-constexpr int LN_MAXC = 8;  // E <= 512
+constexpr int LN_MAXC = 10;  // E <= 640 (d_model 600 of the MELD-dimension text stack)
 constexpr int LN_MAXSLAB = 16;  // split-K / split-F slabs summed on the fly (api.hip MAX_SPLITS)
 
 // NC = column chunks of 64 per lane (E <= 64 NC); NSB = slabs loaded per batch.  Every global load is issued from a
@@ -584,7 +584,9 @@ int launch_add_drop_ln_fwd(const float* x, const float* y, const float* w, const
     if (E <= 64) GF_LN_FWD(1, 8);
     else if (E <= 128) GF_LN_FWD(2, 8);
     else if (E <= 256) GF_LN_FWD(4, 4);
-    else GF_LN_FWD(8, 2);
+    else if (E <= 320) GF_LN_FWD(5, 4);
+    else if (E <= 512) GF_LN_FWD(8, 2);
+    else GF_LN_FWD(10, 2);
 #undef GF_LN_FWD
     GF_LAUNCH_CHECK();
     return 0;
@@ -606,7 +608,9 @@ int launch_add_drop_ln_bwd(const float* d_out, const float* xhat, const float* r
     if (E <= 64) GF_LN_BWD(1, 8);
     else if (E <= 128) GF_LN_BWD(2, 8);
     else if (E <= 256) GF_LN_BWD(4, 4);
-    else GF_LN_BWD(8, 2);
+    else if (E <= 320) GF_LN_BWD(5, 4);
+    else if (E <= 512) GF_LN_BWD(8, 2);
+    else GF_LN_BWD(10, 2);
 #undef GF_LN_BWD
     GF_LAUNCH_CHECK();
     return 0;

@@ -252,12 +252,10 @@ static int launch_ffn(const FfnArgs& a, int splits, int bwd, hipStream_t st) {
     const size_t lds = 2 * STAGE * sizeof(float);
     dim3 grid((a.T + 127) / 128, splits);
     if (bwd) {
-        hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail((int)e, "ffn: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        GF_TRY((lds_optin<ffn_fused_kernel<1>>(lds, "ffn")));
         hipLaunchKernelGGL(ffn_fused_kernel<1>, grid, dim3(256), lds, st, a);
     } else {
-        hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail((int)e, "ffn: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        GF_TRY((lds_optin<ffn_fused_kernel<0>>(lds, "ffn")));
         hipLaunchKernelGGL(ffn_fused_kernel<0>, grid, dim3(256), lds, st, a);
     }
     GF_LAUNCH_CHECK();

@@ -438,11 +438,7 @@ template <int MODE, int BM, int BN, int BK, int EPI, int WGM = 2, int WGN = 2>
 static int launch_cfg(const GemmArgs& g, int splits, hipStream_t st) {
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
     constexpr size_t lds = Smem<MODE, BM, BN, BK>::TOTAL * sizeof(float);
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<MODE, BM, BN, BK, EPI, WGM, WGN>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail((int)e, "gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    }
+    GF_TRY((lds_optin<gemm_kernel<MODE, BM, BN, BK, EPI, WGM, WGN>>(lds, "gemm")));
     hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, BK, EPI, WGM, WGN>), grid, dim3(64 * WGM * WGN), lds, st, g);
     GF_LAUNCH_CHECK();
     return 0;

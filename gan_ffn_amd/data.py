@@ -10,6 +10,9 @@ import torch
 import torch.utils.data
 
 DIMS = {"text": 100, "visual": 512, "acoustic": 100}
+# MELD feature widths (train_MELD.py:143 text D_m = 600; audio 300 per dataloader.py:93-95's videoAudio); MELD has no visual
+# modality.  Used only by the MELD-dimension extension workload (BASELINE.json configs[2]).
+MELD_DIMS = {"text": 600, "acoustic": 300}
 
 
 def dialogue_lengths(B, S_max=94, seed=3407, lo=8, mean=48):
@@ -21,14 +24,15 @@ def dialogue_lengths(B, S_max=94, seed=3407, lo=8, mean=48):
     return L
 
 
-def synthetic_batch(B=32, S_max=94, seed=3407, device="cpu", n_classes=6):
-    """-> dict(text, visual, acoustic, qmask, umask, label, lengths); uniform[0,1) features, zero padding."""
-    L = dialogue_lengths(B, S_max, seed)
+def synthetic_batch(B=32, S_max=94, seed=3407, device="cpu", n_classes=6, dims=None, lo=8, mean=48):
+    """-> dict(text, visual, acoustic, qmask, umask, label, lengths); uniform[0,1) features, zero padding.
+    dims: modality -> feature width (default: IEMOCAP's)."""
+    L = dialogue_lengths(B, S_max, seed, lo=lo, mean=mean)
     S = int(L.max())
     g = torch.Generator().manual_seed(seed)
     out = {}
     valid = (torch.arange(S).unsqueeze(1) < torch.from_numpy(L).unsqueeze(0)).float()       # (S, B)
-    for k, d in DIMS.items():
+    for k, d in (dims or DIMS).items():
         out[k] = (torch.rand(S, B, d, generator=g) * valid.unsqueeze(-1)).to(device).contiguous()
     spk = torch.randint(0, 2, (S, B), generator=g)
     out["qmask"] = (torch.nn.functional.one_hot(spk, 2).float() * valid.unsqueeze(-1)).to(device)

@@ -65,7 +65,10 @@ class NetState:
         self.D1 = module.fc1.weight.shape[0]
         self.D2 = module.fc2.weight.shape[0]
         self.layer_floats = enc // self.L
-        self.obj_floats = (512 * 100 + 100) if module.HAS_OBJECT else 0   # `object` sits right after the layers
+        self.has_obj = bool(module.HAS_OBJECT)
+        self.obj_in = int(module.OBJECT_IN) if self.has_obj else 0       # raw-modality width `object` maps to D_h
+        # `object` (weight [D_h x obj_in] | bias [D_h], each padded to 4 floats) sits right after the layers
+        self.obj_floats = sum((int(p.numel()) + 3) & ~3 for p in (module.object.weight, module.object.bias)) if self.has_obj else 0
 
     def w(self, name, grad=False):
         off, shape = self.named[name]
@@ -117,13 +120,14 @@ def bucket_ranges(enc_floats, obj_floats, total, layer_floats, L, n_buckets):
 
 
 class _Pass:
-    """Buffers of one forward(+backward) pass of one network for B dialogues and up to `S_cap` steps.  Storage is flat
-    and sized for S_cap; `resize(S)` re-derives the configs and the shaped views for a shorter batch without touching
-    the allocator (real loaders deliver a different S every iteration)."""
+    """Buffers of one forward(+backward) pass of one network for up to `B` dialogues of up to `S` steps.  Storage is
+    flat and sized for that capacity; `resize(S, B)` re-derives the configs and the shaped views for a smaller batch
+    without touching the allocator (real loaders deliver a different S every iteration and a short last batch)."""
 
     def __init__(self, net, S, B, dev, need_bwd, S_cap=None):
         self.net, self.B, self.dev, self.need_bwd = net, B, dev, need_bwd
         self.S_cap = max(S, S_cap or 0)
+        self.B_cap = B
         E = net.E
         cfg = ops.enc_cfg(self.S_cap, B, E, net.H, net.L, train=True, p_pe=net.p_pe, p_enc=net.p_enc)
         n_saved, n_ws = ops.enc_sizes(cfg)
@@ -138,9 +142,11 @@ class _Pass:
         self.n_ws = max(n_ws, h_ws)          # at capacity: workspace needs grow with S
         self.resize(S)
 
-    def resize(self, S):
-        assert S <= self.S_cap
-        net, B = self.net, self.B
+    def resize(self, S, B=None):
+        B = self.B_cap if B is None else B
+        assert S <= self.S_cap and B <= self.B_cap
+        net = self.net
+        self.B = B
         E = net.E
         self.S, self.T = S, S * B
         self.cfg_train = ops.enc_cfg(S, B, E, net.H, net.L, train=True, p_pe=net.p_pe, p_enc=net.p_enc)
@@ -173,6 +179,11 @@ STREAM_MAP = {1: [0] * 12,
               2: [0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1],     # measured best of six 2-stream maps (60.9 ms vs 81.6 ms on 1)
               3: [0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 2, 2]}     # visual generator's chain on its own stream: 49.9 ms
 
+# Bi-modal schedule of the MELD-dimension extension workload (BASELINE.json configs[2]; MELD has text and audio only,
+# dataloader.py:93-95): the text/acoustic sub-steps 5-8 of the reference's order (train_IEMOCAP.py:363-370).
+SCHEDULE_BIMODAL = [s for s in SCHEDULE if "visual" not in s[1:]]
+STREAM_MAP_BIMODAL = {1: [0, 0, 0, 0], 2: [0, 0, 1, 1]}
+
 
 class _Runner:
     """network-level forward / backward / Adam on preallocated buffers — shared by the GAN step runner and the
@@ -203,22 +214,32 @@ class GanEngine(_Runner):
     schedule.  Most kernels of this workload fill a fraction of the 256 CUs, so overlapping them is free."""
 
     def __init__(self, gens, discs, lr=1e-4, b1=0.5, b2=0.6, process_group=None, n_buckets=3, use_graph=False,
-                 n_streams=1):
+                 n_streams=1, schedule=None):
         # optimizers: train_IEMOCAP.py:292-297 (G lr, text-G 1.1*lr, every D lr/2); call site :603-606
         self.G = {k: NetState(m, lr * (1.1 if k == "text" else 1.0), (b1, b2)) for k, m in gens.items()}
         self.D = {k: NetState(m, lr / 2, (b1, b2)) for k, m in discs.items()}
         self._init_common(next(iter(self.G.values())).slab.device, process_group, n_buckets)
+        self.modalities = list(self.G.keys())
+        if schedule is None:
+            schedule = SCHEDULE if set(self.modalities) == {"acoustic", "visual", "text"} else \
+                [s_ for s_ in SCHEDULE if s_[1] in self.G and s_[2] in self.G]
+        self.schedule = list(schedule)
+        self.D_h = next(iter(self.G.values())).D2          # width of the fused feature = every discriminator's d_model
+        stream_maps = STREAM_MAP if len(self.schedule) == 12 else \
+            {1: [0] * len(self.schedule), 2: [(i // 2) % 2 for i in range(len(self.schedule))]}
         self.use_graph = use_graph
         self.use_aux = os.environ.get("GANFFN_AUX", "0") == "1"   # wgrad on a 2nd stream: measured slower with >1 sub-step stream
-        self.n_streams = n_streams if n_streams in STREAM_MAP else 1
+        if n_streams not in stream_maps:
+            n_streams = max(k for k in stream_maps if k <= max(1, n_streams))
+        self.n_streams = n_streams
         if use_graph and self.n_streams > 1:
             # multi-stream capture is not used: replay == eager here (the step is GPU-bound, not launch-bound), and
             # eager streams additionally overlap consecutive iterations
             self.use_graph = use_graph = False
-        self.stream_map = STREAM_MAP[self.n_streams]
+        self.stream_map = stream_maps[self.n_streams]
         if os.environ.get("GANFFN_STREAM_MAP"):
             self.stream_map = [int(x) for x in os.environ["GANFFN_STREAM_MAP"].split(",")]
-            assert len(self.stream_map) == 12 and max(self.stream_map) < self.n_streams
+            assert len(self.stream_map) == len(self.schedule) and max(self.stream_map) < self.n_streams
         self.streams = None
         self._res = {}
         self._base_add = 0
@@ -235,18 +256,24 @@ class GanEngine(_Runner):
         self._cur_pg = process_group
         self._shape = None
         self._graph = None
-        self.losses = torch.zeros(12, device=self.dev)
+        self.losses = torch.zeros(len(self.schedule), device=self.dev)
         self._adds = 0
+        self._cap_S = self._cap_B = 0
 
     # ------------------------------------------------------------------------------------------
+    def reserve(self, S, B):
+        """size every step buffer once for dialogues of up to S utterances and batches of up to B dialogues, so that
+        the varying (S, B) of real loaders (no drop_last: every epoch ends on a short batch, train_IEMOCAP.py:62-100)
+        never touches the allocator again"""
+        self._cap_S, self._cap_B = max(self._cap_S, S), max(self._cap_B, B)
+
     def _prepare(self, S, B):
         if self._shape == (S, B):
             return
-        if self._shape is not None and self._shape[1] == B and S <= self._cap_S:
-            # same dialogue count, no longer than what the buffers were sized for: new views, no allocation, no sync
-            for d in (self.pass_G_nosave, self.pass_G, self.pass_D2, self.pass_D1):
-                for p_ in d.values():
-                    p_.resize(S)
+        if self._shape is not None and S <= self._alloc_S and B <= self._alloc_B:
+            # within what the buffers were sized for: new views, no allocation, no sync.  (A pass of fewer dialogues uses
+            # a prefix of the flat storage; layouts are derived from (S, B) alone.)
+            self._resize_passes(S, B)
             self._shape = (S, B)
             self._graph = None
             self.static_batch = None
@@ -256,32 +283,46 @@ class GanEngine(_Runner):
             # the buffers about to be dropped may still be in use by sub-steps queued on the side streams (eager
             # iterations overlap); the caching allocator only tracks the allocating stream
             torch.cuda.synchronize(self.dev)
+        # capacity only ever grows (a short last batch must not shrink it)
+        cS = self._cap_S = max(self._cap_S, S)
+        cB = self._cap_B = max(self._cap_B, B)
+        self._alloc_S, self._alloc_B = cS, cB
         self._shape = (S, B)
-        self._cap_S = S
         self._graph = None
         dev = self.dev
-        self.pass_G_nosave = {k: _Pass(n, S, B, dev, False) for k, n in self.G.items()}
-        self.pass_G = {k: _Pass(n, S, B, dev, True) for k, n in self.G.items()}
-        self.pass_D2 = {k: _Pass(n, S, 2 * B, dev, True) for k, n in self.D.items()}   # [real | fake]
-        self.pass_D1 = {k: _Pass(n, S, B, dev, True) for k, n in self.D.items()}       # frozen D in train_gen
+        self.pass_G_nosave = {k: _Pass(n, cS, cB, dev, False) for k, n in self.G.items()}
+        self.pass_G = {k: _Pass(n, cS, cB, dev, True) for k, n in self.G.items()}
+        self.pass_D2 = {k: _Pass(n, cS, 2 * cB, dev, True) for k, n in self.D.items()}   # [real | fake]
+        self.pass_D1 = {k: _Pass(n, cS, cB, dev, True) for k, n in self.D.items()}       # frozen D in train_gen
         n_ws = max(p.n_ws for d in (self.pass_G, self.pass_D2, self.pass_D1, self.pass_G_nosave) for p in d.values())
         f32 = dict(device=dev, dtype=torch.float32)
+        Dh = self.D_h
         # scratch is per stream (sub-steps on different streams run concurrently); flat, viewed per (S, B)
-        self._scratch_flat = [dict(ws=torch.empty(n_ws, **f32), x_cat=torch.empty(S * 2 * B * 100, **f32),
-                                   obj_out=torch.empty(S * B * 100, **f32), dprob2=torch.empty(S * 2 * B, **f32),
-                                   dprob1=torch.empty(S * B, **f32), d_real=torch.empty(S * B * 100, **f32))
+        self._scratch_flat = [dict(ws=torch.empty(n_ws, **f32), x_cat=torch.empty(cS * 2 * cB * Dh, **f32),
+                                   obj_out=torch.empty(cS * cB * Dh, **f32), dprob2=torch.empty(cS * 2 * cB, **f32),
+                                   dprob1=torch.empty(cS * cB, **f32), d_real=torch.empty(cS * cB * Dh, **f32))
                               for _ in range(self.n_streams)]
+        if (S, B) != (cS, cB):
+            self._resize_passes(S, B)
         self._view_scratch(S, B)
         if self.n_streams > 1 and self.streams is None:
             self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
         self._res = {}
         self.static_batch = None
 
+    def _resize_passes(self, S, B):
+        for d in (self.pass_G_nosave, self.pass_G, self.pass_D1):
+            for p_ in d.values():
+                p_.resize(S, B)
+        for p_ in self.pass_D2.values():
+            p_.resize(S, 2 * B)
+
     def _view_scratch(self, S, B):
-        self.scratch = [dict(ws=f["ws"], x_cat=f["x_cat"][:S * 2 * B * 100].view(S, 2 * B, 100),
-                             obj_out=f["obj_out"][:S * B * 100].view(S, B, 100),
+        Dh = self.D_h
+        self.scratch = [dict(ws=f["ws"], x_cat=f["x_cat"][:S * 2 * B * Dh].view(S, 2 * B, Dh),
+                             obj_out=f["obj_out"][:S * B * Dh].view(S, B, Dh),
                              dprob2=f["dprob2"][:S * 2 * B].view(S, 2 * B, 1), dprob1=f["dprob1"][:S * B].view(S, B, 1),
-                             d_real=f["d_real"][:S * B * 100].view(S, B, 100)) for f in self._scratch_flat]
+                             d_real=f["d_real"][:S * B * Dh].view(S, B, Dh)) for f in self._scratch_flat]
         self._use_scratch(0)
 
     def _use_scratch(self, i):
@@ -388,15 +429,15 @@ class GanEngine(_Runner):
     # ------------------------------------------------------------------------------------------
     def train_disc(self, who, partner, batch, loss_slot):
         """train_IEMOCAP.py:200-227."""
-        S, B = batch["text"].shape[:2]
+        S, B = batch[who].shape[:2]
         Dn, Gn = self.D[who], self.G[partner]
         pg_, pd = self.pass_G_nosave[partner], self.pass_D2[who]
         # fusion = G(real_gen) in eval mode, nothing saved (detach(), :218-219)
         self._net_fwd(Gn, pg_, batch[partner], train=False, save=False)
         # real input of D_m is raw modality m; VisualDiscriminator maps 512 -> 100 first (model.py:1355-1356)
         x_real = batch[who]
-        if who == "visual":
-            ops.linear_fwd_raw(x_real, Dn.w("object.weight"), Dn.w("object.bias"), self.obj_out, S * B, 512, 100)
+        if Dn.has_obj:
+            ops.linear_fwd_raw(x_real, Dn.w("object.weight"), Dn.w("object.bias"), self.obj_out, S * B, Dn.obj_in, self.D_h)
             x_real = self.obj_out
         torch.cat((x_real, pg_.out), dim=1, out=self.x_cat)
         adds = self._net_fwd(Dn, pd, self.x_cat, train=True, save=True)
@@ -408,10 +449,10 @@ class GanEngine(_Runner):
         Dn.grad.zero_()                                              # opt.zero_grad(), :216
         cb, finish = self._make_reducer(Dn)
         self._net_bwd(Dn, pd, self.dprob2, True, adds, True, cb)
-        if who == "visual":
+        if Dn.has_obj:
             self.d_real.copy_(pd.dx[:, :B])                      # gradient of the real half of the batch
             ops.linear_bwd_raw(self.d_real, batch[who], Dn.w("object.weight"), None, Dn.w("object.weight", True),
-                               Dn.w("object.bias", True), S * B, 512, 100)
+                               Dn.w("object.bias", True), S * B, Dn.obj_in, self.D_h)
             if cb is not None:
                 cb(Dn.enc_floats, Dn.enc_floats + Dn.obj_floats, last=True)
         finish()
@@ -420,7 +461,7 @@ class GanEngine(_Runner):
 
     def train_gen(self, who, partner, batch, loss_slot):
         """train_IEMOCAP.py:230-252."""
-        S, B = batch["text"].shape[:2]
+        S, B = batch[who].shape[:2]
         Gn, Dn = self.G[who], self.D[partner]
         pg_, pd = self.pass_G[who], self.pass_D1[partner]
         g_adds = self._net_fwd(Gn, pg_, batch[who], train=True, save=True)
@@ -447,7 +488,7 @@ class GanEngine(_Runner):
     def _iteration_body(self, batch, device_rng_advance):
         self._adds = 0
         if self.n_streams == 1:
-            for i, (kind, who, partner) in enumerate(SCHEDULE):
+            for i, (kind, who, partner) in enumerate(self.schedule):
                 (self.train_disc if kind == "D" else self.train_gen)(who, partner, batch, i)
         else:
             origin = torch.cuda.current_stream()
@@ -458,10 +499,10 @@ class GanEngine(_Runner):
                 st.wait_event(fork)
                 # the caller may drop this batch as soon as we return while the side streams still read it: tell the
                 # caching allocator, so the memory is not handed out again before those streams are done with it
-                for k in ("text", "visual", "acoustic"):
+                for k in self.modalities:
                     if batch[k].is_cuda:
                         batch[k].record_stream(st)
-            for i, (kind, who, partner) in enumerate(SCHEDULE):
+            for i, (kind, who, partner) in enumerate(self.schedule):
                 st = self.streams[smap[i]]
                 trained = (kind, who)
                 other = ("G" if kind == "D" else "D", partner)
@@ -501,13 +542,13 @@ class GanEngine(_Runner):
     def iteration(self, batch):
         """One batch = 12 sub-steps.  Returns the device tensor of the 12 sub-step losses (no host sync).
         With n_streams > 1 call synchronize() (or loss_dict()) before reading it on the current stream."""
-        S, B = batch["text"].shape[:2]
+        S, B = batch[self.modalities[0]].shape[:2]
         self._prepare(S, B)
         if not self.use_graph:
             self._iteration_body(batch, device_rng_advance=False)
             return self.losses
         if self.static_batch is None:
-            self.static_batch = {k: batch[k].clone() for k in ("text", "visual", "acoustic")}
+            self.static_batch = {k: batch[k].clone() for k in self.modalities}
         else:
             for k in self.static_batch:
                 self.static_batch[k].copy_(batch[k])
@@ -531,7 +572,7 @@ class GanEngine(_Runner):
         self.synchronize()
         v = self.losses.tolist()
         out = {}
-        for (kind, who, _), x in zip(SCHEDULE, v):
+        for (kind, who, _), x in zip(self.schedule, v):
             out["%s_%s_loss" % (who, kind)] = x
         return out
 
@@ -566,7 +607,7 @@ def train_GAN(gens, discs, batches, epochs=1, lr=1e-4, b1=0.5, b2=0.6, process_g
         for batch in batches:
             if reserve_S and eng._shape is None:
                 S0, B0 = batch["text"].shape[:2]
-                eng._prepare(max(reserve_S, S0), B0)
+                eng.reserve(max(reserve_S, S0), B0)
             eng.iteration(batch)
             last = eng.loss_dict()
             if log:
@@ -619,21 +660,36 @@ class Phase2Engine(GanEngine):
         self._adds = 0
         self._base_add = 0
 
+    def reserve(self, S, B):
+        """size the pass buffers once for batches of up to (S, B): train / valid / test loaders then never re-allocate"""
+        self._cap_S, self._cap_B = max(getattr(self, "_cap_S", 0), S), max(getattr(self, "_cap_B", 0), B)
+
     def _prepare2(self, S, B):
         if self._shape == (S, B):
             return
+        C_ = self.n_classes
+        if self._shape is None or S > self._alloc_S or B > self._alloc_B:
+            cS = self._cap_S = max(getattr(self, "_cap_S", 0), S)
+            cB = self._cap_B = max(getattr(self, "_cap_B", 0), B)
+            self._alloc_S, self._alloc_B = cS, cB
+            dev = self.dev
+            self.pass_G = {k: _Pass(n, cS, cB, dev, True) for k, n in self.G.items()}
+            n_ws = max(p.n_ws for p in self.pass_G.values())
+            f32 = dict(device=dev, dtype=torch.float32)
+            self.ws = torch.empty(n_ws, **f32)
+            self._flat = dict(fusion=torch.empty(cS * cB * 100, **f32), logits=torch.empty(cS * cB * C_, **f32),
+                              log_prob=torch.empty(cS * cB * C_, **f32), dlogits=torch.empty(cS * cB * C_, **f32),
+                              d_fusion=torch.empty(cS * cB * 100, **f32))
+            self.ws2 = torch.zeros(4, **f32)
         self._shape = (S, B)
-        dev, C_ = self.dev, self.n_classes
-        self.pass_G = {k: _Pass(n, S, B, dev, True) for k, n in self.G.items()}
-        n_ws = max(p.n_ws for p in self.pass_G.values())
-        f32 = dict(device=dev, dtype=torch.float32)
-        self.ws = torch.empty(n_ws, **f32)
-        self.fusion = torch.empty(S, B, 100, **f32)
-        self.logits = torch.empty(S, B, C_, **f32)
-        self.log_prob = torch.empty(S, B, C_, **f32)
-        self.dlogits = torch.empty(S, B, C_, **f32)
-        self.d_fusion = torch.empty(S, B, 100, **f32)
-        self.ws2 = torch.zeros(4, **f32)
+        for p_ in self.pass_G.values():
+            p_.resize(S, B)
+        f = self._flat
+        self.fusion = f["fusion"][:S * B * 100].view(S, B, 100)
+        self.logits = f["logits"][:S * B * C_].view(S, B, C_)
+        self.log_prob = f["log_prob"][:S * B * C_].view(S, B, C_)
+        self.dlogits = f["dlogits"][:S * B * C_].view(S, B, C_)
+        self.d_fusion = f["d_fusion"][:S * B * 100].view(S, B, 100)
 
     def step(self, batch, train=True):
         """batch: text/visual/acoustic (S,B,.), umask (B,S) float, label (B,S) int64.  Returns (loss tensor, log_prob).

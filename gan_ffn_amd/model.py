@@ -87,8 +87,9 @@ def _a4(n):
 
 class _Net(nn.Module):
     """Common body of the six networks.  Subclasses set KIND ('gen'|'disc'), D_MODEL (None -> D_h),
-    NHEAD, FC (hidden widths) and HAS_OBJECT."""
+    NHEAD, FC (hidden widths) and HAS_OBJECT (+ OBJECT_IN, the raw-modality width `object` maps to D_h)."""
     KIND, D_MODEL, NHEAD, FC, HAS_OBJECT = "gen", 100, 10, (512,), False
+    OBJECT_IN = 512
 
     def __init__(self, D_h, dropout=0.2, num_layers=N_LAYERS):
         super().__init__()
@@ -107,7 +108,7 @@ class _Net(nn.Module):
                 for k, p in zip(LAYER_KEYS, holder.ordered()):
                     p.copy_(tsd[k])
         if self.HAS_OBJECT:
-            self.object = self._init_linear(512, 100)  # model.py:1344
+            self.object = self._init_linear(self.OBJECT_IN, 100)  # model.py:1344
         dims = [E] + list(self.FC) + ([D_h] if self.KIND == "gen" else [])
         if self.KIND == "disc":
             dims = [E, 64, 16, 1]                       # model.py:1311-1313
@@ -190,7 +191,7 @@ class _Net(nn.Module):
     # ---- forward ---------------------------------------------------------------------------
     def forward(self, x):
         self._ensure_packed()
-        if self.HAS_OBJECT and x.size(-1) == 512:      # model.py:1355-1356
+        if self.HAS_OBJECT and x.size(-1) == self.OBJECT_IN:      # model.py:1355-1356
             x = ops.LinearFn.apply(x, self.object.weight, self.object.bias)
         if x.size(-1) != self.d_model:
             raise ValueError("%s expects last dim %d, got %d" % (type(self).__name__, self.d_model, x.size(-1)))
@@ -231,6 +232,27 @@ class VisualDiscriminator(_Net):    # model.py:1330-1364
 
 class TextDiscriminator(_Net):      # model.py:1367-1397
     KIND, D_MODEL, NHEAD, FC, HAS_OBJECT = "disc", None, 10, (64, 16), False
+
+
+# ---- extension: MELD-dimension generator / discriminator stacks (BASELINE.json configs[2]) -----------------------------
+# The reference has NO GAN path for MELD (train_MELD.py trains MELDLSTMModel on text only).  These are the
+# reference's generic stack (PE -> 8 post-LN encoder layers, 10 heads -> GELU head) instantiated at MELD's feature widths
+# (text 600, train_MELD.py:143; audio 300, dataloader.py:93-95), with the VisualGenerator / VisualDiscriminator recipe:
+# generator head d -> fc -> D_h, discriminator `object` Linear(d -> D_h) applied to the raw modality.
+class MELDTextGenerator(_Net):
+    KIND, D_MODEL, NHEAD, FC, HAS_OBJECT = "gen", 600, 10, (1024,), False
+
+
+class MELDAudioGenerator(_Net):
+    KIND, D_MODEL, NHEAD, FC, HAS_OBJECT = "gen", 300, 10, (512,), False
+
+
+class MELDTextDiscriminator(_Net):
+    KIND, D_MODEL, NHEAD, FC, HAS_OBJECT, OBJECT_IN = "disc", None, 10, (64, 16), True, 600
+
+
+class MELDAudioDiscriminator(_Net):
+    KIND, D_MODEL, NHEAD, FC, HAS_OBJECT, OBJECT_IN = "disc", None, 10, (64, 16), True, 300
 
 
 class MaskedNLLLoss(nn.Module):

@@ -213,12 +213,15 @@ int ganffn_ffn_fused_bwd(const float* dy, const float* w1, const float* w2, cons
  * deferred weight-gradient GEMMs of all encoder layers of a backward pass (dense leading dimensions) */
 int ganffn_gemm_tn_grouped(int n, const float* const* At, const float* const* Bm, float* const* C,
                            float* const* colsum, const int* M, const int* N, const int* K, void* stream);
-/* qkv [T x 3E] -> o [T x E]; site = dropout site id; p = 0 disables dropout */
-int ganffn_attention_fwd(const float* qkv, float* o, int S, int B, int E, int H, float p,
+/* Attention core of nn.MultiheadAttention (call sites model.py:1210,1244,1276,1307,1340,1377):
+ * qkv [T x 3E] -> o [T x E]; site = dropout site id; p = 0 disables dropout.  lse [B*H x S] receives the log-sum-exp of
+ * every score row (may be NULL when no backward follows).  The backward takes the forward's o and lse back (head_dim
+ * <= 32 uses them instead of recomputing the softmax statistics; larger heads ignore them, NULL allowed there). */
+int ganffn_attention_fwd(const float* qkv, float* o, float* lse, int S, int B, int E, int H, float p,
                          uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, void* stream);
-int ganffn_attention_bwd(const float* qkv, const float* d_o, float* d_qkv, int S, int B, int E, int H,
-                         float p, uint32_t site, const uint64_t* rng, uint64_t rng_offset_add,
-                         void* stream);
+int ganffn_attention_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv,
+                         int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng,
+                         uint64_t rng_offset_add, void* stream);
 /* z = x + drop(y); xhat = (z-mean)*rstd; out = xhat*w + b   (norm1/norm2 of the encoder layer) */
 int ganffn_add_dropout_layernorm_fwd(const float* x, const float* y, const float* w, const float* b,
                                      float* out, float* xhat, float* rstd, int T, int E, float eps,

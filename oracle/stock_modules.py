@@ -24,6 +24,12 @@ SPECS = {
     "AcousticDiscriminator": ("disc", None, 10, (64, 16), False),
     "TextDiscriminator": ("disc", None, 10, (64, 16), False),
     "VisualDiscriminator": ("disc", None, 10, (64, 16), True),
+    # extension (no reference GAN path for MELD): the same recipe at MELD's feature widths, text 600 / audio 300
+    # (train_MELD.py:143, dataloader.py:93-95); has_object = the raw-modality width `object` maps to D_h
+    "MELDTextGenerator": ("gen", 600, 10, (1024,), False),
+    "MELDAudioGenerator": ("gen", 300, 10, (512,), False),
+    "MELDTextDiscriminator": ("disc", None, 10, (64, 16), 600),
+    "MELDAudioDiscriminator": ("disc", None, 10, (64, 16), 300),
 }
 
 
@@ -54,8 +60,9 @@ class StockNet(nn.Module):
         self.position_encoding = _PE(d_model)
         self.encoder_layer = nn.TransformerEncoderLayer(d_model=d_model, nhead=nhead)
         self.transformer_encoder = nn.TransformerEncoder(encoder_layer=self.encoder_layer, num_layers=num_layers)
+        self.obj_in = (512 if has_obj is True else int(has_obj)) if has_obj else 0
         if has_obj:
-            self.object = nn.Linear(512, 100)
+            self.object = nn.Linear(self.obj_in, 100)
         if kind == "gen":
             self.fc1 = nn.Linear(d_model, fcs[0])
             self.fc2 = nn.Linear(fcs[0], D_h)
@@ -67,7 +74,7 @@ class StockNet(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x):
-        if hasattr(self, "object") and x.size(-1) == 512:
+        if hasattr(self, "object") and x.size(-1) == self.obj_in:
             x = self.object(x)
         t = self.gelu(self.transformer_encoder(self.position_encoding(x)))
         if self.kind == "gen":
@@ -118,16 +125,20 @@ def stock_gan_iteration(gens, discs, opts, batch, schedule):
     return out
 
 
-def build_stock(D_h=100, dropout=0.2, lr=1e-4, b1=0.5, b2=0.6, num_layers=8):
-    gens = {m: StockNet(n, D_h, dropout, num_layers) for m, n in
-            (("acoustic", "AcousticGenerator"), ("visual", "VisualGenerator"), ("text", "TextGenerator"))}
-    discs = {m: StockNet(n, D_h, dropout, num_layers) for m, n in
-             (("acoustic", "AcousticDiscriminator"), ("visual", "VisualDiscriminator"), ("text", "TextDiscriminator"))}
+IEMOCAP_NETS = {"G": {"acoustic": "AcousticGenerator", "visual": "VisualGenerator", "text": "TextGenerator"},
+                "D": {"acoustic": "AcousticDiscriminator", "visual": "VisualDiscriminator", "text": "TextDiscriminator"}}
+MELD_NETS = {"G": {"acoustic": "MELDAudioGenerator", "text": "MELDTextGenerator"},
+             "D": {"acoustic": "MELDAudioDiscriminator", "text": "MELDTextDiscriminator"}}
+
+
+def build_stock(D_h=100, dropout=0.2, lr=1e-4, b1=0.5, b2=0.6, num_layers=8, nets=None):
+    nets = nets or IEMOCAP_NETS
+    gens = {m: StockNet(n, D_h, dropout, num_layers) for m, n in nets["G"].items()}
+    discs = {m: StockNet(n, D_h, dropout, num_layers) for m, n in nets["D"].items()}
     A = torch.optim.Adam
-    opts = {("G", "acoustic"): A(gens["acoustic"].parameters(), lr=lr, betas=(b1, b2)),
-            ("D", "acoustic"): A(discs["acoustic"].parameters(), lr=lr / 2, betas=(b1, b2)),
-            ("G", "visual"): A(gens["visual"].parameters(), lr=lr, betas=(b1, b2)),
-            ("D", "visual"): A(discs["visual"].parameters(), lr=lr / 2, betas=(b1, b2)),
-            ("G", "text"): A(gens["text"].parameters(), lr=lr * 1.1, betas=(b1, b2)),
-            ("D", "text"): A(discs["text"].parameters(), lr=lr / 2, betas=(b1, b2))}
+    opts = {}
+    for m in gens:          # train_IEMOCAP.py:292-297: G lr, text-G 1.1 lr, every D lr / 2
+        opts[("G", m)] = A(gens[m].parameters(), lr=lr * 1.1 if m == "text" else lr, betas=(b1, b2))
+    for m in discs:
+        opts[("D", m)] = A(discs[m].parameters(), lr=lr / 2, betas=(b1, b2))
     return gens, discs, opts

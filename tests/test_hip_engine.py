@@ -223,3 +223,40 @@ def test_buffers_are_reused_for_shorter_batches():
         assert eng._cap_S == (21 if cap else 13)
     for k in res[None]:
         assert abs(res[None][k] - res[21][k]) < 2e-3, k
+
+
+def test_short_last_batch_keeps_the_reserved_buffers():
+    """real loaders have no drop_last: every epoch ends on a short batch (IEMOCAP: 32, 32, 32, 12).  The step buffers
+    are sized once (reserve) and re-viewed for every (S, B) within that capacity — no allocation, no device sync — and
+    the results equal those of a fresh engine sized exactly for each batch."""
+    from gan_ffn_amd import engine
+    shapes = [(9, 4), (13, 2), (7, 4), (11, 3)]
+    gens, discs = build_all(zero_dropout=True)
+    eng = engine.GanEngine(gens, discs, n_streams=1)
+    eng.reserve(16, 4)
+    got, ptrs = [], None
+    for S, B in shapes:
+        eng.iteration(gan_batch(S=S, B=B))
+        got.append(eng.loss_dict())
+        cur = (eng.pass_G["text"]._saved.data_ptr(), eng.pass_D2["visual"]._saved.data_ptr(), eng._scratch_flat[0]["ws"].data_ptr())
+        assert ptrs is None or cur == ptrs
+        ptrs = cur
+        assert (eng._cap_S, eng._cap_B) == (16, 4) and eng._shape == (S, B)
+    # fresh engines, one per shape, run the same trajectory on exactly-sized buffers
+    gens, discs = build_all(zero_dropout=True)
+    for i, (S, B) in enumerate(shapes):
+        eng2 = engine.GanEngine(gens, discs, n_streams=1)
+        if i > 0:   # carry the optimizer state over (a fresh engine starts Adam at t = 0)
+            for k in eng2.G:
+                for a in ("exp_avg", "exp_avg_sq", "step"):
+                    getattr(eng2.G[k], a).copy_(state["G"][k][a])
+            for k in eng2.D:
+                for a in ("exp_avg", "exp_avg_sq", "step"):
+                    getattr(eng2.D[k], a).copy_(state["D"][k][a])
+        eng2.iteration(gan_batch(S=S, B=B))
+        want = eng2.loss_dict()
+        state = {"G": {k: {a: getattr(n, a).clone() for a in ("exp_avg", "exp_avg_sq", "step")} for k, n in eng2.G.items()},
+                 "D": {k: {a: getattr(n, a).clone() for a in ("exp_avg", "exp_avg_sq", "step")} for k, n in eng2.D.items()}}
+        tol = 5e-5 if i == 0 else 0.15          # later batches: Adam chaos (same bound as GAN_LOSS_TOL[12:])
+        for k in want:
+            assert abs(want[k] - got[i][k]) < tol, (i, k, want[k], got[i][k])

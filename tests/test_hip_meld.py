@@ -1,0 +1,157 @@
+"""BASELINE.json configs[2] on the GPU: the generic generator / discriminator stack at MELD's feature widths (text 600,
+audio 300; 10 heads -> head_dim 60 / 30), labelled "extension — no reference GAN path for MELD" (SURVEY.md §8d).
+HIP modules and the bi-modal step runner against the oracle (which tests/test_meld_cpu.py pins to stock torch at these
+widths), eval mode and train mode with shared Philox masks, up to the full B = 32 batch."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import formula as F_
+from oracle import ganffn_oracle as O
+from util import MELD_DIN, MELD_DISC, MELD_GEN, NETS, _assert_close, formula_sd
+
+pytestmark = pytest.mark.gpu
+
+
+def build(cls_name, zero_dropout=False):
+    from gan_ffn_amd import model
+    m = getattr(model, cls_name)(100, dropout=0.2)
+    missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in formula_sd(cls_name).items()}, strict=False)
+    assert missing.missing_keys == ["position_encoding.pe"] and not missing.unexpected_keys
+    if zero_dropout:
+        m.dropout.p = 0.0
+        m.position_encoding.dropout.p = 0.0
+        m.transformer_encoder.enc_dropout = 0.0
+    return m.cuda()
+
+
+GRAD_KEYS = ("transformer_encoder.layers.0.self_attn.in_proj_weight", "transformer_encoder.layers.7.linear1.weight",
+             "transformer_encoder.layers.4.linear2.bias", "transformer_encoder.layers.2.norm1.weight",
+             "transformer_encoder.layers.5.norm2.bias", "transformer_encoder.layers.3.self_attn.out_proj.weight",
+             "fc1.weight", "fc2.bias")
+
+
+@pytest.mark.parametrize("cls_name,din,S,B,train", [
+    ("MELDTextGenerator", 600, 13, 2, False), ("MELDTextGenerator", 600, 33, 3, True),
+    ("MELDAudioGenerator", 300, 13, 2, False), ("MELDAudioGenerator", 300, 33, 3, True),
+    ("MELDTextDiscriminator", 600, 13, 2, False), ("MELDTextDiscriminator", 100, 33, 4, True),
+    ("MELDAudioDiscriminator", 300, 21, 2, True), ("MELDTextGenerator", 600, 110, 2, False)])
+def test_meld_module_matches_oracle(cls_name, din, S, B, train):
+    """eval mode, and train mode with dropout ON (same (seed, offset) -> identical Philox masks in kernel and oracle)"""
+    from gan_ffn_amd import _lib, ops
+    kind, _, E, H, fcs, has_obj = NETS[cls_name]
+    net = build(cls_name)
+    net = net.train() if train else net.eval()
+    seed = 99173
+    ops.manual_seed(seed)
+    tag = "meldhip.%s.%d.%d" % (cls_name, din, S)
+    x_np = F_.formula_input(tag, S, B, din, pad_from=max(1, S - 4))
+    x = torch.from_numpy(x_np).cuda().requires_grad_(True)
+    y = net(x)
+    gy = torch.from_numpy(F_.formula_input("grad." + tag, S, B, y.shape[-1])) - 0.5
+    (y * gy.cuda()).sum().backward()
+
+    onet = O.OracleNet(kind, formula_sd(cls_name), H, 0.2, torch.float64)
+    xo = torch.from_numpy(x_np).double().requires_grad_(True)
+    xin = xo
+    if has_obj and din == has_obj:
+        xin = xo @ onet.P["object.weight"].T + onet.P["object.bias"]
+    # the oracle takes the ReLU pattern the HIP forward actually took (see tests/test_hip_modules.py)
+    enc_node = y.grad_fn.next_functions[0][0]
+    T_, F_hid = S * B, int(enc_node.cfg.F)
+    masks = []
+    for l in range(8):
+        off = int(_lib.load().ganffn_encoder_saved_hidden_offset(C.byref(enc_node.cfg), l))
+        hsav = enc_node.saved[off:off + T_ * F_hid].view(S, B, F_hid)
+        masks.append((hsav != 0).double().cpu())
+    if not train:
+        masks = None       # eval: no dropped units, the oracle's own relu decides (a kink flip would show below)
+    h = O.encoder_stack(xin, onet.P, H, O.Rng(seed, 0, train), relu_masks=masks)
+    r1 = O.Rng(seed, 1, train)
+    P = onet.P
+    if kind == "gen":
+        t = O._drop(O.gelu(h), 0.2, O.SITE_HEAD0, r1)
+        t = O.gelu(O._drop(t @ P["fc1.weight"].T + P["fc1.bias"], 0.2, O.SITE_HEAD1, r1))
+        yo = O.gelu(O._drop(t @ P["fc2.weight"].T + P["fc2.bias"], 0.2, O.SITE_HEAD2, r1))
+    else:
+        t = O.gelu(h)
+        t = O.gelu(O._drop(t @ P["fc1.weight"].T + P["fc1.bias"], 0.2, O.SITE_HEAD1, r1))
+        t = O.gelu(O._drop(t @ P["fc2.weight"].T + P["fc2.bias"], 0.2, O.SITE_HEAD2, r1))
+        yo = torch.sigmoid(O._drop(t @ P["fc3.weight"].T + P["fc3.bias"], 0.2, O.SITE_HEAD3, r1))
+    (yo * gy.double()).sum().backward()
+    _assert_close(y.detach().cpu().double().numpy(), yo.detach().numpy(), 1e-4, 1e-6, "out", 0.0, 1.0)   # north_star 1e-4
+    _assert_close(x.grad.cpu().double().numpy(), xo.grad.numpy(), 2e-4, 1e-8, "dx")
+    sd = dict(net.named_parameters())
+    keys = GRAD_KEYS + (("object.weight",) if has_obj and din == has_obj else ())
+    for k in keys:
+        _assert_close(sd[k].grad.cpu().double().numpy(), P[k].grad.numpy(), 1e-3, 1e-8, "grad " + k)
+
+
+def _build_all(zero_dropout):
+    gens = {k: build(c, zero_dropout) for k, c in MELD_GEN.items()}
+    discs = {k: build(c, zero_dropout) for k, c in MELD_DISC.items()}
+    return gens, discs
+
+
+def _batch(S, B):
+    return {k: torch.from_numpy(F_.formula_input("meldgan." + k, S, B, d, pad_from=max(1, S - 6))).cuda()
+            for k, d in MELD_DIN.items()}
+
+
+@pytest.mark.parametrize("S,B", [(9, 2), (33, 32)])
+def test_bimodal_engine_matches_oracle_iteration(S, B):
+    """The 4 sub-steps of the bi-modal schedule (dropout p = 0) against the oracle's train_disc / train_gen on the same
+    formula weights and batch — at (33, 32) this is BASELINE.json configs[2]'s full batch.  Losses at 1e-4; every
+    network's first Adam update against the oracle's."""
+    from gan_ffn_amd import engine
+    gens, discs = _build_all(zero_dropout=True)
+    before = {(g_, k): {n: p.detach().cpu().clone() for n, p in m.named_parameters()}
+              for g_, grp in (("G", gens), ("D", discs)) for k, m in grp.items()}
+    eng = engine.GanEngine(gens, discs, n_streams=1)
+    assert eng.schedule == engine.SCHEDULE_BIMODAL
+    batch = _batch(S, B)
+    eng.iteration(batch)
+    got = eng.loss_dict()
+
+    ogens = {k: O.OracleNet("gen", formula_sd(c), 10, 0.0, torch.float64) for k, c in MELD_GEN.items()}
+    odiscs = {k: O.OracleNet("disc", formula_sd(c), 10, 0.0, torch.float64) for k, c in MELD_DISC.items()}
+    opts = O.make_optimizers(ogens, odiscs)
+    ob = {k: v.cpu().double() for k, v in batch.items()}
+    want = O.gan_iteration(ogens, odiscs, opts, ob, None, schedule=engine.SCHEDULE_BIMODAL)
+    for k, v in want.items():
+        assert abs(got[k] - v) < 1e-4, (k, got[k], v)
+    # first update of each network: Adam's first step is ~lr * sign(g); compare the update direction where the
+    # gradient is not within rounding of zero (same policy as tests/test_oracle_golden.check_first_update)
+    for (g_, k), sd0 in before.items():
+        net = (gens if g_ == "G" else discs)[k]
+        onet = (ogens if g_ == "G" else odiscs)[k]
+        lr = 1e-4 * (1.1 if (g_ == "G" and k == "text") else 1.0) * (0.5 if g_ == "D" else 1.0)
+        for n in ("transformer_encoder.layers.7.linear2.weight", "transformer_encoder.layers.0.self_attn.in_proj_weight",
+                  "fc1.weight"):
+            d_hip = (dict(net.named_parameters())[n].detach().cpu() - sd0[n]).double().numpy().reshape(-1)
+            d_ora = (onet.P[n].detach() - torch.from_numpy(formula_sd(MELD_GEN[k] if g_ == "G" else MELD_DISC[k])[n]).double()).numpy().reshape(-1)
+            # t = 1 deltas are ~ +-lr; elements whose gradient is rounding noise may flip sign (outliers), as in
+            # tests/test_oracle_golden.check_first_update
+            bad = np.abs(d_hip - d_ora) > 3e-2 * lr
+            assert bad.mean() < 0.06, (g_, k, n, bad.mean())
+
+
+def test_bimodal_engine_train_mode_full_batch_two_streams():
+    """configs[2] shape (B = 32, S = 33) in train mode on 2 streams: finite, plausible losses; masks advance"""
+    from gan_ffn_amd import engine, ops
+    gens, discs = _build_all(zero_dropout=False)
+    ops.manual_seed(11)
+    eng = engine.GanEngine(gens, discs, n_streams=2)
+    batch = _batch(33, 32)
+    a = eng.iteration(batch).clone()
+    eng.synchronize()
+    torch.cuda.synchronize()
+    a = a.clone()
+    b = eng.iteration(batch)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    assert set(eng.loss_dict()) == {"text_D_loss", "acoustic_G_loss", "acoustic_D_loss", "text_G_loss"}
+    assert torch.isfinite(a).all() and torch.isfinite(b).all() and (a > 0.2).all() and (a < 3.0).all()
+    assert not torch.allclose(a, b)

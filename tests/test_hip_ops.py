@@ -93,7 +93,10 @@ def test_dropout_mask_matches_philox_contract(lib, R, Cn, p):
 
 
 ATTN_CASES = [(7, 2, 100, 10), (110, 3, 100, 10), (94, 4, 512, 8), (33, 2, 100, 10), (1, 1, 100, 10), (64, 2, 512, 8),
-              (32, 1, 100, 10), (96, 2, 100, 10), (97, 1, 512, 8)]
+              (32, 1, 100, 10), (96, 2, 100, 10), (97, 1, 512, 8), (16, 3, 100, 10), (17, 1, 100, 10), (94, 32, 100, 10),
+              (80, 2, 100, 10), (49, 5, 100, 10),
+              # MELD-dimension stacks (BASELINE.json configs[2]): text E = 600 (head_dim 60), audio E = 300 (head_dim 30)
+              (94, 2, 600, 10), (33, 3, 600, 10), (110, 2, 600, 10), (94, 3, 300, 10), (7, 2, 300, 10), (110, 2, 300, 10)]
 
 
 @pytest.mark.parametrize("S,B,E,H", ATTN_CASES)
@@ -116,12 +119,19 @@ def test_attention_fwd_bwd(lib, S, B, E, H, p):
     rng = torch.tensor([seed, off], dtype=torch.int64, device="cuda")
     qd, dod = dev(qkv), dev(do)
     od = torch.full((S, B, E), float("nan"), device="cuda")
-    lib.call("ganffn_attention_fwd", ptr(qd), ptr(od), S, B, E, H, C.c_float(p), C.c_uint32(site), ptr(rng),
+    lse = torch.full((B * H, S), float("nan"), device="cuda")
+    lib.call("ganffn_attention_fwd", ptr(qd), ptr(od), ptr(lse), S, B, E, H, C.c_float(p), C.c_uint32(site), ptr(rng),
              C.c_uint64(add), stream())
     assert rel_err(od, o_ref.detach()) < 2e-5
+    if E // H <= 32:   # small-head kernels keep the log-sum-exp of every (dialogue, head, query) score row
+        hd = E // H
+        q = qkv[..., :E].double().reshape(S, B * H, hd).transpose(0, 1)
+        k = qkv[..., E:2 * E].double().reshape(S, B * H, hd).transpose(0, 1)
+        lse_ref = torch.logsumexp(q @ k.transpose(1, 2) / hd ** 0.5, dim=-1)
+        assert float((lse.double().cpu() - lse_ref).abs().max()) < 2e-5
     dq = torch.full((S, B, 3 * E), float("nan"), device="cuda")
-    lib.call("ganffn_attention_bwd", ptr(qd), ptr(dod), ptr(dq), S, B, E, H, C.c_float(p), C.c_uint32(site), ptr(rng),
-             C.c_uint64(add), stream())
+    lib.call("ganffn_attention_bwd", ptr(qd), ptr(od), ptr(lse), ptr(dod), ptr(dq), S, B, E, H, C.c_float(p),
+             C.c_uint32(site), ptr(rng), C.c_uint64(add), stream())
     assert rel_err(dq, q64.grad) < 5e-5
 
 

@@ -16,7 +16,15 @@ NETS = {
     "AcousticDiscriminator": ("disc", 100, 100, 10, (64, 16, 1), False),
     "TextDiscriminator": ("disc", 100, 100, 10, (64, 16, 1), False),
     "VisualDiscriminator": ("disc", 100, 100, 10, (64, 16, 1), True),
+    # extension: MELD-dimension stacks (BASELINE.json configs[2]); has_object = `object`'s input width
+    "MELDTextGenerator": ("gen", 600, 600, 10, (1024, 100), False),
+    "MELDAudioGenerator": ("gen", 300, 300, 10, (512, 100), False),
+    "MELDTextDiscriminator": ("disc", 100, 100, 10, (64, 16, 1), 600),
+    "MELDAudioDiscriminator": ("disc", 100, 100, 10, (64, 16, 1), 300),
 }
+MELD_GEN = {"acoustic": "MELDAudioGenerator", "text": "MELDTextGenerator"}
+MELD_DISC = {"acoustic": "MELDAudioDiscriminator", "text": "MELDTextDiscriminator"}
+MELD_DIN = {"acoustic": 300, "text": 600}
 GEN = {"acoustic": "AcousticGenerator", "visual": "VisualGenerator", "text": "TextGenerator"}
 DISC = {"acoustic": "AcousticDiscriminator", "visual": "VisualDiscriminator", "text": "TextDiscriminator"}
 DIN = {"acoustic": 100, "visual": 512, "text": 100}
@@ -50,7 +58,7 @@ def state_shapes(cls_name, n_layers=8):
     for l in range(n_layers):
         layer("transformer_encoder.layers.%d." % l)
     if has_obj:
-        sh["object.weight"] = (100, 512)
+        sh["object.weight"] = (100, 512 if has_obj is True else int(has_obj))
         sh["object.bias"] = (100,)
     prev = E
     for i, d in enumerate(fcs):

@@ -28,7 +28,7 @@ for (E, H) in ((100, 10), (512, 8)):
     qkv = torch.randn(S, B, 3 * E, device="cuda"); rng = torch.tensor([1, 2], dtype=torch.int64, device="cuda")
     def att(q):
         o = torch.empty(S, B, E, device="cuda")
-        _lib.call("ganffn_attention_fwd", P(q), P(o), S, B, E, H, C.c_float(0.0), C.c_uint32(16), P(rng), C.c_uint64(0), st)
+        _lib.call("ganffn_attention_fwd", P(q), P(o), None, S, B, E, H, C.c_float(0.0), C.c_uint32(16), P(rng), C.c_uint64(0), st)
         return o
     o1 = att(qkv); o2 = att(qkv[:, perm].contiguous())
     print("attention E=%d differing: %d" % (E, int((o2 != o1[:, perm]).sum())))
