@@ -29,22 +29,30 @@ FP32_MFMA_PEAK = 157.3e12      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_
 FLOP_PER_TOKEN_ITER = 954.3e6
 
 
-def flops_per_token(S):
+def flops_per_token(S, config="iemocap"):
     """reference-equivalent FLOPs per padded token per iteration (fwd + 2x bwd), SURVEY.md §8d formulas."""
     F = 2048
 
     def layer(E):
         return 8 * E * E + 4 * S * E + 4 * E * F
+    D = 8 * layer(100) + 2 * (100 * 64 + 64 * 16 + 16)
+    if config == "meld":
+        # bi-modal schedule (4 sub-steps): per train_disc 2 D fwd + 1 G fwd, 2 D bwd; per train_gen G fwd + D fwd, D bwd + G bwd
+        G600 = 8 * layer(600) + 2 * (600 * 1024 + 1024 * 100)
+        G300 = 8 * layer(300) + 2 * (300 * 512 + 512 * 100)
+        OBJ = 2 * 600 * 100 + 2 * 300 * 100          # one `object` pass of each discriminator per iteration
+        fwd = 6 * D + 2 * G600 + 2 * G300 + OBJ
+        bwd = 2 * (6 * D + G600 + G300 + OBJ)
+        return fwd + bwd
     G100 = 8 * layer(100) + 2 * (100 * 512 + 512 * 100)
     G512 = 8 * layer(512) + 2 * (512 * 1024 + 1024 * 100)
-    D = 8 * layer(100) + 2 * (100 * 64 + 64 * 16 + 16)
     OBJ = 2 * 512 * 100
     fwd = 18 * D + 8 * G100 + 4 * G512 + 2 * OBJ
     bwd = 2 * (18 * D + 4 * G100 + 2 * G512 + 2 * OBJ)
     return fwd + bwd
 
 
-def wgrad_groups(S, B):
+def wgrad_groups(S, B, config="iemocap"):
     """The dominant kernel `gemm_tn_grouped_kernel` = the deferred weight-gradient GEMMs of one encoder backward pass
     (8 layers x {linear2, linear1, out_proj, in_proj}: dW[M x N] += dY^T[M x K] X[K x N], K = tokens, split-K + fp32
     atomics, bias gradients folded in) in one launch.  One iteration issues 6 launches for the discriminators' batched
@@ -53,6 +61,12 @@ def wgrad_groups(S, B):
     T1, T2 = S * B, S * 2 * B
     e100 = [(100, 2048), (2048, 100), (100, 100), (300, 100)]
     e512 = [(512, 2048), (2048, 512), (512, 512), (1536, 512)]
+    if config == "meld":
+        e600 = [(600, 2048), (2048, 600), (600, 600), (1800, 600)]
+        e300 = [(300, 2048), (2048, 300), (300, 300), (900, 300)]
+        return [(2, [(m, n, T2) for _ in range(8) for (m, n) in e100]),
+                (1, [(m, n, T1) for _ in range(8) for (m, n) in e600]),
+                (1, [(m, n, T1) for _ in range(8) for (m, n) in e300])]
     return [(6, [(m, n, T2) for _ in range(8) for (m, n) in e100]),
             (4, [(m, n, T1) for _ in range(8) for (m, n) in e100]),
             (2, [(m, n, T1) for _ in range(8) for (m, n) in e512])]
@@ -61,10 +75,10 @@ def wgrad_groups(S, B):
 TRAFFIC_FILE = "profiles/r01_wgrad_traffic.json"
 
 
-def wgrad_algorithmic_bytes(S, B):
+def wgrad_algorithmic_bytes(S, B, config="iemocap"):
     """average compulsory bytes of one launch: every dY and X operand read once, every dW (and db) written once"""
     tot, n = 0.0, 0
-    for cnt, probs in wgrad_groups(S, B):
+    for cnt, probs in wgrad_groups(S, B, config):
         b = sum(4.0 * (k * m + k * n_ + m * n_ + m) for (m, n_, k) in probs)
         tot += cnt * b
         n += cnt
@@ -84,12 +98,12 @@ def committed_traffic(S, B):
     return None
 
 
-def time_dominant_kernel(S, B, reps=3):
+def time_dominant_kernel(S, B, reps=3, config="iemocap"):
     """Live HIP-event timing, on the stream the kernel is launched on (torch's current stream), of one iteration's
     launches of the dominant kernel (see wgrad_groups), replayed back to back in isolation.
     Returns (average seconds per launch, average algorithmic flops per launch, launches per iteration)."""
     from gan_ffn_amd import _lib, ops
-    groups = wgrad_groups(S, B)
+    groups = wgrad_groups(S, B, config)
     st = ops._stream()
     calls = []
     keep = []
@@ -128,7 +142,7 @@ def time_dominant_kernel(S, B, reps=3):
     return e0.elapsed_time(e1) * 1e-3 / (reps * n), flops, n
 
 
-def cpu_baseline(S, B_sample, threads, dropout=True):
+def cpu_baseline(S, B_sample, threads, dropout=True, config="iemocap"):
     """Stock-PyTorch CPU execution (oracle/stock_modules.py: nn.TransformerEncoder stacks, train-mode dropout,
     the reference's sub-step logic) of ONE full 12-sub-step iteration on a bounded sample: B_sample dialogues of
     the same S.  dropout=False: every dropout probability 0 (the CPU run is dominated by bernoulli_ mask generation,
@@ -139,7 +153,9 @@ def cpu_baseline(S, B_sample, threads, dropout=True):
     from oracle.ganffn_oracle import SCHEDULE
     torch.set_num_threads(threads)
     torch.manual_seed(3407)
-    gens, discs, opts = SM.build_stock()
+    meld = config == "meld"
+    gens, discs, opts = SM.build_stock(nets=SM.MELD_NETS if meld else None)
+    schedule = [s_ for s_ in SCHEDULE if "visual" not in s_[1:]] if meld else SCHEDULE
     if not dropout:
         for m in list(gens.values()) + list(discs.values()):
             for mod in m.modules():
@@ -147,17 +163,40 @@ def cpu_baseline(S, B_sample, threads, dropout=True):
                     mod.p = 0.0
                 if isinstance(mod, torch.nn.MultiheadAttention):
                     mod.dropout = 0.0
-    batch = D.synthetic_batch(B=B_sample, S_max=S, seed=3407, device="cpu")
+    batch = make_batch(config, B_sample, S, 3407, "cpu")
     # tiny warm-up (thread pools, allocator): one D sub-step on 2 dialogues
-    wb = {k: batch[k][:, :2].contiguous() for k in ("text", "visual", "acoustic")}
-    SM.stock_gan_iteration(gens, discs, opts, wb, SCHEDULE[:1])
+    wb = {k: batch[k][:, :2].contiguous() for k in gens}
+    SM.stock_gan_iteration(gens, discs, opts, wb, schedule[:1])
     t0 = time.perf_counter()
-    for i, step in enumerate(SCHEDULE):            # one sub-step at a time so progress is visible
+    for i, step in enumerate(schedule):            # one sub-step at a time so progress is visible
         SM.stock_gan_iteration(gens, discs, opts, batch, [step])
-        print("[bench] cpu_baseline%s sub-step %d/12 done at %.1f s" % ("" if dropout else " (dropout-free)", i + 1, time.perf_counter() - t0), file=sys.stderr, flush=True)
+        print("[bench] cpu_baseline%s sub-step %d/%d done at %.1f s" % ("" if dropout else " (dropout-free)", i + 1, len(schedule), time.perf_counter() - t0), file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
     utts = float(batch["umask"].sum())
     return utts / dt, dt, utts
+
+
+def make_batch(config, B, S, seed, device):
+    """synthetic batch of the named workload (dataset pickles are absent: .MISSING_LARGE_BLOBS)"""
+    from gan_ffn_amd import data as D
+    if config == "meld":
+        # MELD feature widths (text 600, audio 300; no visual), 7 emotion classes (train_MELD.py:139,143)
+        return D.synthetic_batch(B=B, S_max=S, seed=seed, device=device, n_classes=7, dims=D.MELD_DIMS, lo=2, mean=10)
+    return D.synthetic_batch(B=B, S_max=S, seed=seed, device=device)
+
+
+def build_workload(config, dev):
+    """the networks of the named workload, randomly initialised under the reference's seed"""
+    from gan_ffn_amd import engine, model
+    if config == "meld":
+        torch.manual_seed(3407)
+        discs = {"acoustic": model.MELDAudioDiscriminator(100, dropout=0.2), "text": model.MELDTextDiscriminator(100, dropout=0.2)}
+        gens = {"acoustic": model.MELDAudioGenerator(100, dropout=0.2), "text": model.MELDTextGenerator(100, dropout=0.2)}
+        for d in (gens, discs):
+            for k in d:
+                d[k] = d[k].to(dev)
+        return gens, discs
+    return engine.build_networks(device=dev, seed=3407)       # random init of the reference architecture
 
 
 def host_threads():
@@ -183,15 +222,26 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="dialogues per GPU (reference hard-codes 32, train_IEMOCAP.py:603)")
-    ap.add_argument("--seq", type=int, default=94, help="padded dialogue length S (model.py:1437)")
+    ap.add_argument("--seq", type=int, default=None, help="padded dialogue length S (default 94, model.py:1437; "
+                    "--config meld: 33, MELD's longest dialogue [public, not stated by the reference])")
+    ap.add_argument("--config", choices=["iemocap", "meld"], default="iemocap",
+                    help="iemocap = BASELINE.json configs[1] (the headline metric's workload); meld = configs[2], the "
+                         "generic G/D stack at MELD's feature widths on the bi-modal schedule (extension: the reference "
+                         "has no GAN path for MELD)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams running independent sub-steps concurrently")
-    ap.add_argument("--cpu-sample-batch", type=int, default=16)
+    ap.add_argument("--cpu-sample-batch", type=int, default=None,
+                    help="dialogues of the CPU-baseline sample (default: the whole batch, BASELINE.md §3)")
     ap.add_argument("--replay-dominant-only", action="store_true",
                     help="only replay the roofline kernel's launch mix once (the command tools/traffic_pmc.sh profiles "
                          "with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass)")
     args = ap.parse_args()
+    if args.seq is None:
+        args.seq = 33 if args.config == "meld" else 94
+    if args.cpu_sample_batch is None:
+        args.cpu_sample_batch = args.batch
+    cfgname = args.config
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -212,24 +262,22 @@ def main():
 
     from gan_ffn_amd import _lib, engine, ops
     if args.replay_dominant_only:
-        kt, kflop, klaunch = time_dominant_kernel(args.seq, args.batch, reps=1)
+        kt, kflop, klaunch = time_dominant_kernel(args.seq, args.batch, reps=1, config=cfgname)
         print(json.dumps({"avg_kernel_us": kt * 1e6, "launches": klaunch}), flush=True)
         return
     from gan_ffn_amd import data as D
     _lib.load()
-    if os.environ.get("GANFFN_TN_TARGET"):
-        _lib.load().ganffn_debug_set_gemm_cfg(0, int(os.environ["GANFFN_TN_TARGET"]))
     if os.environ.get("GANFFN_FFN_MODE"):
         _lib.load().ganffn_debug_set_ffn_mode(int(os.environ["GANFFN_FFN_MODE"]))
 
-    gens, discs = engine.build_networks(device=dev, seed=3407)       # random init of the reference architecture
+    gens, discs = build_workload(cfgname, dev)
     if pg is not None:
         import torch.distributed as dist
         for d in (gens, discs):
             for m in d.values():
                 dist.broadcast(m.slab, src=0)                        # replicated parameters
     ops.manual_seed(3407 + 1000 * rank, dev)                          # rank-offset dropout streams
-    batch = D.synthetic_batch(B=args.batch, S_max=args.seq, seed=3407 + rank, device=dev)
+    batch = make_batch(cfgname, args.batch, args.seq, 3407 + rank, dev)
     S, B = batch["text"].shape[:2]
     use_graph = (not args.no_graph) and pg is None and args.streams == 1
     eng = engine.GanEngine(gens, discs, process_group=pg, use_graph=use_graph, n_streams=args.streams)
@@ -269,17 +317,23 @@ def main():
               file=sys.stderr, flush=True)
 
     if rank == 0:
-        kt, kflop, klaunch = time_dominant_kernel(S, B)
-        traffic = committed_traffic(S, B)
-        fpt = flops_per_token(S)
+        kt, kflop, klaunch = time_dominant_kernel(S, B, config=cfgname)
+        traffic = committed_traffic(S, B) if cfgname == "iemocap" else None
+        fpt = flops_per_token(S, cfgname)
         step_tflops = fpt * S * B * world * args.steps / dt / 1e12
         out = {
-            "metric": "utterances/sec per GAN train step, IEMOCAP tri-modal",
+            "metric": "utterances/sec per GAN train step, IEMOCAP tri-modal" if cfgname == "iemocap" else
+                      "utterances/sec per GAN train step, MELD-dimension bi-modal (extension: no reference GAN path for MELD)",
             "value": round(value, 2), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "IEMOCAP tri-modal batch=32 fp32 on 1xMI355X, full G+D step "
-                                   "(12 sub-steps: 6 train_disc + 6 train_gen, train-mode dropout, BCE, Adam)",
+            "config": {"workload": ("IEMOCAP tri-modal batch=%d per GPU fp32 on %dxMI355X, full G+D step "
+                                    "(12 sub-steps: 6 train_disc + 6 train_gen, train-mode dropout, BCE, Adam)" % (B, world))
+                       if cfgname == "iemocap" else
+                       ("MELD feature dims (text 600, audio 300; train_MELD.py:143, dataloader.py:93-95), 7-class labels, "
+                        "batch=%d per GPU fp32 on %dxMI355X: generic G/D stacks (E = 600 / 300, 10 heads) on the bi-modal "
+                        "schedule (4 sub-steps: 2 train_disc + 2 train_gen, train-mode dropout, BCE, Adam); EXTENSION — the "
+                        "reference has no GAN path for MELD (SURVEY.md §8d)" % (B, world)),
                        "dialogues_per_gpu": B, "seq_len": S, "real_utterances_per_gpu_batch": float(batch["umask"].sum()),
                        "padded_tokens_per_s": round(S * B * world * args.steps / dt, 1),
                        "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager", "streams": eng.n_streams,
@@ -292,25 +346,26 @@ def main():
                          "frac": round(kflop / kt / FP32_MFMA_PEAK, 4), "traffic": traffic,
                          "traffic_unit": "bytes per launch (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE, separate "
                                          "rocprofv3 --pmc passes: " + TRAFFIC_FILE + ")" if traffic is not None else None,
-                         "algorithmic_bytes_per_launch": round(wgrad_algorithmic_bytes(S, B)),
+                         "algorithmic_bytes_per_launch": round(wgrad_algorithmic_bytes(S, B, cfgname)),
                          "avg_kernel_us": round(kt * 1e6, 2), "avg_gflop_per_launch": round(kflop / 1e9, 4),
                          "how": "HIP events around one iteration's launch mix of this kernel replayed in isolation on the launch stream"},
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = host_threads()
-            cv, cdt, cutts = cpu_baseline(S, args.cpu_sample_batch, threads)
+            cv, cdt, cutts = cpu_baseline(S, args.cpu_sample_batch, threads, config=cfgname)
             out["cpu_baseline"] = {"value": round(cv, 2), "unit": "utterances/s", "cores": threads, "kind": "port",
-                                   "sample": "1 full 12-sub-step iteration, stock PyTorch CPU nn.TransformerEncoder "
-                                             "stacks (oracle/stock_modules.py), train-mode dropout, %d dialogues "
+                                   "sample": "1 full %d-sub-step iteration, stock PyTorch CPU nn.TransformerEncoder "
+                                             "stacks (oracle/stock_modules.py), train-mode dropout, %s%d dialogues "
                                              "padded to S=%d (%d real utterances), %.1f s" %
-                                             (args.cpu_sample_batch, S, int(cutts), cdt)}
+                                             (len(eng.schedule), "the identical batch: " if args.cpu_sample_batch == B else "",
+                                              args.cpu_sample_batch, S, int(cutts), cdt)}
             out["config"]["gpu_over_cpu"] = round(value / cv, 1)
-            cv0, cdt0, _ = cpu_baseline(S, args.cpu_sample_batch, threads, dropout=False)
+            cv0, cdt0, _ = cpu_baseline(S, args.cpu_sample_batch, threads, dropout=False, config=cfgname)
             out["cpu_baseline"]["dropout_free_value"] = round(cv0, 2)     # same sample, every dropout p = 0
             out["cpu_baseline"]["dropout_free_seconds"] = round(cdt0, 1)
             out["config"]["gpu_over_cpu_dropout_free"] = round(value / cv0, 1)
             if threads > 8:       # an 8-thread figure, comparable with the survey's 8-core measurement
-                cv8, cdt8, _ = cpu_baseline(S, max(4, args.cpu_sample_batch // 2), 8)
+                cv8, cdt8, _ = cpu_baseline(S, max(4, args.cpu_sample_batch // 2), 8, config=cfgname)
                 out["cpu_baseline"]["value_8_threads"] = round(cv8, 2)
                 out["cpu_baseline"]["seconds_8_threads"] = round(cdt8, 1)
         print(json.dumps(out), flush=True)

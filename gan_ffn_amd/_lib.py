@@ -40,7 +40,6 @@ SIGNATURES = {
     "ganffn_pe_table": (_I, [_P, _I, _I, _P]),
     "ganffn_encoder_fwd": (_I, [_PE, _P, _P, _P, _P, _P, _P, _P, _U64, _P]),
     "ganffn_encoder_bwd": (_I, [_PE, _I, _I, _P, _P, _P, _P, _P, _P, _U64, _P]),
-    "ganffn_encoder_bwd2": (_I, [_PE, _I, _I, _P, _P, _P, _P, _P, _P, _U64, _P, _P]),
     "ganffn_head_fwd": (_I, [_PH, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _P]),
     "ganffn_head_bwd": (_I, [_PH, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _P]),
     "ganffn_linear_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
@@ -63,7 +62,6 @@ SIGNATURES = {
     "ganffn_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),
     "ganffn_add_dropout_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U32, _P, _U64, _P]),
     "ganffn_add_dropout_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U32, _P, _U64, _P]),
-    "ganffn_debug_set_gemm_cfg": (_I, [_I, _I]),
     "ganffn_general2_attention_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ganffn_general2_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ganffn_debug_set_ffn_mode": (_I, [_I]),

@@ -23,7 +23,7 @@ int launch_disc_tail_fwd(const float* a2, const float* w3, const float* b3, floa
                          const uint64_t* rng, uint64_t add, int train, hipStream_t st);
 int launch_disc_tail_bwd(const float* dprob, const float* prob, const float* a2, const float* u2, const float* w3,
                          float* d_pre2, float* gw3, float* gb3, int T, int D2, float p, const uint64_t* rng, uint64_t add,
-                         int train, hipStream_t st);
+                         int train, hipStream_t st, float* gpart);
 int launch_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int T, int K, int N, hipStream_t st);
 int launch_small_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* gw, float* gb, int T, int K,
                             int N, hipStream_t st);
@@ -96,13 +96,16 @@ static int check_cfg(const ganffn_enc_cfg* c) {
 
 // which FFN passes use the fused kernel: 1 = forward (h saved), 2 = forward (nothing saved), 4 = backward dgrad.
 // Tuning hook ganffn_debug_set_ffn_mode; default chosen from measurements.
-int g_wgrad_grouped = 1;   // deferred + grouped weight-gradient GEMMs (ganffn_debug_set_ffn_mode bit 3 clears it)
 int g_ffn_mode = 0;   // measured neutral at T = 3008/6016 (1.5 / 2.9 workgroups per CU leave SIMDs unevenly loaded); see DESIGN.md
 constexpr int MAX_SPLITS = 16;  // partial-output slabs: fused FFN (16 F splits) / split-K GEMMs (<= 8)
 
+// per LayerNorm backward launch: per-block partial sums of the weight / bias gradient
+static int64_t ln_part_floats(const ganffn_enc_cfg* c) { return (int64_t)ln_bwd_blocks(c->S * c->B) * 2 * c->E; }
+
 static int64_t enc_ws_floats(const ganffn_enc_cfg* c) {
     const int64_t T = (int64_t)c->S * c->B, TE = T * c->E, TF = T * c->F;
-    const int64_t bwd = (int64_t)c->L * (TF + 5 * TE) + (3 + MAX_SPLITS) * TE;   // L x (dh | dyA dyB d_qkv(3)) | dz2 dz1 d_attn | tmp slabs
+    // L x (dh | dyA dyB d_qkv(3)) | dz2 dz1 d_attn | tmp slabs | L x 2 LayerNorm partial-sum blocks
+    const int64_t bwd = (int64_t)c->L * (TF + 5 * TE) + (3 + MAX_SPLITS) * TE + (int64_t)c->L * 2 * ln_part_floats(c);
     const SavedOff s = saved_off(c);
     const int64_t fwd_nosave = 2 * TE + s.per_layer + MAX_SPLITS * TE;   // X ping-pong + one layer's saved set + tmp slabs
     return (bwd > fwd_nosave ? bwd : fwd_nosave) + 64;
@@ -213,35 +216,9 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
 // ------------------------------------------------------------------------------------------
 // encoder stack backward over layers [lo_l, hi_l)
 // ------------------------------------------------------------------------------------------
-// Event pool for the optional second ("aux") stream of the backward pass.  Host-side objects only, created
-// lazily, never destroyed; one set per (thread, layer).  Not used when aux_stream == NULL.
-namespace ganffn {
-struct AuxEvents {
-    hipEvent_t ev[64][5];
-    bool made[64] = {};
-};
-static thread_local AuxEvents g_aux;
-static int aux_events(int l, hipEvent_t** out) {
-    if (!g_aux.made[l]) {
-        for (int k = 0; k < 5; ++k) {
-            hipError_t e = hipEventCreateWithFlags(&g_aux.ev[l][k], hipEventDisableTiming);
-            if (e != hipSuccess) return fail((int)e, "encoder_bwd: hipEventCreate failed: %s", hipGetErrorString(e));
-        }
-        g_aux.made[l] = true;
-    }
-    *out = g_aux.ev[l];
-    return 0;
-}
-#define GF_HIP(expr)                                                                              \
-    do {                                                                                          \
-        hipError_t e__ = (expr);                                                                  \
-        if (e__ != hipSuccess) return fail((int)e__, "%s failed: %s", #expr, hipGetErrorString(e__)); \
-    } while (0)
-}  // namespace ganffn
-
-extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int layer_hi, float* dx, const float* params,
-                                   float* grads, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
-                                   void* stream, void* aux_stream) {
+extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int layer_hi, float* dx, const float* params,
+                                  float* grads, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
+                                  void* stream) {
     GF_TRY(check_cfg(c));
     GF_CHECK_ARG(dx && params && saved && workspace, "encoder_bwd: null pointer");
     GF_CHECK_ARG(0 <= layer_lo && layer_lo < layer_hi && layer_hi <= c->L, "encoder_bwd: bad layer range [%d,%d)", layer_lo, layer_hi);
@@ -250,9 +227,6 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
     const bool drop = c->train && (c->p_pe > 0.f || c->p_enc > 0.f);
     GF_CHECK_ARG(!drop || rng, "encoder_bwd: rng required in train mode");
     hipStream_t st = (hipStream_t)stream;
-    // weight gradients on a second stream: they are off the critical (input-gradient) chain, so they overlap it
-    const bool use_aux = aux_stream != nullptr && aux_stream != stream && grads != nullptr;
-    hipStream_t ax = use_aux ? (hipStream_t)aux_stream : st;
     const int S = c->S, B = c->B, E = c->E, H = c->H, F = c->F, T = S * B;
     const int64_t TE = (int64_t)T * E, TF = (int64_t)T * F;
     const LayerOff lo = layer_off(E, F);
@@ -261,19 +235,22 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
     const float pdrop = (train ? c->p_enc : 0.f);
 
     // Weight gradients are DEFERRED: every layer keeps what its 4 wgrad GEMMs read (dh, dyA, dyB, d_qkv) in its own
-    // buffer set, and one grouped launch at the end of the range computes all of them (4 x layers problems).
-    // With an aux stream instead (legacy mode) two sets by layer parity are enough.
-    const bool grouped = !use_aux && grads != nullptr && g_wgrad_grouped;
-    const int nsets = grouped ? (layer_hi - layer_lo) : 2;
+    // buffer set, and one grouped launch at the end of the range computes all of them (4 x layers problems).  The
+    // LayerNorm weight / bias gradients are reduced the same way: per-block partial sums now, one ordered reduce
+    // launch for the whole range at the end.  Nothing in here uses atomics: gradients are bit-reproducible.
     const int64_t SET = TF + 5 * TE;              // dh | dyA | dyB | d_qkv(3)
     float* set0 = workspace;
     float* dz2 = set0 + (int64_t)c->L * SET;      // [T x E] LN2 input gradient (residual branch into x1)
-    (void)nsets;
-    TnDesc tn[40];
-    int ntn = 0;
     float* dz1 = dz2 + TE;            // [T x E] LN1 input gradient (residual branch into X[l])
     float* d_attn = dz1 + TE;         // [T x E]
     float* tmp = d_attn + TE;         // [MAX_SPLITS][T x E] partial slabs of dh W1
+    float* lnp0 = tmp + (int64_t)MAX_SPLITS * TE;   // [L][2] LayerNorm partial-sum blocks
+    const int64_t LNP = ln_part_floats(c);
+    const int lnblk = ln_bwd_blocks(T);
+    TnDesc tn[40];
+    int ntn = 0;
+    float* r_gw[2 * 64]; float* r_gb[2 * 64]; const float* r_part[2 * 64]; int r_nb[2 * 64];
+    int nred = 0;
 
     for (int l = layer_hi - 1; l >= layer_lo; --l) {
         const float* P = params + (int64_t)l * lo.total;
@@ -281,28 +258,21 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
         const float* sv = saved + so.layers + (int64_t)l * so.per_layer;
         const float* Xl = saved + so.X + (int64_t)l * TE;
         const uint32_t site = SITE_LAYER0 + 4 * l;
-        float* bs = set0 + (int64_t)(grouped ? (l - layer_lo) : (l & 1)) * SET;
+        float* bs = set0 + (int64_t)(l - layer_lo) * SET;
         float* dh = bs;               // [T x F]
         float* dyA = dh + TF;         // [T x E] d(FFN output)
         float* dyB = dyA + TE;        // [T x E] d(attention block output)
         float* d_qkv = dyB + TE;      // [T x 3E]
-        hipEvent_t* ev = nullptr;
-        if (use_aux) {
-            GF_TRY(aux_events(l, &ev));
-            if (l + 2 < layer_hi) {   // this buffer set was last read by the aux stream for layer l+2
-                hipEvent_t* ev2 = nullptr;
-                GF_TRY(aux_events(l + 2, &ev2));
-                GF_HIP(hipStreamWaitEvent(st, ev2[4], 0));
-            }
-        }
+        float* lnp2 = lnp0 + (int64_t)(2 * (l - layer_lo)) * LNP;
+        float* lnp1 = lnp2 + LNP;
         EpiArgs none;
         // LN2 backward: dx = dL/dX[l+1] -> dz2 (to x1), dyA (to FFN output)
         GF_TRY(launch_add_drop_ln_bwd(dx, sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dyA, G ? G + lo.n2w : nullptr,
-                                      G ? G + lo.n2b : nullptr, T, E, c->p_enc, site + 3, rng, add, train, st));
-        if (use_aux) { GF_HIP(hipEventRecord(ev[0], st)); GF_HIP(hipStreamWaitEvent(ax, ev[0], 0)); }
+                                      G ? G + lo.n2b : nullptr, T, E, c->p_enc, site + 3, rng, add, train, st, 1, 0, nullptr,
+                                      G ? lnp2 : nullptr));
+        if (G) { r_gw[nred] = G + lo.n2w; r_gb[nred] = G + lo.n2b; r_part[nred] = lnp2; r_nb[nred] = lnblk; ++nred; }
         // linear2 wgrad: gW2[E,F] += dyA^T h ; gb2 += colsum(dyA)
-        if (G && grouped) tn[ntn++] = TnDesc{dyA, E, sv + so.h, F, G + lo.w2, F, G + lo.b2, E, F, T};
-        else if (G) GF_TRY(launch_gemm_tn_acc(dyA, E, sv + so.h, F, G + lo.w2, F, G + lo.b2, E, F, T, ax));
+        if (G) tn[ntn++] = TnDesc{dyA, E, sv + so.h, F, G + lo.w2, F, G + lo.b2, E, F, T};
         const float mscale = (pdrop > 0.f) ? 1.0f / (1.0f - pdrop) : 1.0f;
         int splits = 1;
         const bool fused = ffn_fused_supported(E, F) && (g_ffn_mode & 4);
@@ -315,31 +285,26 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
             em.mscale = mscale;
             GF_TRY(launch_gemm_nn(dyA, E, P + lo.w2, F, dh, F, T, F, E, EPI_MASK_POS, em, st));
         }
-        if (use_aux) { GF_HIP(hipEventRecord(ev[1], st)); GF_HIP(hipStreamWaitEvent(ax, ev[1], 0)); }
         // linear1 wgrad: gW1[F,E] += dh^T x1 ; gb1 += colsum(dh)
-        if (G && grouped) tn[ntn++] = TnDesc{dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T};
-        else if (G) GF_TRY(launch_gemm_tn_acc(dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T, ax));
+        if (G) tn[ntn++] = TnDesc{dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T};
         if (!fused) {
             // d x1 = dh W1 (split-K slabs) + dz2, consumed directly by the LN1 backward
             splits = gemm_splitk_factor(T, E, F);
             GF_TRY(launch_gemm_nn(dh, F, P + lo.w1, E, tmp, E, T, E, F, EPI_NONE, none, st, &splits, TE));
         }
         GF_TRY(launch_add_drop_ln_bwd(tmp, sv + so.xhat1, sv + so.rstd1, P + lo.n1w, dz1, dyB, G ? G + lo.n1w : nullptr,
-                                      G ? G + lo.n1b : nullptr, T, E, c->p_enc, site + 1, rng, add, train, st, splits, TE, dz2));
-        if (use_aux) { GF_HIP(hipEventRecord(ev[2], st)); GF_HIP(hipStreamWaitEvent(ax, ev[2], 0)); }
+                                      G ? G + lo.n1b : nullptr, T, E, c->p_enc, site + 1, rng, add, train, st, splits, TE, dz2,
+                                      G ? lnp1 : nullptr));
+        if (G) { r_gw[nred] = G + lo.n1w; r_gb[nred] = G + lo.n1b; r_part[nred] = lnp1; r_nb[nred] = lnblk; ++nred; }
         // out-proj wgrad + dgrad
-        if (G && grouped) tn[ntn++] = TnDesc{dyB, E, sv + so.attn_o, E, G + lo.out_w, E, G + lo.out_b, E, E, T};
-        else if (G) GF_TRY(launch_gemm_tn_acc(dyB, E, sv + so.attn_o, E, G + lo.out_w, E, G + lo.out_b, E, E, T, ax));
+        if (G) tn[ntn++] = TnDesc{dyB, E, sv + so.attn_o, E, G + lo.out_w, E, G + lo.out_b, E, E, T};
         GF_TRY(launch_gemm_nn(dyB, E, P + lo.out_w, E, d_attn, E, T, E, E, EPI_NONE, none, st));
         // attention core backward
         GF_TRY(launch_attention_bwd(sv + so.qkv, sv + so.attn_o, sv + so.lse, d_attn, d_qkv, S, B, E, H, c->p_enc, site + 0, rng,
                                     add, train, st));
-        if (use_aux) { GF_HIP(hipEventRecord(ev[3], st)); GF_HIP(hipStreamWaitEvent(ax, ev[3], 0)); }
         // in-proj wgrad + dgrad; dX[l] = d_qkv W_in + dz1
-        if (G && grouped) tn[ntn++] = TnDesc{d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T};
-        else if (G) GF_TRY(launch_gemm_tn_acc(d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T, ax));
-        if (use_aux) GF_HIP(hipEventRecord(ev[4], ax));
-        if (ntn == 40 || (grouped && l == layer_lo && ntn > 0)) {
+        if (G) tn[ntn++] = TnDesc{d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T};
+        if (ntn == 40 || (l == layer_lo && ntn > 0)) {
             GF_TRY(launch_gemm_tn_grouped(tn, ntn, st));
             ntn = 0;
         }
@@ -347,22 +312,9 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
         eadd.aux_in = dz1;            // dX[l] = d_qkv W_in + dz1 (residual) in the GEMM epilogue
         GF_TRY(launch_gemm_nn(d_qkv, 3 * E, P + lo.in_w, E, dx, E, T, E, 3 * E, EPI_NONE, eadd, st));
     }
-    if (use_aux) {
-        // join: every weight gradient of this range is complete before the caller's next operation on `stream`
-        for (int l = layer_lo; l < layer_hi && l < layer_lo + 2; ++l) {
-            hipEvent_t* ev = nullptr;
-            GF_TRY(aux_events(l, &ev));
-            GF_HIP(hipStreamWaitEvent(st, ev[4], 0));
-        }
-    }
+    if (nred > 0) GF_TRY(launch_ln_param_reduce(nred, r_gw, r_gb, r_part, r_nb, E, st));
     if (layer_lo == 0) GF_TRY(launch_dropout_bwd_inplace(dx, T, E, c->p_pe, SITE_PE, rng, add, train, st));
     return 0;
-}
-
-extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int layer_hi, float* dx, const float* params,
-                                  float* grads, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
-                                  void* stream) {
-    return ganffn_encoder_bwd2(c, layer_lo, layer_hi, dx, params, grads, saved, workspace, rng, add, stream, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -386,10 +338,15 @@ extern "C" int64_t ganffn_head_saved_floats(const ganffn_head_cfg* c) {
     if (c->kind == 1) n += T * c->D2 + T4;
     return n;
 }
+// workspace of the head backward: d_pre1 [T x D1] | d_pre2 [T x D2] | split-K partial slabs of the two weight-gradient
+// GEMMs | per-block partial sums of the discriminator tail
+static int64_t a4(int64_t n) { return (n + 3) & ~int64_t(3); }
+static int64_t head_part2(const ganffn_head_cfg* c) { return a4(gemm_tn_part_floats(c->D2, c->D1, c->T)); }
+static int64_t head_part1(const ganffn_head_cfg* c) { return a4(gemm_tn_part_floats(c->D1, c->E, c->T)); }
 extern "C" int64_t ganffn_head_workspace_floats(const ganffn_head_cfg* c) {
     if (check_head(c) != 0) return -1;
     const int64_t T = c->T;
-    return T * c->D1 + T * c->D2 + T * c->E + 64;  // d_pre1 | d_pre2 | spare
+    return a4(T * c->D1) + a4(T * c->D2) + head_part2(c) + head_part1(c) + ((T + 255) / 256) * 36 + 64;
 }
 
 extern "C" int ganffn_head_fwd(const ganffn_head_cfg* c, const float* x, const float* w1, const float* b1, const float* w2,
@@ -435,6 +392,7 @@ extern "C" int ganffn_head_bwd(const ganffn_head_cfg* c, const float* d_out, con
                                void* stream) {
     GF_TRY(check_head(c));
     GF_CHECK_ARG(d_out && x && w1 && w2 && dx && saved && workspace, "head_bwd: null pointer");
+    GF_CHECK_ARG(aligned16(workspace), "head_bwd: workspace must be 16-byte aligned");
     GF_CHECK_ARG(c->kind == 0 || w3, "head_bwd: disc needs fc3");
     GF_CHECK_ARG(!(c->train && c->p > 0.f) || rng, "head_bwd: rng required in train mode");
     hipStream_t st = (hipStream_t)stream;
@@ -444,21 +402,24 @@ extern "C" int ganffn_head_bwd(const ganffn_head_cfg* c, const float* d_out, con
     const float* a1 = u1 + (int64_t)T * D1;
     const float* u2 = a1 + (int64_t)T * D1;
     float* d_pre1 = workspace;                       // [T x D1]
-    float* d_pre2 = d_pre1 + (int64_t)T * D1;        // [T x D2]
+    float* d_pre2 = d_pre1 + a4((int64_t)T * D1);    // [T x D2]
+    float* part2 = d_pre2 + a4((int64_t)T * D2);     // split-K slabs of gw2
+    float* part1 = part2 + head_part2(c);            // split-K slabs of gw1
+    float* tailp = part1 + head_part1(c);            // discriminator tail: per-block sums
     if (c->kind == 0) {
         // d_pre2 = d_out * gelu'(u2) * m2
         GF_TRY(launch_gelu_bwd_drop(d_out, u2, d_pre2, T, D2, c->p, SITE_HEAD2, rng, add, train, st));
     } else {
         const float* a2 = u2 + (int64_t)T * D2;
         const float* prob = a2 + (int64_t)T * D2;
-        GF_TRY(launch_disc_tail_bwd(d_out, prob, a2, u2, w3, d_pre2, gw3, gb3, T, D2, c->p, rng, add, train, st));
+        GF_TRY(launch_disc_tail_bwd(d_out, prob, a2, u2, w3, d_pre2, gw3, gb3, T, D2, c->p, rng, add, train, st, tailp));
     }
-    if (gw2) GF_TRY(launch_gemm_tn_acc(d_pre2, D2, a1, D1, gw2, D1, gb2, D2, D1, T, st));
+    if (gw2) GF_TRY(launch_gemm_tn_acc(d_pre2, D2, a1, D1, gw2, D1, gb2, D2, D1, T, st, part2, head_part2(c)));
     EpiArgs e;
     e.p = c->p; e.rng = rng; e.rng_add = add; e.train = train;
     e.aux_in = u1; e.site = SITE_HEAD1;
     GF_TRY(launch_gemm_nn(d_pre2, D2, w2, D1, d_pre1, D1, T, D1, D2, EPI_GELU_BWD_DROP, e, st));
-    if (gw1) GF_TRY(launch_gemm_tn_acc(d_pre1, D1, s0, E, gw1, E, gb1, D1, E, T, st));
+    if (gw1) GF_TRY(launch_gemm_tn_acc(d_pre1, D1, s0, E, gw1, E, gb1, D1, E, T, st, part1, head_part1(c)));
     e.aux_in = x;
     if (c->kind == 0) {
         e.site = SITE_HEAD0;
@@ -523,7 +484,6 @@ extern "C" int ganffn_ffn_linear1_fwd(const float* x, const float* w1, const flo
 }
 extern "C" int ganffn_debug_set_ffn_mode(int bits) {
     g_ffn_mode = bits & 7;
-    g_wgrad_grouped = (bits & 8) ? 0 : 1;
     return 0;
 }
 extern "C" int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h,

@@ -197,9 +197,12 @@ int gemm_splitk_factor(int M, int N, int K);
 // C[MxN] = A[MxK] * B[KxN] (NN)
 int launch_gemm_nn(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
                    int epi, const EpiArgs& ea, hipStream_t st, int* splits_io = nullptr, long slab_stride = 0);
-// C[MxN] += At[KxM]^T * B[KxN]  (TN, split-K, atomic accumulate); colsum[M] += sum_k At[k][m]
+// C[MxN] += At[KxM]^T * B[KxN]  (TN); colsum[M] += sum_k At[k][m].  Deterministic: with a partial-slab workspace
+// (gemm_tn_part_floats floats) the token range is split over workgroups and reduced in split order, without one a
+// single workgroup per output tile runs the whole range.  No atomics.
+long gemm_tn_part_floats(int M, int N, int K);
 int launch_gemm_tn_acc(const float* At, int lda, const float* Bm, int ldb, float* C, int ldc, float* colsum,
-                       int M, int N, int K, hipStream_t st);
+                       int M, int N, int K, hipStream_t st, float* part_ws = nullptr, long part_floats = 0);
 
 // fused feed-forward block (ffn.hip), d_model = 100 only
 bool ffn_fused_supported(int E, int F);
@@ -243,10 +246,15 @@ int launch_dropout(const float* x, float* out, int R, int C, float p, uint32_t s
 int launch_add_drop_ln_fwd(const float* x, const float* y, const float* w, const float* b, float* out, float* xhat,
                            float* rstd, int T, int E, float eps, float p, uint32_t site, const uint64_t* rng,
                            uint64_t add, int train, hipStream_t st, int nslab = 1, long slab_stride = 0);
+// gw / gb: per-block partial sums go to gpart (ln_bwd_blocks(T) * 2 * E floats), to be added by launch_ln_param_reduce;
+// gpart == NULL runs one workgroup that adds its sums directly.  No atomics either way.
+int ln_bwd_blocks(int T);
 int launch_add_drop_ln_bwd(const float* d_out, const float* xhat, const float* rstd, const float* w, float* dz,
                            float* dy, float* gw, float* gb, int T, int E, float p, uint32_t site,
                            const uint64_t* rng, uint64_t add, int train, hipStream_t st, int nslab = 1,
-                           long slab_stride = 0, const float* addend = nullptr);
+                           long slab_stride = 0, const float* addend = nullptr, float* gpart = nullptr);
+int launch_ln_param_reduce(int n, float* const* gw, float* const* gb, const float* const* part, const int* nblk, int E,
+                           hipStream_t st);
 int launch_add_inplace(float* a, const float* b, int64_t n, hipStream_t st);
 int launch_gelu_drop_fwd(const float* x, float* out, int R, int C, float p, uint32_t site, const uint64_t* rng,
                          uint64_t add, int train, hipStream_t st);

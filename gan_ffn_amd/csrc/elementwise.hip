@@ -174,7 +174,9 @@ __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __res
 }
 
 // backward: g = d_out * w; dz = rstd * (g - mean(g) - xhat * mean(g * xhat)); dy = dz * dropmult
-// gw += sum_t d_out * xhat, gb += sum_t d_out   (per-block partial sums in registers -> LDS -> atomics)
+// gw += sum_t d_out * xhat, gb += sum_t d_out: per-block partial sums (registers -> LDS) are STORED to
+// gpart[block][{w, b}][E] and summed in block order by ln_param_reduce_kernel — no atomics, so the parameter gradients do
+// not depend on the order workgroups run in.  A one-block launch (gpart == nullptr) adds its sums directly.
 template <int NC, int NSB>
 __global__ __launch_bounds__(256) void add_drop_ln_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ xhat,
                                                               const float* __restrict__ rstd, const float* __restrict__ w,
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void add_drop_ln_bwd_kernel(const float* __res
                                                               float* __restrict__ gw, float* __restrict__ gb, int T, int E,
                                                               float p, uint32_t site, const uint64_t* __restrict__ rng,
                                                               uint64_t add, int train, int nslab, long slab_stride,
-                                                              const float* __restrict__ addend) {
+                                                              const float* __restrict__ addend, float* __restrict__ gpart) {
     __shared__ float red[2][4][64 * NC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const DropCtx dc = make_drop(rng, add, site, p, train);
@@ -283,9 +285,37 @@ __global__ __launch_bounds__(256) void add_drop_ln_bwd_kernel(const float* __res
     for (int c = threadIdx.x; c < E; c += 256) {
         const float sw = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
         const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-        atomicAdd(gw + c, sw);
-        atomicAdd(gb + c, sb);
+        if (gpart != nullptr) {
+            gpart[((size_t)blockIdx.x * 2 + 0) * E + c] = sw;
+            gpart[((size_t)blockIdx.x * 2 + 1) * E + c] = sb;
+        } else {               // gridDim.x == 1 (launcher's rule): this block owns the sums
+            gw[c] += sw;
+            gb[c] += sb;
+        }
     }
+}
+
+// gw[c] += sum_b part[b][0][c], gb[c] += sum_b part[b][1][c] for up to LN_RED_MAX LayerNorm instances per launch
+// (blockIdx.y = instance), partials added in block order
+constexpr int LN_RED_MAX = 32;
+struct LnRedGroup {
+    float* gw[LN_RED_MAX];
+    float* gb[LN_RED_MAX];
+    const float* part[LN_RED_MAX];
+    int nblk[LN_RED_MAX];
+};
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(LnRedGroup grp, int E) {
+    const int j = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= E) return;
+    const float* p = grp.part[j];
+    const int nb = grp.nblk[j];
+    float sw = 0.f, sb = 0.f;
+    for (int b = 0; b < nb; ++b) {
+        sw += p[((size_t)b * 2 + 0) * E + c];
+        sb += p[((size_t)b * 2 + 1) * E + c];
+    }
+    grp.gw[j][c] += sw;
+    grp.gb[j][c] += sb;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -311,7 +341,7 @@ __global__ __launch_bounds__(256) void disc_tail_bwd_kernel(const float* __restr
                                                             const float* __restrict__ w3, float* __restrict__ d_pre2,
                                                             float* __restrict__ gw3, float* __restrict__ gb3, int T, int D2,
                                                             float p, const uint64_t* __restrict__ rng, uint64_t add,
-                                                            int train) {
+                                                            int train, float* __restrict__ gpart) {
     __shared__ float red[4][33];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -338,9 +368,18 @@ __global__ __launch_bounds__(256) void disc_tail_bwd_kernel(const float* __restr
         const float s = wave_sum(dpre3);
         if (lane == 0) red[wv][32] = s;
         __syncthreads();
-        if (threadIdx.x < D2) atomicAdd(gw3 + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
-        if (threadIdx.x == 32) atomicAdd(gb3, red[0][32] + red[1][32] + red[2][32] + red[3][32]);
+        // per-block sums -> gpart[block][0..D2-1 | 32]; disc_tail_reduce_kernel adds them in block order (no atomics)
+        if (threadIdx.x < D2) gpart[blockIdx.x * 36 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (threadIdx.x == 32) gpart[blockIdx.x * 36 + 32] = red[0][32] + red[1][32] + red[2][32] + red[3][32];
     }
+}
+__global__ void disc_tail_reduce_kernel(const float* __restrict__ gpart, int nblk, int D2, float* __restrict__ gw3,
+                                        float* __restrict__ gb3) {
+    const int k = threadIdx.x;
+    if (k >= D2 && k != 32) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += gpart[b * 36 + k];
+    if (k == 32) gb3[0] += s; else gw3[k] += s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -349,11 +388,14 @@ __global__ __launch_bounds__(256) void disc_tail_bwd_kernel(const float* __restr
 // target of element i: (i % period) < split ? target : target_b   (period 0: constant `target`).
 // The batched discriminator pass holds [real | fake] dialogues side by side in the batch axis, so one
 // call with period 2B, split B yields (BCE(real,1) + BCE(fake,0)) / 2 = the D loss (train_IEMOCAP.py:220-223).
-__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ prob, float target_a, float target_b,
-                                                      int period, int split, int n, float scale, float* __restrict__ loss) {
-    __shared__ float red[4];
+// ONE workgroup of 1024 threads: the mean is a fixed-order tree (lane strides, wave shuffles, 16 wave sums in order), so the
+// loss value is bit-reproducible; n = S*B (<= a few 10^4) makes a wider grid pointless.
+__global__ __launch_bounds__(1024) void bce_fwd_kernel(const float* __restrict__ prob, float target_a, float target_b,
+                                                       int period, int split, int n, float scale, float* __restrict__ loss,
+                                                       int accumulate) {
+    __shared__ float red[16];
     float s = 0.f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (int i = threadIdx.x; i < n; i += 1024) {
         const float target = (period > 0 && (i % period) >= split) ? target_b : target_a;
         const float p = prob[i];
         const float lp = fmaxf(logf(p), -100.f);
@@ -363,7 +405,12 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ 
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * scale / (float)n);
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        t = t * scale / (float)n;
+        loss[0] = accumulate ? loss[0] + t : t;
+    }
 }
 
 __global__ void bce_bwd_kernel(const float* __restrict__ prob, float target_a, float target_b, int period, int split, int n,
@@ -439,12 +486,15 @@ __global__ void pe_table_kernel(float* __restrict__ pe, int max_len, int E) {
 // A11: log_softmax over C classes + masked weighted NLL   (model.py:1448-1449, :74-81)
 // acc2[0] += sum w[y] m lp[y] ; acc2[1] += sum w[y] m   then a finishing kernel divides
 // ------------------------------------------------------------------------------------------
-__global__ void logsoftmax_nll_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                      const float* __restrict__ umask, const float* __restrict__ cw,
-                                      float* __restrict__ logp, float* __restrict__ acc2, int S, int B, int C) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;  // token t = s*B + b
+// ONE workgroup of 1024 threads striding over the tokens: the two loss sums are fixed-order trees (bit-reproducible); the
+// work (S*B tokens x C <= 7 classes) is far too small for a wider grid to matter.
+__global__ __launch_bounds__(1024) void logsoftmax_nll_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                              const float* __restrict__ umask, const float* __restrict__ cw,
+                                                              float* __restrict__ logp, float* __restrict__ acc2, int S, int B,
+                                                              int C) {
+    __shared__ float red[2][16];
     float num = 0.f, den = 0.f;
-    if (t < S * B) {
+    for (int t = threadIdx.x; t < S * B; t += 1024) {      // token t = s*B + b
         const int s = t / B, b = t - s * B;
         const float* x = logits + (size_t)t * C;
         float m = x[0];
@@ -457,16 +507,23 @@ __global__ void logsoftmax_nll_kernel(const float* __restrict__ logits, const in
             const int y = (int)labels[(size_t)b * S + s];
             const float mk = umask[(size_t)b * S + s];
             const float wy = cw ? cw[y] : 1.f;
-            num = wy * mk * (x[y] - lse);
-            den = wy * mk;
+            num += wy * mk * (x[y] - lse);
+            den += wy * mk;
         }
     }
     if (labels) {
         num = wave_sum(num);
         den = wave_sum(den);
         if ((threadIdx.x & 63) == 0) {
-            atomicAdd(acc2, num);
-            atomicAdd(acc2 + 1, den);
+            red[0][threadIdx.x >> 6] = num;
+            red[1][threadIdx.x >> 6] = den;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float a = 0.f, b = 0.f;
+            for (int w = 0; w < 16; ++w) { a += red[0][w]; b += red[1][w]; }
+            acc2[0] = a;
+            acc2[1] = b;
         }
     }
 }
@@ -592,19 +649,27 @@ int launch_add_drop_ln_fwd(const float* x, const float* y, const float* w, const
     return 0;
 }
 
+int ln_bwd_blocks(int T) {
+    int blocks = ((T + 3) / 4 + 3) / 4;
+    return blocks > 256 ? 256 : blocks;
+}
+
+// gw / gb (when non-NULL): with a partial buffer gpart (>= ln_bwd_blocks(T) * 2 * E floats) the launch is full-width and
+// the caller must run launch_ln_param_reduce afterwards; without one a single workgroup does the whole tensor and adds
+// its sums directly (unit-test hook; still deterministic).
 int launch_add_drop_ln_bwd(const float* d_out, const float* xhat, const float* rstd, const float* w, float* dz,
                            float* dy, float* gw, float* gb, int T, int E, float p, uint32_t site,
                            const uint64_t* rng, uint64_t add, int train, hipStream_t st, int nslab, long slab_stride,
-                           const float* addend) {
+                           const float* addend, float* gpart) {
     GF_CHECK_ARG(E <= 64 * LN_MAXC, "layernorm: E=%d > %d", E, 64 * LN_MAXC);
     GF_CHECK_ARG(nslab >= 1 && nslab <= LN_MAXSLAB, "layernorm: nslab=%d out of [1,%d]", nslab, LN_MAXSLAB);
-    const int G = (T + 3) / 4;
-    int blocks = (G + 3) / 4;
-    if (blocks > 256) blocks = 256;
+    int blocks = ln_bwd_blocks(T);
+    if (gw != nullptr && gpart == nullptr) blocks = 1;
+    if (gw == nullptr) gpart = nullptr;
     const dim3 grid(blocks), blk(256);
 #define GF_LN_BWD(NC, NSB)                                                                                            \
     hipLaunchKernelGGL((add_drop_ln_bwd_kernel<NC, NSB>), grid, blk, 0, st, d_out, xhat, rstd, w, dz, dy, gw, gb, T, \
-                       E, p, site, rng, add, train, nslab, slab_stride, addend)
+                       E, p, site, rng, add, train, nslab, slab_stride, addend, gpart)
     if (E <= 64) GF_LN_BWD(1, 8);
     else if (E <= 128) GF_LN_BWD(2, 8);
     else if (E <= 256) GF_LN_BWD(4, 4);
@@ -616,19 +681,41 @@ int launch_add_drop_ln_bwd(const float* d_out, const float* xhat, const float* r
     return 0;
 }
 
+// add the per-block partial sums of n LayerNorm backward launches (gw[i], gb[i] += sum over nblk[i] blocks of part[i])
+int launch_ln_param_reduce(int n, float* const* gw, float* const* gb, const float* const* part, const int* nblk, int E,
+                           hipStream_t st) {
+    for (int i0 = 0; i0 < n; i0 += LN_RED_MAX) {
+        LnRedGroup grp;
+        const int m = n - i0 < LN_RED_MAX ? n - i0 : LN_RED_MAX;
+        for (int i = 0; i < m; ++i) {
+            grp.gw[i] = gw[i0 + i]; grp.gb[i] = gb[i0 + i]; grp.part[i] = part[i0 + i]; grp.nblk[i] = nblk[i0 + i];
+        }
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((E + 255) / 256, m), dim3(256), 0, st, grp, E);
+        GF_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 int launch_disc_tail_fwd(const float* a2, const float* w3, const float* b3, float* prob, int T, int D2, float p,
                          const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
     hipLaunchKernelGGL(disc_tail_fwd_kernel, dim3(nblk(T, 256)), dim3(256), 0, st, a2, w3, b3, prob, T, D2, p, rng, add, train);
     GF_LAUNCH_CHECK();
     return 0;
 }
+// gpart: nblk(T, 256) * 36 floats of per-block partial sums (required when gw3 != NULL)
 int launch_disc_tail_bwd(const float* dprob, const float* prob, const float* a2, const float* u2, const float* w3,
                          float* d_pre2, float* gw3, float* gb3, int T, int D2, float p, const uint64_t* rng, uint64_t add,
-                         int train, hipStream_t st) {
+                         int train, hipStream_t st, float* gpart) {
     GF_CHECK_ARG(D2 <= 32, "disc tail: D2=%d > 32", D2);
-    hipLaunchKernelGGL(disc_tail_bwd_kernel, dim3(nblk(T, 256)), dim3(256), 0, st, dprob, prob, a2, u2, w3, d_pre2, gw3, gb3, T,
-                       D2, p, rng, add, train);
+    GF_CHECK_ARG(gw3 == nullptr || (gpart != nullptr && gb3 != nullptr), "disc tail: fc3 gradients need gb3 and the partial-sum workspace");
+    const int nb = nblk(T, 256);
+    hipLaunchKernelGGL(disc_tail_bwd_kernel, dim3(nb), dim3(256), 0, st, dprob, prob, a2, u2, w3, d_pre2, gw3, gb3, T,
+                       D2, p, rng, add, train, gpart);
     GF_LAUNCH_CHECK();
+    if (gw3 != nullptr) {
+        hipLaunchKernelGGL(disc_tail_reduce_kernel, dim3(1), dim3(64), 0, st, (const float*)gpart, nb, D2, gw3, gb3);
+        GF_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -684,13 +771,8 @@ extern "C" int ganffn_bce2_fwd(const float* prob, float target_a, float target_b
                                float* loss_out, int accumulate, void* stream) {
     GF_CHECK_ARG(prob && loss_out && n > 0 && period >= 0 && split >= 0, "bce_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (!accumulate) {
-        hipError_t e = hipMemsetAsync(loss_out, 0, sizeof(float), st);
-        if (e != hipSuccess) return fail((int)e, "bce_fwd: memset failed: %s", hipGetErrorString(e));
-    }
-    int blocks = (n + 255) / 256;
-    if (blocks > 64) blocks = 64;
-    hipLaunchKernelGGL(bce_fwd_kernel, dim3(blocks), dim3(256), 0, st, prob, target_a, target_b, period, split, n, scale, loss_out);
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(1024), 0, st, prob, target_a, target_b, period, split, n, scale, loss_out,
+                       accumulate);
     GF_LAUNCH_CHECK();
     return 0;
 }
@@ -740,11 +822,7 @@ extern "C" int ganffn_logsoftmax_nll(const float* logits, const int64_t* labels,
     GF_CHECK_ARG(!labels || (umask && loss_out && workspace2), "logsoftmax_nll: labels need umask, loss_out, workspace2");
     hipStream_t st = (hipStream_t)stream;
     const int T = S * B;
-    if (labels) {
-        hipError_t e = hipMemsetAsync(workspace2, 0, 2 * sizeof(float), st);
-        if (e != hipSuccess) return fail((int)e, "logsoftmax_nll: memset failed");
-    }
-    hipLaunchKernelGGL(logsoftmax_nll_kernel, dim3((T + 255) / 256), dim3(256), 0, st, logits, labels, umask, class_w, log_prob,
+    hipLaunchKernelGGL(logsoftmax_nll_kernel, dim3(1), dim3(1024), 0, st, logits, labels, umask, class_w, log_prob,
                        workspace2, S, B, C);
     GF_LAUNCH_CHECK();
     if (labels) {
@@ -780,5 +858,5 @@ extern "C" int ganffn_add_dropout_layernorm_bwd(const float* d_out, const float*
     GF_CHECK_ARG(d_out && xhat && rstd && w && dz && T > 0 && E > 0, "add_dropout_layernorm_bwd: bad arguments");
     GF_CHECK_ARG(p <= 0.f || rng, "add_dropout_layernorm_bwd: rng required");
     return launch_add_drop_ln_bwd(d_out, xhat, rstd, w, dz, dy, gw, gb, T, E, p, site, rng, rng_offset_add, 1,
-                                  (hipStream_t)stream);
+                                  (hipStream_t)stream, 1, 0, nullptr, nullptr);
 }

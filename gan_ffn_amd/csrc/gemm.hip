@@ -5,19 +5,21 @@
 // /root/reference/model.py:1210-1216,1244-1249,1307-1313):
 //   NT  C[MxN]  = A[MxK] * W[NxK]^T          forward  (A, W both K-contiguous)
 //   NN  C[MxN]  = A[MxK] * B[KxN]            dgrad    (B N-contiguous)
-//   TN  C[MxN] += At[KxM]^T * B[KxN]         wgrad    (both K-major), split-K + fp32 atomics
+//   TN  C[MxN] += At[KxM]^T * B[KxN]         wgrad    (both K-major); deterministic: one owner workgroup per output
+//                                                      tile adds in place, or (split-K) partial slabs + an ordered reduce
 //
 // Numerics: v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain in k order (no reduced precision).
 //
-// Tiling: 256 threads = 4 waves (2 x 2); block tile BM x BN in {64, 128}^2, BK = 16; each wave owns
-// (BM/2) x (BN/2) = TM x TN tiles of 32x32 (16 accumulator VGPRs each).  LDS images:
-//   K-contiguous operand: [rows][20] floats — row stride 20 (= 4 * odd) makes the ds_read_b128
-//     fragment reads (lane (r,h) -> row r, k = kk + 4h .. 4h+3) bank-conflict-free;
+// Tiling: 256 threads = 4 waves (2 x 2); block tile 64 x 64, BK = 16; each wave owns one 32x32 tile (16 accumulator
+// VGPRs).  LDS images:
+//   K-contiguous operand: [rows][BK] floats, unpadded, 16-byte slots XOR-swizzled by the row (kc_off below): the
+//     loaders' ds_write_b128 and the ds_read_b128 fragment reads (lane (r,h) -> row r, k = kk + 4h .. 4h+3) are both
+//     bank-conflict-free;
 //   K-major operand:      [16][cols + 4] — lanes read consecutive columns with ds_read_b32.
 // The k index inside an 8-wide group is permuted identically for A and B (MFMA j of the group takes
 // k = kk + 4h + j on lane half h), which is all an MFMA needs.
-// Global->LDS staging is register-staged and double-buffered: the loads of tile t+1 are issued before
-// the MFMAs of tile t and written to the other LDS buffer after them; one barrier per K tile.
+// Global->LDS staging goes through a register prefetch queue (2-4 tiles deep) into two LDS stages: the loads of tile
+// t+PD are issued before the MFMAs of tile t, tile t+1 is written to the other stage after them; one barrier per K tile.
 #include "common.h"
 
 #include <type_traits>
@@ -39,6 +41,11 @@ struct GemmArgs {
     int kchunk;  // split-K chunk (multiple of 64); K when not split
     long slab_stride;  // NT/NN split-K: split z writes its partial product to C + z*slab_stride (plain stores)
     EpiArgs ea;
+    // TN split-K (deterministic): split z stores its partial dW to part + z*part_stride ([M x N] dense, then [M] column
+    // sums); a reduce kernel adds the slabs to C / colsum in split order.  part == nullptr: the launch is not split and
+    // the single owner workgroup of a tile adds its result to C in place (no atomics either way).
+    float* part = nullptr;
+    long part_stride = 0;
 };
 
 // Operand tile loaders.  Every global load is UNCONDITIONAL and comes from a clamped (always valid) address:
@@ -355,15 +362,30 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 
     // ---------------- epilogue ----------------
     if (MODE == MODE_TN) {
+        // No atomics: an output tile has ONE owner per K split.  Unsplit (part == nullptr) the owner adds in place
+        // (the gradient slab is accumulated into, +=); split, it stores a partial slab that tn_reduce_kernel sums
+        // in split order.  Either way the result does not depend on the order workgroups run in.
+        float* const slab = g.part ? g.part + (size_t)bz * g.part_stride : nullptr;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
                 const int col = n0 + wn * WN + b * 32 + r;
+                float old[16];
+                if (!slab) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = min(m0 + wm * WM + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, g.M - 1);
+                        old[i] = g.C[(size_t)row * g.ldc + min(col, g.N - 1)];
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int row = m0 + wm * WM + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (row < g.M && col < g.N) atomicAdd(g.C + (size_t)row * g.ldc + col, acc[a][b][i]);
+                    if (row < g.M && col < g.N) {
+                        if (slab) slab[(size_t)row * g.N + col] = acc[a][b][i];
+                        else g.C[(size_t)row * g.ldc + col] = old[i] + acc[a][b][i];
+                    }
                 }
             }
         if (want_colsum) {   // wave-uniform; smem is free: the K loop ended with a barrier
@@ -375,7 +397,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
                 float sum = 0.f;
 #pragma unroll
                 for (int i = 0; i < NR; ++i) sum += smem[i * BM + tid];
-                if (m0 + tid < g.M) atomicAdd(g.colsum + m0 + tid, sum);
+                if (m0 + tid < g.M) {
+                    if (slab) slab[(size_t)g.M * g.N + m0 + tid] = sum;
+                    else g.colsum[m0 + tid] += sum;       // bx == 0 is the only workgroup touching these rows' sums
+                }
             }
         }
         return;
@@ -387,6 +412,32 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 template <int MODE, int BM, int BN, int BK, int EPI, int WGM = 2, int WGN = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmArgs g) {
     gemm_body<MODE, BM, BN, BK, EPI, WGM, WGN>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// C[i] += sum_z part[z][i] (i < nC), colsum[i] += sum_z part[z][nC + i] (i < nS), slabs added in split order z = 0, 1, ...
+__global__ __launch_bounds__(256) void tn_reduce_kernel(float* __restrict__ C, float* __restrict__ colsum,
+                                                        const float* __restrict__ part, long part_stride, int splits, long nC,
+                                                        int nS, int ldc, int N) {
+    const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 < nC) {                                     // nC = M * N, N % 4 == 0: a float4 stays inside one row
+        float4 s = *reinterpret_cast<const float4*>(part + i4);
+        for (int z = 1; z < splits; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)z * part_stride + i4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const long row = i4 / N, col = i4 - row * N;
+        float* dst = C + row * ldc + col;
+        dst[0] += s.x; dst[1] += s.y; dst[2] += s.z; dst[3] += s.w;
+    } else if (colsum != nullptr && i4 < nC + 4 * (long)((nS + 3) / 4)) {
+        for (int e = 0; e < 4; ++e) {
+            const long i = i4 - nC + e;
+            if (i < nS) {
+                float s = part[nC + i];
+                for (int z = 1; z < splits; ++z) s += part[(size_t)z * part_stride + nC + i];
+                colsum[i] += s;
+            }
+        }
+    }
 }
 
 // Grouped weight-gradient GEMM: up to MAXP independent TN problems (the 4 weight gradients of every encoder layer of
@@ -431,9 +482,6 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
     gemm_body<MODE_TN, 64, 64, 16, EPI_NONE, 2, 2>(g, nt, mt, bz);
 }
 
-int g_gemm_tn_target = 0;
-int g_gemm_cfg = 0;  // tuning knob (ganffn_debug_set_gemm_cfg): 0 = heuristic; else forces a tile config
-
 template <int MODE, int BM, int BN, int BK, int EPI, int WGM = 2, int WGN = 2>
 static int launch_cfg(const GemmArgs& g, int splits, hipStream_t st) {
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
@@ -446,12 +494,6 @@ static int launch_cfg(const GemmArgs& g, int splits, hipStream_t st) {
 
 template <int MODE, int EPI>
 static int launch_pick(const GemmArgs& g, int splits, hipStream_t st) {
-    switch (g_gemm_cfg) {
-        case 1: return launch_cfg<MODE, 64, 64, 16, EPI>(g, splits, st);
-        case 2: return launch_cfg<MODE, 64, 64, 32, EPI>(g, splits, st);
-        case 7: return launch_cfg<MODE, 128, 64, 16, EPI, 4, 1>(g, splits, st);    // 4 waves, wave tile 32 x 64
-        default: break;
-    }
     // measured on MI355X (tools/gemm_bench.py, M = 3008 / 6016, N = 100 .. 2048, K = 100 .. 2048): with the
     // straight-line K loop the 4-wave 64x64x16 block is the fastest or within 2 % of the fastest of every block /
     // wave-tile shape tried (64x64x32, 128x64, 64x128, 128x128 with 2, 4, 8 or 16 waves), so it is the only one used.
@@ -521,36 +563,59 @@ int launch_gemm_nn(const float* A, int lda, const float* Bm, int ldb, float* C, 
     EPI_SWITCH(MODE_NN, g, st)
 }
 
+// floats of partial-slab workspace a split TN launch of this shape can use (0: it will not split)
+long gemm_tn_part_floats(int M, int N, int K) {
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    long splits = (768 + tiles - 1) / tiles;             // ~3 blocks per CU measured best (tools/gemm_bench.py)
+    const long maxsplits = (K + 63) / 64;                // at least 64 k per block
+    if (splits > maxsplits) splits = maxsplits;
+    if (splits <= 1) return 0;
+    return splits * ((long)M * N + M);
+}
+
+static int launch_tn_reduce(float* C, int ldc, float* colsum, const float* part, long part_stride, int splits, int M, int N,
+                            hipStream_t st) {
+    const long nC = (long)M * N;
+    const long n4 = nC / 4 + (colsum ? (M + 3) / 4 : 0);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, C, colsum, part, part_stride,
+                       splits, nC, M, ldc, N);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+// C[M x N] += At^T B (+ column sums of At).  With a partial-slab workspace (part_ws, part_floats) the K range is split
+// over workgroups (slabs + ordered reduce: deterministic); without one a single workgroup per tile runs the whole K.
 int launch_gemm_tn_acc(const float* At, int lda, const float* Bm, int ldb, float* C, int ldc, float* colsum,
-                       int M, int N, int K, hipStream_t st) {
+                       int M, int N, int K, hipStream_t st, float* part_ws, long part_floats) {
     GF_TRY(check_common(At, lda, Bm, ldb, C, M, N, K));
     GF_CHECK_ARG((M & 3) == 0 && (N & 3) == 0, "gemm_tn: M=%d and N=%d must be multiples of 4", M, N);
     EpiArgs ea;
     GemmArgs g{At, lda, Bm, ldb, C, ldc, colsum, M, N, K, K, 0, ea};
     const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-    long splits = (768 + tiles - 1) / tiles;             // ~3 blocks per CU measured best (tools/gemm_bench.py)
-    long maxsplits = (K + 63) / 64;                      // at least 64 k per block
-    if (g_gemm_tn_target > 0) { splits = (g_gemm_tn_target + tiles - 1) / tiles; }
+    const long per = (long)M * N + M;
+    long splits = (768 + tiles - 1) / tiles;
+    const long maxsplits = (K + 63) / 64;
     if (splits > maxsplits) splits = maxsplits;
+    if (part_ws == nullptr) splits = 1;
+    else if (splits * per > part_floats) splits = part_floats / per;
     if (splits < 1) splits = 1;
     int kchunk = (int)(((K + splits - 1) / splits + 63) / 64 * 64);   // multiple of every BK
     splits = (K + kchunk - 1) / kchunk;
     g.kchunk = kchunk;
-    if (g_gemm_cfg == 2) return launch_cfg<MODE_TN, 64, 64, 32, EPI_NONE>(g, (int)splits, st);
-    return launch_cfg<MODE_TN, 64, 64, 16, EPI_NONE>(g, (int)splits, st);
+    if (splits > 1) {
+        GF_CHECK_ARG(aligned16(part_ws), "gemm_tn: partial-slab workspace must be 16-byte aligned");
+        g.part = part_ws;
+        g.part_stride = (per + 3) & ~3L;
+        if (splits * g.part_stride > part_floats) { splits = 1; g.part = nullptr; g.kchunk = K; }
+    }
+    GF_TRY((launch_cfg<MODE_TN, 64, 64, 16, EPI_NONE>(g, (int)splits, st)));
+    if (splits > 1) GF_TRY(launch_tn_reduce(C, ldc, colsum, g.part, g.part_stride, (int)splits, M, N, st));
+    return 0;
 }
 
-static void tn_plan(int M, int N, int K, long target_blocks, int* kchunk, int* splits) {
-    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-    long s = (target_blocks + tiles - 1) / tiles;
-    const long maxs = (K + 63) / 64;
-    if (s > maxs) s = maxs;
-    if (s < 1) s = 1;
-    *kchunk = (int)(((K + s - 1) / s + 63) / 64 * 64);
-    *splits = (K + *kchunk - 1) / *kchunk;
-}
-
-// dW_i[M_i x N_i] += At_i^T B_i for n problems in one launch (see gemm_tn_grouped_kernel)
+// dW_i[M_i x N_i] += At_i^T B_i for n problems in one launch (see gemm_tn_grouped_kernel).  No split-K: every output tile
+// has one owner workgroup that runs the whole token range and adds its result in place — deterministic, and the group
+// is wide enough without it (one encoder backward pass: 1136 tiles at d_model 100, 6144 at 512).
 int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st) {
     GF_CHECK_ARG(d && n >= 1 && n <= MAXP, "gemm_tn_grouped: n=%d out of [1,%d]", n, MAXP);
     TnGroup grp;
@@ -562,15 +627,12 @@ int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st) {
         TnProblem& q = grp.p[i];
         q.A = d[i].At; q.B = d[i].B; q.C = d[i].C; q.colsum = d[i].colsum;
         q.lda = d[i].lda; q.ldb = d[i].ldb; q.ldc = d[i].ldc; q.M = d[i].M; q.N = d[i].N; q.K = d[i].K;
-        int splits;
-        // big problems alone would take ~768 workgroups; in a group the launch is already wide, so fewer, longer splits
-        // (less atomic traffic) are enough
-        tn_plan(d[i].M, d[i].N, d[i].K, g_gemm_tn_target > 0 ? g_gemm_tn_target : (n >= 8 ? 256 : 768), &q.kchunk, &splits);
+        q.kchunk = d[i].K;
         const int tm = (d[i].M + 63) / 64;
         q.tiles_n = (d[i].N + 63) / 64;
         q.tiles_mn = tm * q.tiles_n;
         q.block0 = total;
-        total += q.tiles_mn * splits;
+        total += q.tiles_mn;
     }
     constexpr size_t lds = Smem<MODE_TN, 64, 64, 16>::TOTAL * sizeof(float);
     hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(256), lds, st, grp);
@@ -579,9 +641,3 @@ int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st) {
 }
 
 }  // namespace ganffn
-
-extern "C" int ganffn_debug_set_gemm_cfg(int cfg, int tn_target_blocks) {
-    ganffn::g_gemm_cfg = cfg;
-    ganffn::g_gemm_tn_target = tn_target_blocks;
-    return 0;
-}

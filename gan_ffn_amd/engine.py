@@ -228,7 +228,6 @@ class GanEngine(_Runner):
         stream_maps = STREAM_MAP if len(self.schedule) == 12 else \
             {1: [0] * len(self.schedule), 2: [(i // 2) % 2 for i in range(len(self.schedule))]}
         self.use_graph = use_graph
-        self.use_aux = os.environ.get("GANFFN_AUX", "0") == "1"   # wgrad on a 2nd stream: measured slower with >1 sub-step stream
         if n_streams not in stream_maps:
             n_streams = max(k for k in stream_maps if k <= max(1, n_streams))
         self.n_streams = n_streams
@@ -389,27 +388,16 @@ class GanEngine(_Runner):
                          g("fc3.weight") if net.kind == 1 else None, g("fc3.bias") if net.kind == 1 else None,
                          ps.dx, ps.hsaved, self.ws, self.rng.state, a1)
         gslab = net.grad if want_wgrad else None
-        aux = self._aux_for_current() if want_wgrad else None
         if reduce_cb is None or not want_wgrad:
-            ops.encoder_bwd_raw(cfg, 0, net.L, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0, aux)
+            ops.encoder_bwd_raw(cfg, 0, net.L, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0)
         else:
             # bucketed: backward a group of layers, then hand that slice of the grad slab to the all-reduce
             bks = net.buckets(self.n_buckets)
             reduce_cb(*bks[0], last=False)                       # head (+object handled by caller before this)
             for i, (lo_f, hi_f) in enumerate(bks[1:]):
                 lo, hi = lo_f // net.layer_floats, hi_f // net.layer_floats
-                ops.encoder_bwd_raw(cfg, lo, hi, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0, aux)
+                ops.encoder_bwd_raw(cfg, lo, hi, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0)
                 reduce_cb(lo_f, hi_f, last=(i == len(bks) - 2))
-
-    def _aux_for_current(self):
-        """second HIP stream for the weight-gradient GEMMs of the sub-step running on the current stream"""
-        if not getattr(self, "use_aux", False):
-            return None
-        key = torch.cuda.current_stream().cuda_stream
-        pool = self.__dict__.setdefault("_aux_pool", {})
-        if key not in pool:
-            pool[key] = torch.cuda.Stream(device=self.dev)
-        return pool[key]
 
     def _adam(self, net):
         ops.adam_step_raw(net.slab, net.grad, net.exp_avg, net.exp_avg_sq, net.step, net.total, net.lr,

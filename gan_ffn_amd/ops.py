@@ -121,10 +121,9 @@ def encoder_fwd_raw(cfg, x, pe, slab, out, saved, ws, rng, add):
               _ptr(rng), C.c_uint64(add), _stream())
 
 
-def encoder_bwd_raw(cfg, lo, hi, dx, slab, gslab, saved, ws, rng, add, aux_stream=None):
-    aux = C.c_void_p(aux_stream.cuda_stream) if aux_stream is not None else None
-    _lib.call("ganffn_encoder_bwd2", C.byref(cfg), lo, hi, _ptr(dx), _ptr(slab), _ptr(gslab), _ptr(saved), _ptr(ws),
-              _ptr(rng), C.c_uint64(add), _stream(), aux)
+def encoder_bwd_raw(cfg, lo, hi, dx, slab, gslab, saved, ws, rng, add):
+    _lib.call("ganffn_encoder_bwd", C.byref(cfg), lo, hi, _ptr(dx), _ptr(slab), _ptr(gslab), _ptr(saved), _ptr(ws),
+              _ptr(rng), C.c_uint64(add), _stream())
 
 
 def head_fwd_raw(cfg, x, w1, b1, w2, b2, w3, b3, out, saved, ws, rng, add):

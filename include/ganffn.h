@@ -14,8 +14,13 @@
  *    token t = s*B + b, i.e. exactly the memory of the reference's (S, B, C) tensors
  *    (train_IEMOCAP.py:142-147).
  *  - The caller owns EVERY buffer (inputs, outputs, saved-for-backward, workspace,
- *    parameter/gradient/optimizer-state slabs).  The library allocates nothing and keeps
- *    no mutable global state.
+ *    parameter/gradient/optimizer-state slabs).  The library allocates nothing, creates no
+ *    streams or events, and keeps no mutable state between calls except two caches that
+ *    do not affect results: the thread-local last-error string and, per (kernel, device,
+ *    host thread), the fact that hipFuncSetAttribute has opted a kernel in to > 48 KiB of LDS.
+ *  - Results are bit-reproducible: no kernel accumulates with floating-point atomics (weight
+ *    gradients, bias gradients, LayerNorm gradients and loss sums are owner-computed or reduced
+ *    in a fixed order), so two runs from the same state and RNG offset give identical bits.
  *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it and the call
  *    returns without synchronising (so calls are capturable in a hipGraph).
  *  - Return value: 0 ok; < 0 argument/shape/alignment error (message via
@@ -26,7 +31,7 @@
  *    slab through nn.Parameter views named like the reference's state_dict keys
  *    (transformer_encoder.layers.N.self_attn.in_proj_weight ...).
  *  - Dropout uses the counter-based Philox4x32-10 contract of oracle/philox.py /
- *    csrc/philox.h.  `rng` points to TWO device uint64: {seed, offset}; kernels read them
+ *    gan_ffn_amd/csrc/common.h (philox4, drop_mult4).  `rng` points to TWO device uint64: {seed, offset}; kernels read them
  *    at run time, so a captured graph replays with fresh masks after ganffn_rng_advance.
  */
 #ifndef GANFFN_H
@@ -111,14 +116,6 @@ int ganffn_encoder_fwd(const ganffn_enc_cfg* cfg, const float* x_in, const float
 int ganffn_encoder_bwd(const ganffn_enc_cfg* cfg, int layer_lo, int layer_hi, float* dx,
                        const float* params, float* grads, const float* saved, float* workspace,
                        const uint64_t* rng, uint64_t rng_offset_add, void* stream);
-
-/* Same, with the weight-gradient GEMMs enqueued on `aux_stream` (may be NULL = same as above).  They are off
- * the input-gradient chain, so a second stream overlaps them with it; the call records/waits HIP events so
- * that, for the caller, everything is complete in `stream` order when the next operation on `stream` starts.
- * (The library keeps a small pool of hipEvent_t for this — its only internally created objects.) */
-int ganffn_encoder_bwd2(const ganffn_enc_cfg* cfg, int layer_lo, int layer_hi, float* dx,
-                        const float* params, float* grads, const float* saved, float* workspace,
-                        const uint64_t* rng, uint64_t rng_offset_add, void* stream, void* aux_stream);
 
 /* ---- A3-A6: heads ------------------------------------------------------------------- */
 /* x [T x E] = encoder output.  w1[D1,E] b1[D1] w2[D2,D1] b2[D2]; disc only: w3[1,D2] b3[1].
@@ -236,9 +233,6 @@ int ganffn_add_dropout_layernorm_bwd(const float* d_out, const float* xhat, cons
 int ganffn_dropout(const float* x, float* out, int R, int C, float p, uint32_t site,
                    const uint64_t* rng, uint64_t rng_offset_add, void* stream);
 
-/* Tuning hook (process-wide, not for production use): force a GEMM tile configuration
- * (0 = built-in heuristic) and the split-K block target of the wgrad GEMM (0 = default). */
-int ganffn_debug_set_gemm_cfg(int cfg, int tn_target_blocks);
 /* which encoder FFN passes use the fused kernel: bit 0 forward (saving h), bit 1 forward (inference), bit 2 backward */
 int ganffn_debug_set_ffn_mode(int bits);
 

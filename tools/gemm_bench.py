@@ -39,15 +39,8 @@ def bench(kind, M, N, K, cfgs, tn_targets=(0,)):
     else:
         a, w, c, s = rnd(K, M, device="cuda"), rnd(K, N, device="cuda"), torch.zeros(M, N, device="cuda"), torch.zeros(M, device="cuda")
         fn = lambda: _lib.call("ganffn_gemm_tn_acc", ops._ptr(a), ops._ptr(w), ops._ptr(c), ops._ptr(s), M, N, K, st)
-    for cfg in cfgs:
-        for tt in (tn_targets if kind == "tn" else (0,)):
-            lib.ganffn_debug_set_gemm_cfg(cfg, tt)
-            try:
-                us = timeit(fn)
-                out.append("cfg%d%s: %6.1fus %5.1fTF" % (cfg, ("/t%d" % tt) if kind == "tn" else "", us, 2.0 * M * N * K / us / 1e6))
-            except Exception as e:
-                out.append("cfg%d: ERR %s" % (cfg, str(e)[:40]))
-    lib.ganffn_debug_set_gemm_cfg(0, 0)
+    us = timeit(fn)
+    out.append("%6.1fus %5.1fTF" % (us, 2.0 * M * N * K / us / 1e6))
     print("%s M=%5d N=%5d K=%5d | %s" % (kind, M, N, K, " | ".join(out)), flush=True)
 
 
@@ -69,7 +62,7 @@ def bench_torch(M, N, K, iters=50):
 
 
 if __name__ == "__main__":
-    cfgs = [int(c) for c in os.environ.get('CFGS', '1,2,7').split(',')]
+    cfgs = None    # tile-config sweeps used a debug hook that the release library no longer carries
     torch.backends.cuda.matmul.allow_tf32 = False
     if len(sys.argv) > 1 and sys.argv[1] == "big":
         for (N, K) in ((2048, 100), (2048, 512), (512, 2048), (1536, 512)):
