@@ -43,7 +43,8 @@ SIGNATURES = {
     "ganffn_head_fwd": (_I, [_PH, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _P]),
     "ganffn_head_bwd": (_I, [_PH, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _P]),
     "ganffn_linear_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
-    "ganffn_linear_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ganffn_linear_bwd_workspace_floats": (_L, [_I, _I, _I]),
+    "ganffn_linear_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P]),
     "ganffn_bce_fwd": (_I, [_P, _F, _I, _F, _P, _I, _P]),
     "ganffn_bce_bwd": (_I, [_P, _F, _I, _F, _P, _P]),
     "ganffn_bce2_fwd": (_I, [_P, _F, _F, _I, _I, _I, _F, _P, _I, _P]),
@@ -55,8 +56,9 @@ SIGNATURES = {
     "ganffn_gemm_nn": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ganffn_gemm_tn_acc": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ganffn_ffn_linear1_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _U32, _P, _U64, _I, _P]),
-    "ganffn_ffn_fused_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U32, _P, _U64, _I, _P]),
-    "ganffn_ffn_fused_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "ganffn_ffn_pack_floats": (_L, [_I]),
+    "ganffn_ffn_fused_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U32, _P, _U64, _I, _P]),
+    "ganffn_ffn_fused_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "ganffn_gemm_tn_grouped": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ganffn_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),
     "ganffn_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),

@@ -94,10 +94,12 @@ static int check_cfg(const ganffn_enc_cfg* c) {
     return 0;
 }
 
-// which FFN passes use the fused kernel: 1 = forward (h saved), 2 = forward (nothing saved), 4 = backward dgrad.
-// Tuning hook ganffn_debug_set_ffn_mode; default chosen from measurements.
-int g_ffn_mode = 0;   // measured neutral at T = 3008/6016 (1.5 / 2.9 workgroups per CU leave SIMDs unevenly loaded); see DESIGN.md
+// d_model = 100 feed-forward block: the fused kernel (ffn.hip) unless switched off (A/B measurement hook
+// ganffn_debug_set_ffn_mode; both paths are parity-tested)
+int g_ffn_fused = 1;
 constexpr int MAX_SPLITS = 16;  // partial-output slabs: fused FFN (16 F splits) / split-K GEMMs (<= 8)
+
+static int64_t a4(int64_t n) { return (n + 3) & ~int64_t(3); }
 
 // per LayerNorm backward launch: per-block partial sums of the weight / bias gradient
 static int64_t ln_part_floats(const ganffn_enc_cfg* c) { return (int64_t)ln_bwd_blocks(c->S * c->B) * 2 * c->E; }
@@ -105,9 +107,11 @@ static int64_t ln_part_floats(const ganffn_enc_cfg* c) { return (int64_t)ln_bwd_
 static int64_t enc_ws_floats(const ganffn_enc_cfg* c) {
     const int64_t T = (int64_t)c->S * c->B, TE = T * c->E, TF = T * c->F;
     // L x (dh | dyA dyB d_qkv(3)) | dz2 dz1 d_attn | tmp slabs | L x 2 LayerNorm partial-sum blocks
-    const int64_t bwd = (int64_t)c->L * (TF + 5 * TE) + (3 + MAX_SPLITS) * TE + (int64_t)c->L * 2 * ln_part_floats(c);
+    // + L packed FFN weight blocks (fused feed-forward kernel, d_model 100)
+    const int64_t pack = ffn_fused_supported(c->E, c->F) ? (int64_t)c->L * ffn_pack_floats(c->F) : 0;
+    const int64_t bwd = (int64_t)c->L * (TF + 5 * TE) + (3 + MAX_SPLITS) * TE + (int64_t)c->L * 2 * ln_part_floats(c) + pack;
     const SavedOff s = saved_off(c);
-    const int64_t fwd_nosave = 2 * TE + s.per_layer + MAX_SPLITS * TE;   // X ping-pong + one layer's saved set + tmp slabs
+    const int64_t fwd_nosave = 2 * TE + s.per_layer + MAX_SPLITS * TE + pack;   // X ping-pong + one layer's saved set + tmp slabs + packs
     return (bwd > fwd_nosave ? bwd : fwd_nosave) + 64;
 }
 
@@ -160,7 +164,7 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
     const SavedOff so = saved_off(c);
     const int train = c->train;
 
-    float* tmp;      // [T x E] GEMM output before residual+LN
+    float* tmp;      // [MAX_SPLITS][T x E] GEMM output (partial slabs) before residual+LN
     float* Xcur;
     if (saved) {
         tmp = workspace;
@@ -169,6 +173,11 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
         tmp = workspace + 2 * TE + so.per_layer;
         Xcur = workspace;
     }
+    // d_model 100: the feed-forward block runs as ONE fused kernel per layer on weights packed in MFMA fragment order
+    const bool fused = ffn_fused_supported(E, F) && g_ffn_fused;
+    float* pack = tmp + (int64_t)MAX_SPLITS * TE;
+    const int64_t PK = fused ? ffn_pack_floats(F) : 0;
+    if (fused) GF_TRY(launch_ffn_pack(params, lo.total, lo.w1, lo.w2, pack, L, F, 0, st));
     GF_TRY(launch_pe_dropout(x_in, pe, Xcur, S, B, E, c->p_pe, rng, add, train, st));
 
     for (int l = 0; l < L; ++l) {
@@ -190,9 +199,9 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
                                       c->ln_eps, c->p_enc, site + 1, rng, add, train, st));
         // FFN: h = drop(relu(x1 W1^T + b1)); y = h W2^T + b2
         int splits = 1;
-        if (ffn_fused_supported(E, F) && (g_ffn_mode & (saved ? 1 : 2))) {
+        if (fused) {
             // one kernel; the hidden tile feeds linear2 from registers; h is streamed out only when backward needs it
-            GF_TRY(launch_ffn_fused_fwd(sv + so.x1, P + lo.w1, P + lo.b1, P + lo.w2, P + lo.b2, saved ? sv + so.h : nullptr,
+            GF_TRY(launch_ffn_fused_fwd(sv + so.x1, pack + (int64_t)l * PK, P + lo.b1, P + lo.b2, saved ? sv + so.h : nullptr,
                                         tmp, TE, T, E, F, c->p_enc, site + 2, rng, add, train, &splits, st));
         } else {
             EpiArgs e1;
@@ -246,6 +255,11 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
     float* tmp = d_attn + TE;         // [MAX_SPLITS][T x E] partial slabs of dh W1
     float* lnp0 = tmp + (int64_t)MAX_SPLITS * TE;   // [L][2] LayerNorm partial-sum blocks
     const int64_t LNP = ln_part_floats(c);
+    float* pack = lnp0 + (int64_t)c->L * 2 * LNP;    // packed FFN weights of the layers of this range (backward orientation)
+    const bool fused = ffn_fused_supported(E, F) && g_ffn_fused;
+    const int64_t PK = fused ? ffn_pack_floats(F) : 0;
+    if (fused)
+        GF_TRY(launch_ffn_pack(params + (int64_t)layer_lo * lo.total, lo.total, lo.w1, lo.w2, pack, layer_hi - layer_lo, F, 1, st));
     const int lnblk = ln_bwd_blocks(T);
     TnDesc tn[40];
     int ntn = 0;
@@ -275,10 +289,9 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
         if (G) tn[ntn++] = TnDesc{dyA, E, sv + so.h, F, G + lo.w2, F, G + lo.b2, E, F, T};
         const float mscale = (pdrop > 0.f) ? 1.0f / (1.0f - pdrop) : 1.0f;
         int splits = 1;
-        const bool fused = ffn_fused_supported(E, F) && (g_ffn_mode & 4);
         if (fused) {
             // dh = (dy W2) * [h > 0] / (1-p) and d x1 = dh W1 in one kernel (dh streamed out for the wgrad below)
-            GF_TRY(launch_ffn_fused_bwd(dyA, P + lo.w1, P + lo.w2, sv + so.h, dh, tmp, TE, T, E, F, mscale, &splits, st));
+            GF_TRY(launch_ffn_fused_bwd(dyA, pack + (int64_t)(l - layer_lo) * PK, sv + so.h, dh, tmp, TE, T, E, F, mscale, &splits, st));
         } else {
             EpiArgs em;
             em.aux_in = sv + so.h;
@@ -340,7 +353,6 @@ extern "C" int64_t ganffn_head_saved_floats(const ganffn_head_cfg* c) {
 }
 // workspace of the head backward: d_pre1 [T x D1] | d_pre2 [T x D2] | split-K partial slabs of the two weight-gradient
 // GEMMs | per-block partial sums of the discriminator tail
-static int64_t a4(int64_t n) { return (n + 3) & ~int64_t(3); }
 static int64_t head_part2(const ganffn_head_cfg* c) { return a4(gemm_tn_part_floats(c->D2, c->D1, c->T)); }
 static int64_t head_part1(const ganffn_head_cfg* c) { return a4(gemm_tn_part_floats(c->D1, c->E, c->T)); }
 extern "C" int64_t ganffn_head_workspace_floats(const ganffn_head_cfg* c) {
@@ -446,14 +458,21 @@ extern "C" int ganffn_linear_fwd(const float* x, const float* w, const float* b,
     return launch_small_linear_fwd(x, w, b, y, T, K, N, st);
 }
 
+extern "C" int64_t ganffn_linear_bwd_workspace_floats(int T, int K, int N) {
+    return mfma_ok(K, N) ? a4(gemm_tn_part_floats(N, K, T)) : 0;
+}
+
 extern "C" int ganffn_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* gw, float* gb, int T,
-                                 int K, int N, void* stream) {
+                                 int K, int N, float* workspace, int64_t workspace_floats, void* stream) {
     GF_CHECK_ARG(dy && x && w && T > 0 && K > 0 && N > 0, "linear_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (mfma_ok(K, N) && aligned16(dy) && aligned16(x) && aligned16(w)) {
         EpiArgs e;
         if (dx) GF_TRY(launch_gemm_nn(dy, N, w, K, dx, K, T, K, N, EPI_NONE, e, st));
-        if (gw) GF_TRY(launch_gemm_tn_acc(dy, N, x, K, gw, K, gb, N, K, T, st));
+        // weight gradient: split over tokens into partial slabs when the caller lends a workspace (deterministic
+        // ordered reduce), one workgroup per tile over the whole token range otherwise
+        const bool ws_ok = workspace != nullptr && aligned16(workspace);
+        if (gw) GF_TRY(launch_gemm_tn_acc(dy, N, x, K, gw, K, gb, N, K, T, st, ws_ok ? workspace : nullptr, ws_ok ? (long)workspace_floats : 0));
         return 0;
     }
     return launch_small_linear_bwd(dy, x, w, dx, gw, gb, T, K, N, st);
@@ -483,23 +502,30 @@ extern "C" int ganffn_ffn_linear1_fwd(const float* x, const float* w1, const flo
     return launch_gemm_nt(x, E, w1, E, h, F, T, F, E, EPI_RELU_DROP, e, (hipStream_t)stream);
 }
 extern "C" int ganffn_debug_set_ffn_mode(int bits) {
-    g_ffn_mode = bits & 7;
+    g_ffn_fused = bits ? 1 : 0;
     return 0;
 }
 extern "C" int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h,
-                                    float* slabs, int T, int E, int F, float p, uint32_t site, const uint64_t* rng, uint64_t add,
-                                    int train, void* stream) {
+                                    float* slabs, float* pack_ws, int T, int E, int F, float p, uint32_t site,
+                                    const uint64_t* rng, uint64_t add, int train, void* stream) {
+    GF_CHECK_ARG(w1 && w2 && pack_ws && ffn_fused_supported(E, F), "ffn_fused_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    // w1 / w2 are separate tensors here: pack them as a one-layer "slab" addressed relative to w1
+    GF_TRY(launch_ffn_pack(w1, 0, 0, (long)(w2 - w1), pack_ws, 1, F, 0, st));
     int splits = 0;
-    GF_TRY(launch_ffn_fused_fwd(x, w1, b1, w2, b2, h, slabs, (long)T * E, T, E, F, p, site, rng, add, train, &splits,
-                                (hipStream_t)stream));
+    GF_TRY(launch_ffn_fused_fwd(x, pack_ws, b1, b2, h, slabs, (long)T * E, T, E, F, p, site, rng, add, train, &splits, st));
     return -1000 - splits;   // negative "code" carries the slab count back to the test harness (see ganffn.h)
 }
 extern "C" int ganffn_ffn_fused_bwd(const float* dy, const float* w1, const float* w2, const float* h, float* dh, float* slabs,
-                                    int T, int E, int F, float mscale, void* stream) {
+                                    float* pack_ws, int T, int E, int F, float mscale, void* stream) {
+    GF_CHECK_ARG(w1 && w2 && pack_ws && ffn_fused_supported(E, F), "ffn_fused_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    GF_TRY(launch_ffn_pack(w1, 0, 0, (long)(w2 - w1), pack_ws, 1, F, 1, st));
     int splits = 0;
-    GF_TRY(launch_ffn_fused_bwd(dy, w1, w2, h, dh, slabs, (long)T * E, T, E, F, mscale, &splits, (hipStream_t)stream));
+    GF_TRY(launch_ffn_fused_bwd(dy, pack_ws, h, dh, slabs, (long)T * E, T, E, F, mscale, &splits, st));
     return -1000 - splits;
 }
+extern "C" int64_t ganffn_ffn_pack_floats(int F) { return ffn_pack_floats(F); }
 extern "C" int ganffn_gemm_tn_grouped(int n, const float* const* At, const float* const* Bm, float* const* C, float* const* colsum,
                                       const int* M, const int* N, const int* K, void* stream) {
     GF_CHECK_ARG(n >= 1 && n <= 40 && At && Bm && C && M && N && K, "gemm_tn_grouped: bad arguments");

@@ -50,37 +50,42 @@ struct HeadSrc16 {
     float scale;
 };
 
-// Stage NM [S x HD] head slices into LDS images [16 NT rows][LD] (rows >= S and columns >= HD zero).  Every global load
-// of all matrices is issued (clamped addresses, masked by a select) before the first LDS write: one memory round trip.
+// Stage NM [S x HD] head slices into LDS images [16 NT rows][LD] (rows >= S and columns >= HD zero), in two phases so that
+// the caller can put data-independent work (the Philox calls) between issuing the global loads and waiting for them:
+// every global load of all matrices is issued (clamped addresses, masked by a select) before the first LDS write.
 template <int HD, int NT, int NM>
-__device__ __forceinline__ void stage_heads(const HeadSrc16 (&m)[NM], int S, int B, int b, int tid) {
-    constexpr int LD = A16<HD>::LD, PR = LD / 2, ROWS = 16 * NT, PER = ROWS * PR, NTH = 64 * NT;
-    constexpr int U = (PER + NTH - 1) / NTH;
+struct HeadStage {
+    static constexpr int LD = A16<HD>::LD, PR = LD / 2, ROWS = 16 * NT, PER = ROWS * PR, NTH = 64 * NT;
+    static constexpr int U = (PER + NTH - 1) / NTH;
     float2 v[NM][U];
+    __device__ __forceinline__ void load(const HeadSrc16 (&m)[NM], int S, int B, int b, int tid) {
 #pragma unroll
-    for (int mi = 0; mi < NM; ++mi) {
+        for (int mi = 0; mi < NM; ++mi) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = min(tid + u * NTH, PER - 1);
-            const int s = i / PR, j = i - s * PR;
-            const bool ok = s < S && 2 * j < HD;
-            const float2 q = *reinterpret_cast<const float2*>(m[mi].src + (size_t)(min(s, S - 1) * B + b) * m[mi].ld_src + min(2 * j, HD - 2));
-            v[mi][u] = ok ? make_float2(q.x * m[mi].scale, q.y * m[mi].scale) : make_float2(0.f, 0.f);
-        }
-    }
-#pragma unroll
-    for (int mi = 0; mi < NM; ++mi) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = tid + u * NTH;
-            if (PER % NTH == 0 || i < PER) {
+            for (int u = 0; u < U; ++u) {
+                const int i = min(tid + u * NTH, PER - 1);
                 const int s = i / PR, j = i - s * PR;
-                *reinterpret_cast<float2*>(m[mi].dst + s * LD + 2 * j) = v[mi][u];
+                const bool ok = s < S && 2 * j < HD;
+                const float2 q = *reinterpret_cast<const float2*>(m[mi].src + (size_t)(min(s, S - 1) * B + b) * m[mi].ld_src + min(2 * j, HD - 2));
+                v[mi][u] = ok ? make_float2(q.x * m[mi].scale, q.y * m[mi].scale) : make_float2(0.f, 0.f);
             }
         }
-        if (tid < A16<HD>::TAIL) m[mi].dst[ROWS * LD + tid] = 0.f;
     }
-}
+    __device__ __forceinline__ void store(const HeadSrc16 (&m)[NM], int tid) const {
+#pragma unroll
+        for (int mi = 0; mi < NM; ++mi) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = tid + u * NTH;
+                if (PER % NTH == 0 || i < PER) {
+                    const int s = i / PR, j = i - s * PR;
+                    *reinterpret_cast<float2*>(m[mi].dst + s * LD + 2 * j) = v[mi][u];
+                }
+            }
+            if (tid < A16<HD>::TAIL) m[mi].dst[ROWS * LD + tid] = 0.f;
+        }
+    }
+};
 
 // acc[t] (+)= X_t Y^T over the head dimension: A = rows 16t + c of Xm (one tile per t), B = row `yrow` of Ym for this lane.
 // D[m][n]: m = row of X inside tile t (4g + reg), n = this lane's Y row.
@@ -172,10 +177,28 @@ __global__ __launch_bounds__(64 * NT) void attn16_fwd_kernel(const float* __rest
     float* Ks = Qs + MAT;
     float* Vs = Ks + MAT;
     const int ld3 = 3 * E;
+    const DropCtx dc = make_drop(rng, add, site, p, train);
+    uint32_t mine = 0;
     {
         const HeadSrc16 m3[3] = {{Qs, qkv + head * HD, ld3, rsqrtf((float)HD)}, {Ks, qkv + E + head * HD, ld3, 1.f},
                                  {Vs, qkv + 2 * E + head * HD, ld3, 1.f}};
-        stage_heads<HD, NT, 3>(m3, S, B, b, tid);
+        HeadStage<HD, NT, 3> stg;
+        stg.load(m3, S, B, b, tid);
+        if (dc.on) {
+            // Dropout keep-bits, computed while the global loads are in flight (they depend on indices only).  One Philox
+            // call = 4 consecutive queries (the 4 lanes of a quad) at one key.  Lane ql of a quad evaluates the calls of
+            // register r == ql (keys 16t + 4g + ql); bit 4t + qq of `mine` = keep(query 4Q + qq, that key).
+            const int ql = c & 3;
+            const uint32_t rowgroup = (uint32_t)(bh * 28 + 4 * w + (c >> 2));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                uint32_t wd[4];
+                philox4(rowgroup * 128u + (uint32_t)(16 * t + 4 * g + ql), dc.site, dc.o0, dc.o1, dc.k0, dc.k1, wd);
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) mine |= (wd[qq] >= dc.thr ? 1u : 0u) << (4 * t + qq);
+            }
+        }
+        stg.store(m3, tid);
     }
     __syncthreads();
 
@@ -210,21 +233,8 @@ __global__ __launch_bounds__(64 * NT) void attn16_fwd_kernel(const float* __rest
     const int qi = 16 * w + c;
     if (lse != nullptr && g == 0 && qi < S) lse[(size_t)bh * S + qi] = m + __logf(sum);
 
-    const DropCtx dc = make_drop(rng, add, site, p, train);
     if (dc.on) {
-        // One Philox call = 4 consecutive queries (the 4 lanes of a quad) at one key.  Lane ql of a quad evaluates the
-        // calls of register r == ql (keys 16t + 4g + ql); bit 4t + qq of `mine` = keep(query 4Q + qq, that key).
         const int ql = c & 3;
-        uint32_t mine = 0;
-        const uint32_t rowgroup = (uint32_t)(bh * 28 + 4 * w + (c >> 2));
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            uint32_t wd[4];
-            philox4(rowgroup * 128u + (uint32_t)(16 * t + 4 * g + ql), dc.site, dc.o0, dc.o1, dc.k0, dc.k1, wd);
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq)
-                if (wd[qq] >= dc.thr) mine |= 1u << (4 * t + qq);
-        }
         const uint32_t mq[4] = {quad_bcast<0>(mine), quad_bcast<1>(mine), quad_bcast<2>(mine), quad_bcast<3>(mine)};
         const float ps = inv * dc.scale;
 #pragma unroll
@@ -273,6 +283,10 @@ __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __rest
     float* SS = Ds + ROWS;       // [ROWS][LDS_S] dS
     const int ld3 = 3 * E;
     const float scale = rsqrtf((float)HD);
+    const DropCtx dc = make_drop(rng, add, site, p, train);
+    uint32_t wdt[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wdt[t][0] = wdt[t][1] = wdt[t][2] = wdt[t][3] = 0xFFFFFFFFu;
     {
         const HeadSrc16 m4[4] = {{Qs, qkv + head * HD, ld3, scale}, {Ks, qkv + E + head * HD, ld3, 1.f},
                                  {Vs, qkv + 2 * E + head * HD, ld3, 1.f}, {Os, d_o + head * HD, E, 1.f}};
@@ -288,7 +302,16 @@ __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __rest
             dv[kk] = d_o[rowo + d];
         }
         const float lv = lse[(size_t)bh * S + min(qi, S - 1)];
-        stage_heads<HD, NT, 4>(m4, S, B, b, tid);
+        HeadStage<HD, NT, 4> stg;
+        stg.load(m4, S, B, b, tid);
+        if (dc.on) {
+            // the keep words of this lane's (key, 4-query group) pairs: exactly one Philox call per accumulator tile, and
+            // data-independent — evaluated while the global loads are in flight
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                philox4((uint32_t)(bh * 28 + 4 * t + g) * 128u + (uint32_t)(16 * w + c), dc.site, dc.o0, dc.o1, dc.k0, dc.k1, wdt[t]);
+        }
+        stg.store(m4, tid);
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) part += (4 * kk + g < HD && qi < S) ? ov[kk] * dv[kk] : 0.f;
         part += __shfl_xor(part, 16, 64);
@@ -312,18 +335,15 @@ __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __rest
     dot_tiles<HD, NT>(ps, Qs, Ks + kj * LD + g, c, g);      // S[query 16t+4g+reg][key kj] - LSE
     dot_tiles<HD, NT>(dp, Os, Vs + kj * LD + g, c, g);      // dP~[query][key] = dO . V
 
-    const DropCtx dc = make_drop(rng, add, site, p, train);
     const bool keyok = kj < S;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        uint32_t wd[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (dc.on) philox4((uint32_t)(bh * 28 + 4 * t + g) * 128u + (uint32_t)kj, dc.site, dc.o0, dc.o1, dc.k0, dc.k1, wd);
         const float4 d4 = *reinterpret_cast<const float4*>(Ds + 16 * t + 4 * g);
         const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float pv = keyok ? __expf(ps[t][r]) : 0.f;             // probability (pre-dropout)
-            const bool keep = !dc.on || wd[r] >= dc.thr;
+            const bool keep = !dc.on || wdt[t][r] >= dc.thr;
             const float dpk = keep ? dp[t][r] * dc.scale : 0.f;          // dP = keep * scale * dP~
             ps[t][r] = keep ? pv * dc.scale : 0.f;                       // P~
             dp[t][r] = pv * (dpk - dd[r]);                               // dS

@@ -204,13 +204,18 @@ long gemm_tn_part_floats(int M, int N, int K);
 int launch_gemm_tn_acc(const float* At, int lda, const float* Bm, int ldb, float* C, int ldc, float* colsum,
                        int M, int N, int K, hipStream_t st, float* part_ws = nullptr, long part_floats = 0);
 
-// fused feed-forward block (ffn.hip), d_model = 100 only
+// fused feed-forward block (ffn.hip), d_model = 100 only.  `packed` = this layer's linear1 / linear2 weights in MFMA
+// fragment order (launch_ffn_pack: forward or backward orientation, ffn_pack_floats(F) floats per layer).
 bool ffn_fused_supported(int E, int F);
-int launch_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h,
-                         float* slabs, long slab_stride, int T, int E, int F, float p, uint32_t site, const uint64_t* rng,
-                         uint64_t add, int train, int* splits_out, hipStream_t st);
-int launch_ffn_fused_bwd(const float* dy, const float* w1, const float* w2, const float* h, float* dh, float* slabs,
-                         long slab_stride, int T, int E, int F, float mscale, int* splits_out, hipStream_t st);
+int ffn_fused_splits(int T, int F);
+long ffn_pack_floats(int F);
+int launch_ffn_pack(const float* params, long layer_stride, long off_w1, long off_w2, float* packed, int L, int F, int bwd,
+                    hipStream_t st);
+int launch_ffn_fused_fwd(const float* x, const float* packed, const float* b1, const float* b2, float* h, float* slabs,
+                         long slab_stride, int T, int E, int F, float p, uint32_t site, const uint64_t* rng, uint64_t add,
+                         int train, int* splits_out, hipStream_t st);
+int launch_ffn_fused_bwd(const float* dy, const float* packed, const float* h, float* dh, float* slabs, long slab_stride, int T,
+                         int E, int F, float mscale, int* splits_out, hipStream_t st);
 
 // grouped wgrad: n independent TN problems in one launch
 struct TnDesc {

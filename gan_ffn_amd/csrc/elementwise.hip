@@ -4,6 +4,12 @@
 // column share one Philox call), so row-wise kernels process rows in groups of 4.
 #include "common.h"
 
+// No implicit floating-point contraction in this file: left on, hipcc fuses a*b+c into an fma in some of the four row
+// slots a wave works on and not in others, which makes a token's bits depend on its position in the batch (measured:
+// 1 ulp in LayerNorm).  Every fma below is written explicitly (__fmaf_rn); these kernels are HBM-bound, so the extra
+// rounding steps cost nothing.
+#pragma clang fp contract(off)
+
 namespace ganffn {
 
 // ------------------------------------------------------------------------------------------
@@ -304,18 +310,31 @@ struct LnRedGroup {
     const float* part[LN_RED_MAX];
     int nblk[LN_RED_MAX];
 };
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(LnRedGroup grp, int E) {
-    const int j = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= E) return;
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(LnRedGroup grp, int E) {
+    // 64 columns x 16 partial groups per workgroup: thread (c, q) adds partial blocks q, q + 16, ... (independent loads, a
+    // fixed order), then the 16 group sums are added in order — the association is fixed, so the result is reproducible
+    __shared__ float red[2][16][64];
+    const int j = blockIdx.y, cl = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     const float* p = grp.part[j];
     const int nb = grp.nblk[j];
     float sw = 0.f, sb = 0.f;
-    for (int b = 0; b < nb; ++b) {
-        sw += p[((size_t)b * 2 + 0) * E + c];
-        sb += p[((size_t)b * 2 + 1) * E + c];
+    if (c < E) {
+#pragma unroll 4
+        for (int b = q; b < nb; b += 16) {
+            sw += p[((size_t)b * 2 + 0) * E + c];
+            sb += p[((size_t)b * 2 + 1) * E + c];
+        }
     }
-    grp.gw[j][c] += sw;
-    grp.gb[j][c] += sb;
+    red[0][q][cl] = sw;
+    red[1][q][cl] = sb;
+    __syncthreads();
+    if (q == 0 && c < E) {
+        float tw = 0.f, tb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { tw += red[0][i][cl]; tb += red[1][i][cl]; }
+        grp.gw[j][c] += tw;
+        grp.gb[j][c] += tb;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -690,7 +709,7 @@ int launch_ln_param_reduce(int n, float* const* gw, float* const* gb, const floa
         for (int i = 0; i < m; ++i) {
             grp.gw[i] = gw[i0 + i]; grp.gb[i] = gb[i0 + i]; grp.part[i] = part[i0 + i]; grp.nblk[i] = nblk[i0 + i];
         }
-        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((E + 255) / 256, m), dim3(256), 0, st, grp, E);
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((E + 63) / 64, m), dim3(1024), 0, st, grp, E);
         GF_LAUNCH_CHECK();
     }
     return 0;

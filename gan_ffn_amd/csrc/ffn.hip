@@ -5,19 +5,29 @@
 //     y = linear2(dropout(relu(linear1(x))))          x [T x 100], hidden [T x 2048], y [T x 100]
 // and its input-gradient chain  dh = (dy W2) * relu'/dropout mask,  dx = dh W1.
 //
-// Why fused: unfused, the [T x 2048] hidden makes an HBM round trip between two GEMMs and the second GEMM
-// (N = 100, K = 2048) has only T/64 x 2 output tiles for 256 CUs.  Here both products run TRANSPOSED with the
-// token on the MFMA lane axis, so the first product's accumulator tile (32 hidden units x 32 tokens) IS the B
-// operand of the second product — the hidden activations never leave the registers between the two GEMMs
-// (they are also streamed out once, because the weight-gradient GEMMs need h and dh).
-//     GEMM1   hT[f][t]  = sum_e  W1[f][e] x[t][e]       A = W1 tile (LDS),  B = x fragments (registers, loaded once)
-//     GEMM2   yT[e][t] += sum_f  W2[e][f] hT[f][t]      A = W2 tile (LDS),  B = GEMM1's accumulator registers
-// The backward dgrad pass is the same skeleton with the two weight tiles read in the other orientation
-// (dhT = W2^T dy^T, masked by the saved h; dxT += W1^T dhT), so no transposed weight copies exist.
-// Work split: workgroup = 4 waves = 128 tokens x (F / FSPLIT) hidden units; weight tiles are staged once per
-// workgroup in LDS (double-buffered, register-staged) and shared by the 4 waves; the FSPLIT partial outputs are
-// written as slabs and summed by the LayerNorm kernel that consumes them (no atomics, deterministic).
-// All MFMAs are v_mfma_f32_32x32x2_f32 (exact fp32): 52 + 64 per (32 tokens x 32 hidden units).
+// Why fused: unfused, the [T x 2048] hidden makes an HBM round trip between two GEMMs, the first GEMM (K = 100) is
+// seven short K tiles per workgroup with every latency exposed, and the second (N = 100, K = 2048) has T/64 x 2 output
+// tiles for 256 CUs.  Here both products run TRANSPOSED with the token on the MFMA lane axis, so the first product's
+// accumulator tile (32 hidden units x 32 tokens) IS the B operand of the second product — the hidden activations never
+// leave the registers between the two GEMMs (they are streamed out once, because the weight-gradient GEMMs need h / dh).
+//     GEMM1   hT[f][t]  = sum_e  W1[f][e] x[t][e]       A = W1 fragments,  B = x fragments (LDS, staged once per workgroup)
+//     GEMM2   yT[e][t] += sum_f  W2[e][f] hT[f][t]      A = W2 fragments,  B = GEMM1's accumulator registers
+// The backward dgrad pass is the same skeleton with the two weights in the other orientation
+// (dhT = W2^T dy^T, masked by the saved h; dxT += W1^T dhT).
+//
+// Round-2 structure (the round-1 kernel staged weight tiles through LDS with a barrier per tile and measured no faster
+// than the two GEMMs):
+//   * WEIGHTS ARE PRE-PACKED in MFMA fragment order (ffn_pack_kernel, once per encoder pass, ~15 MB): every A operand
+//     is one fully coalesced 16-byte-per-lane global load straight into registers — no LDS staging, no layout
+//     transformation and NO BARRIER in the main loop, so the two waves per SIMD drift apart and one wave's epilogue
+//     (bias / ReLU / Philox / stores: VALU) runs under the other's MFMAs;
+//   * a workgroup is 2 waves that share one 32-token tile (x staged once in LDS) and split its hidden range; their
+//     partial outputs are summed through LDS at the end, so a launch writes 16 (T <= 4096) or 8 partial slabs, which the
+//     LayerNorm kernel that consumes them sums on the fly (no atomics, deterministic);
+//   * work split for balance: one unit = 32 tokens x 32 hidden units = 116 MFMAs; T = 3008 gives 6016 units = 3008
+//     waves of 2 units (2.94 per SIMD), T = 6016 gives 3008 waves of 4 units — dispatched workgroup by workgroup, so the
+//     SIMDs stay within a few % of evenly loaded.
+// All MFMAs are v_mfma_f32_32x32x2_f32 (exact fp32): 52 + 64 per unit.
 #include "common.h"
 
 namespace ganffn {
@@ -28,57 +38,84 @@ namespace {
 constexpr int FE = 100;        // d_model handled by this kernel
 constexpr int KG = 13;         // groups of 8 along e (104 >= 100)
 constexpr int ET = 4;          // 32-wide tiles covering e (128 >= 100)
-constexpr int S1 = 108;        // LDS row stride of the W1 tile [32 f][100 e]  (108 = 4 * 27: b128 row reads conflict-free)
-constexpr int S2 = 36;         // LDS row stride of the W2 tile [128 e][32 f]  (36 = 4 * 9)
-constexpr int W1_FLOATS = 32 * S1;
-constexpr int W2_FLOATS = 128 * S2;
-constexpr int STAGE = W1_FLOATS + W2_FLOATS + 32;   // + b1 tile
+constexpr int XS = 108;        // LDS row stride of the x tile [32 tokens][100 e] (108 = 4 * 27: b128 row reads conflict-free)
+constexpr int G1_VEC = KG * 64;            // float4 per f-tile of the GEMM1 A fragments
+constexpr int G2_VEC = ET * 4 * 64;        // float4 per f-tile of the GEMM2 A fragments
+constexpr int UNIT_VEC = G1_VEC + G2_VEC;  // 1856 float4 = 29,696 bytes per f-tile
 
 __device__ __forceinline__ int krow(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------
+// weight packing: [layer][f-tile]{ G1 fragments [g][lane] | G2 fragments [et][gq][lane] } as float4
+//   forward :  G1 = W1[32ft + r][8g + 4h + j]              G2 = W2[32et + r][32ft + 8gq + 4h + j]
+//   backward:  G1 = W2[8g + 4h + j][32ft + r]              G2 = W1[32ft + 8gq + 4h + j][32et + r]
+// (lane = 32h + r; j = component; entries with an e index >= 100 are zero)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__ params, long layer_stride, long off_w1, long off_w2,
+                                                       float4* __restrict__ packed, int F, int bwd, int nvec_layer) {
+    const int layer = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvec_layer) return;
+    const float* w1 = params + (size_t)layer * layer_stride + off_w1;   // [F x 100]
+    const float* w2 = params + (size_t)layer * layer_stride + off_w2;   // [100 x F]
+    const int ft = v / UNIT_VEC, u = v - ft * UNIT_VEC;
+    const int lane = u & 63, r = lane & 31, h = lane >> 5;
+    float o[4];
+    if (u < G1_VEC) {
+        const int g = u >> 6;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = 8 * g + 4 * h + j, f = 32 * ft + r;
+            o[j] = e < FE ? (bwd ? w2[(size_t)e * F + f] : w1[(size_t)f * FE + e]) : 0.f;
+        }
+    } else {
+        const int q = (u - G1_VEC) >> 6, et = q >> 2, gq = q & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = 32 * et + r, f = 32 * ft + 8 * gq + 4 * h + j;
+            o[j] = e < FE ? (bwd ? w1[(size_t)f * FE + e] : w2[(size_t)e * F + f]) : 0.f;
+        }
+    }
+    packed[(size_t)layer * nvec_layer + v] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 struct FfnArgs {
-    const float* x;      // fwd: x [T x E];  bwd: dy [T x E]
-    const float* w1;     // [F x E]
-    const float* b1;     // [F]       (fwd)
-    const float* w2;     // [E x F]
-    const float* b2;     // [E]       (fwd, added by split 0)
-    float* h;            // fwd: out (may be null: nothing kept);  bwd: in (saved post-ReLU/dropout hidden)
-    float* dh;           // bwd: out [T x F]
-    float* slabs;        // [FSPLIT][T x E] partial outputs
+    const float* x;        // fwd: x [T x E];  bwd: dy [T x E]
+    const float4* packed;  // this layer's packed weights (ffn_pack_kernel)
+    const float* b1;       // [F]       (fwd)
+    const float* b2;       // [E]       (fwd, added by slab 0)
+    float* h;              // fwd: out (may be null: nothing kept);  bwd: in (saved post-ReLU/dropout hidden)
+    float* dh;             // bwd: out [T x F]
+    float* slabs;          // [gridDim.y][T x E] partial outputs
     long slab_stride;
-    int T, F;
-    float mscale;        // bwd: 1/(1-p) if dropout was active else 1
+    int T, F, units;       // units = f-tiles per wave
+    float mscale;          // bwd: 1/(1-p) if dropout was active else 1
     float p; uint32_t site; const uint64_t* rng; uint64_t rng_add; int train;   // fwd dropout
 };
 
 template <int BWD>
-__global__ __launch_bounds__(256) void ffn_fused_kernel(FfnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__global__ __launch_bounds__(128, 2) void ffn_fused_kernel(FfnArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[ET * 16 * 64];   // x tile [32][XS] (13.8 KB), later the 16 KB reduce buffer
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int t = blockIdx.x * 128 + w * 32 + r;
+    const int t = blockIdx.x * 32 + r;
     const bool tok = t < a.T;
-    const int nft = a.F / 32 / gridDim.y;       // f-tiles of this workgroup
-    const int ft0 = blockIdx.y * nft;
+    const int ft0 = (blockIdx.y * 2 + w) * a.units;
 
-    // zero the LDS pad that GEMM1 reads as k = 100..103 (W1 tile columns 100..107; W2 tile rows 100..127)
-    for (int i = tid; i < 2 * 32 * 8; i += 256) {
-        const int buf = i / 256, rem = i % 256;
-        smem[buf * STAGE + (rem >> 3) * S1 + 100 + (rem & 7)] = 0.f;
-    }
-    for (int i = tid; i < 2 * 28 * S2; i += 256) {
-        const int buf = i / (28 * S2), rem = i % (28 * S2);
-        smem[buf * STAGE + W1_FLOATS + 100 * S2 + rem] = 0.f;
-    }
-
-    // B operand of GEMM1: this lane's token row, k = 8g + 4h + j
-    float xf[KG][4];
+    // stage the x tile (32 tokens x 100, zero-padded to 108 columns; rows beyond T zero)
+    {
+        constexpr int NV = 32 * (XS / 4);                 // 864 float4
 #pragma unroll
-    for (int g = 0; g < KG; ++g) {
-        const int k = 8 * g + 4 * h;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tok && k < FE) v = *reinterpret_cast<const float4*>(a.x + (size_t)t * FE + k);
-        xf[g][0] = v.x; xf[g][1] = v.y; xf[g][2] = v.z; xf[g][3] = v.w;
+        for (int j = 0; j < (NV + 127) / 128; ++j) {
+            const int i = tid + 128 * j;
+            if (i < NV) {
+                const int row = i / (XS / 4), c4 = (i - row * (XS / 4)) * 4;
+                const int tt = blockIdx.x * 32 + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (tt < a.T && c4 < FE) v = *reinterpret_cast<const float4*>(a.x + (size_t)tt * FE + c4);
+                *reinterpret_cast<float4*>(smem + row * XS + c4) = v;
+            }
+        }
     }
 
     floatx16 acc2[ET];
@@ -87,68 +124,61 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc2[e][i] = 0.f;
 
-    // register staging of one weight tile pair: 800 + 800 float4 over 256 threads
-    float4 s1[4], s2[4];
-    float sb = 0.f;
-    auto gload = [&](int ft) {
-        const int f0 = ft * 32;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = tid + 256 * j;
-            s1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            s2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < 800) {
-                s1[j] = *reinterpret_cast<const float4*>(a.w1 + (size_t)(f0 + i / 25) * FE + (i % 25) * 4);
-                s2[j] = *reinterpret_cast<const float4*>(a.w2 + (size_t)(i >> 3) * a.F + f0 + (i & 7) * 4);
-            }
-        }
-        if (!BWD && tid < 32) sb = a.b1[f0 + tid];
-    };
-    auto sstore = [&](int buf) {
-        float* W1s = smem + buf * STAGE;
-        float* W2s = W1s + W1_FLOATS;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = tid + 256 * j;
-            if (i < 800) {
-                *reinterpret_cast<float4*>(W1s + (i / 25) * S1 + (i % 25) * 4) = s1[j];
-                *reinterpret_cast<float4*>(W2s + (i >> 3) * S2 + (i & 7) * 4) = s2[j];
-            }
-        }
-        if (!BWD && tid < 32) W2s[W2_FLOATS + tid] = sb;
-    };
-
     DropCtx dc;
     if (!BWD) dc = make_drop(a.rng, a.rng_add, a.site, a.p, a.train);
 
-    gload(ft0);
-    sstore(0);
-    __syncthreads();
+    const float4* pk = a.packed + (size_t)ft0 * UNIT_VEC + lane;
+    float4 w1f[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) w1f[g] = pk[g * 64];
+    __syncthreads();                                      // x tile staged
 
-    for (int j = 0; j < nft; ++j) {
+    for (int j = 0; j < a.units; ++j) {
         const int f0 = (ft0 + j) * 32;
-        if (j + 1 < nft) gload(ft0 + j + 1);
-        const float* W1s = smem + (j & 1) * STAGE;
-        const float* W2s = W1s + W1_FLOATS;
-        const float* b1s = W2s + W2_FLOATS;
+        // GEMM2's A fragments of this unit, hidden-unit groups gq = 0, 1: in flight under GEMM1 (gq = 2, 3 follow under
+        // GEMM2's first half — holding all 16 vectors at once would spill)
+        float4 wA[ET], wB[ET], wC[ET];
+#pragma unroll
+        for (int e = 0; e < ET; ++e) {
+            wA[e] = pk[G1_VEC + (e * 4 + 0) * 64];
+            wB[e] = pk[G1_VEC + (e * 4 + 1) * 64];
+        }
+        const float4* pk2 = pk + G1_VEC;
 
         // ---- GEMM1: hidden tile (32 hidden units x 32 tokens), K = 100 (13 groups of 8, last half zero)
         floatx16 acc1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
+        {
+            // x fragments in chunks of 4 groups, one chunk ahead of the MFMAs (all 13 at once would cost 52 registers)
+            const float* xrow = smem + r * XS + 4 * h;
+            float4 xa[4], xn[4];
 #pragma unroll
-        for (int g = 0; g < KG; ++g) {
-            float af[4];
-            if (!BWD) {
-                const float4 q = *reinterpret_cast<const float4*>(W1s + r * S1 + 8 * g + 4 * h);
-                af[0] = q.x; af[1] = q.y; af[2] = q.z; af[3] = q.w;
-            } else {
+            for (int i = 0; i < 4; ++i) xa[i] = *reinterpret_cast<const float4*>(xrow + 8 * i);
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) af[jj] = W2s[(8 * g + 4 * h + jj) * S2 + r];
+            for (int g0 = 0; g0 < KG; g0 += 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (g0 + 4 + i < KG) xn[i] = *reinterpret_cast<const float4*>(xrow + 8 * (g0 + 4 + i));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (g0 + i < KG) {
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1f[g0 + i].x, xa[i].x, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1f[g0 + i].y, xa[i].y, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1f[g0 + i].z, xa[i].z, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1f[g0 + i].w, xa[i].w, acc1, 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xa[i] = xn[i];
             }
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj], xf[g][jj], acc1, 0, 0, 0);
         }
+        // next unit's GEMM1 fragments: in flight under the epilogue and GEMM2 (the last unit re-reads its own: harmless)
+        pk += (j + 1 < a.units) ? UNIT_VEC : 0;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) w1f[g] = pk[g * 64];
 
         // ---- epilogue 1 in registers: register i <-> hidden unit f0 + krow(i, h), this lane's token
         if (!BWD) {
@@ -163,63 +193,73 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnArgs a) {
                     philox4((uint32_t)(t >> 2) * (uint32_t)a.F + (uint32_t)f, dc.site, dc.o0, dc.o1, dc.k0, dc.k1, wd);
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (wd[q] >= dc.thr) mine |= 1u << (gq * 4 + q);
+                        mine |= (wd[q] >= dc.thr ? 1u : 0u) << (gq * 4 + q);
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) mq[q] = __shfl(mine, (lane & ~3) | q, 64);
+                mq[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0x00, 0xF, 0xF, true);
+                mq[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0x55, 0xF, 0xF, true);
+                mq[2] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xAA, 0xF, 0xF, true);
+                mq[3] = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xFF, 0xF, 0xF, true);
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = fmaxf(acc1[i] + b1s[krow(i, h)], 0.f);
-                const bool keep = (mq[i & 3] >> ((i >> 2) * 4 + (lane & 3))) & 1u;
-                acc1[i] = keep ? v * dc.scale : 0.f;
-            }
-            if (a.h != nullptr && tok) {
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 bb = *reinterpret_cast<const float4*>(a.b1 + f0 + 8 * gq + 4 * h);
+                const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq)
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 4 * gq + q;
+                    const float v = fmaxf(acc1[i] + bv[q], 0.f);
+                    const bool keep = (mq[q] >> (gq * 4 + (lane & 3))) & 1u;
+                    acc1[i] = keep ? v * dc.scale : 0.f;
+                }
+                if (a.h != nullptr && tok)
                     *reinterpret_cast<float4*>(a.h + (size_t)t * a.F + f0 + 8 * gq + 4 * h) =
                         make_float4(acc1[4 * gq], acc1[4 * gq + 1], acc1[4 * gq + 2], acc1[4 * gq + 3]);
             }
         } else {
+            float4 hv[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                hv[gq] = *reinterpret_cast<const float4*>(a.h + (size_t)min(t, a.T - 1) * a.F + f0 + 8 * gq + 4 * h);
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (tok) hv = *reinterpret_cast<const float4*>(a.h + (size_t)t * a.F + f0 + 8 * gq + 4 * h);
-                acc1[4 * gq + 0] = hv.x > 0.f ? acc1[4 * gq + 0] * a.mscale : 0.f;
-                acc1[4 * gq + 1] = hv.y > 0.f ? acc1[4 * gq + 1] * a.mscale : 0.f;
-                acc1[4 * gq + 2] = hv.z > 0.f ? acc1[4 * gq + 2] * a.mscale : 0.f;
-                acc1[4 * gq + 3] = hv.w > 0.f ? acc1[4 * gq + 3] * a.mscale : 0.f;
+                acc1[4 * gq + 0] = hv[gq].x > 0.f ? acc1[4 * gq + 0] * a.mscale : 0.f;
+                acc1[4 * gq + 1] = hv[gq].y > 0.f ? acc1[4 * gq + 1] * a.mscale : 0.f;
+                acc1[4 * gq + 2] = hv[gq].z > 0.f ? acc1[4 * gq + 2] * a.mscale : 0.f;
+                acc1[4 * gq + 3] = hv[gq].w > 0.f ? acc1[4 * gq + 3] * a.mscale : 0.f;
                 if (tok)
                     *reinterpret_cast<float4*>(a.dh + (size_t)t * a.F + f0 + 8 * gq + 4 * h) =
                         make_float4(acc1[4 * gq], acc1[4 * gq + 1], acc1[4 * gq + 2], acc1[4 * gq + 3]);
             }
         }
 
-        // ---- GEMM2: yT[e][t] += sum over this tile's 32 hidden units; B operand = acc1 registers
+        // ---- GEMM2: yT[e][t] += sum over this tile's 32 hidden units; B operand = acc1 registers.  Consecutive MFMAs
+        // share the B register (only A changes): the issue pattern the fp32 MFMA sustains at full rate.
+#define GF_FFN_G2(W, GQ)                                                                                                   \
+        _Pragma("unroll") for (int e = 0; e < ET; ++e) acc2[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(W[e].x, acc1[4 * (GQ) + 0], acc2[e], 0, 0, 0); \
+        _Pragma("unroll") for (int e = 0; e < ET; ++e) acc2[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(W[e].y, acc1[4 * (GQ) + 1], acc2[e], 0, 0, 0); \
+        _Pragma("unroll") for (int e = 0; e < ET; ++e) acc2[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(W[e].z, acc1[4 * (GQ) + 2], acc2[e], 0, 0, 0); \
+        _Pragma("unroll") for (int e = 0; e < ET; ++e) acc2[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(W[e].w, acc1[4 * (GQ) + 3], acc2[e], 0, 0, 0);
 #pragma unroll
-        for (int e = 0; e < ET; ++e) {
+        for (int e = 0; e < ET; ++e) wC[e] = pk2[(e * 4 + 2) * 64];
+        GF_FFN_G2(wA, 0)
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                float af[4];
-                if (!BWD) {
-                    const float4 q = *reinterpret_cast<const float4*>(W2s + (32 * e + r) * S2 + 8 * gq + 4 * h);
-                    af[0] = q.x; af[1] = q.y; af[2] = q.z; af[3] = q.w;
-                } else {
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) af[jj] = W1s[krow(4 * gq + jj, h) * S1 + 32 * e + r];
-                }
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                    acc2[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj], acc1[4 * gq + jj], acc2[e], 0, 0, 0);
-            }
-        }
-
-        if (j + 1 < nft) sstore((j + 1) & 1);
-        __syncthreads();
+        for (int e = 0; e < ET; ++e) wA[e] = pk2[(e * 4 + 3) * 64];
+        GF_FFN_G2(wB, 1)
+        GF_FFN_G2(wC, 2)
+        GF_FFN_G2(wA, 3)
+#undef GF_FFN_G2
     }
 
-    // ---- partial output slab of this F split: register i of tile e <-> column 32e + krow(i, h), this lane's token
-    if (tok) {
+    // ---- sum the two waves' partial outputs through LDS (fixed order: wave 0 + wave 1), then the slab store
+    __syncthreads();                                      // both waves are done reading the x tile
+    if (w == 1) {
+#pragma unroll
+        for (int e = 0; e < ET; ++e)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) smem[(e * 16 + i) * 64 + lane] = acc2[e][i];
+    }
+    __syncthreads();
+    if (w == 0 && tok) {
         float* out = a.slabs + (size_t)blockIdx.y * a.slab_stride + (size_t)t * FE;
 #pragma unroll
         for (int e = 0; e < ET; ++e) {
@@ -227,7 +267,10 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnArgs a) {
             for (int gq = 0; gq < 4; ++gq) {
                 const int e0 = 32 * e + 8 * gq + 4 * h;
                 if (e0 < FE) {
-                    float4 v = make_float4(acc2[e][4 * gq], acc2[e][4 * gq + 1], acc2[e][4 * gq + 2], acc2[e][4 * gq + 3]);
+                    float4 v = make_float4(acc2[e][4 * gq] + smem[(e * 16 + 4 * gq) * 64 + lane],
+                                           acc2[e][4 * gq + 1] + smem[(e * 16 + 4 * gq + 1) * 64 + lane],
+                                           acc2[e][4 * gq + 2] + smem[(e * 16 + 4 * gq + 2) * 64 + lane],
+                                           acc2[e][4 * gq + 3] + smem[(e * 16 + 4 * gq + 3) * 64 + lane]);
                     if (!BWD && blockIdx.y == 0) {
                         const float4 bb = *reinterpret_cast<const float4*>(a.b2 + e0);
                         v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
@@ -239,51 +282,57 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnArgs a) {
     }
 }
 
-bool ffn_fused_supported(int E, int F) { return E == FE && F >= 512 && (F % 512) == 0; }
+bool ffn_fused_supported(int E, int F) { return E == FE && F >= 256 && (F % 256) == 0; }
 
-// number of F splits (= slabs written): 16 keeps >= ~1.4 workgroups per CU at T = 3008
-int ffn_fused_splits(int T, int F) {
-    int s = 16;
-    while (s > 1 && (F / 32) % s != 0) s >>= 1;
-    return s;
-}
+// f-tiles per wave: 2 below ~4096 tokens (T = 3008: 3008 waves, 2.94 per SIMD), 4 above (T = 6016: again 3008 waves)
+static int ffn_units(int T) { return T <= 4096 ? 2 : 4; }
+int ffn_fused_splits(int T, int F) { return F / 32 / (2 * ffn_units(T)); }
 
-static int launch_ffn(const FfnArgs& a, int splits, int bwd, hipStream_t st) {
-    const size_t lds = 2 * STAGE * sizeof(float);
-    dim3 grid((a.T + 127) / 128, splits);
-    if (bwd) {
-        GF_TRY((lds_optin<ffn_fused_kernel<1>>(lds, "ffn")));
-        hipLaunchKernelGGL(ffn_fused_kernel<1>, grid, dim3(256), lds, st, a);
-    } else {
-        GF_TRY((lds_optin<ffn_fused_kernel<0>>(lds, "ffn")));
-        hipLaunchKernelGGL(ffn_fused_kernel<0>, grid, dim3(256), lds, st, a);
-    }
+long ffn_pack_floats(int F) { return (long)(F / 32) * UNIT_VEC * 4; }
+
+// pack linear1 / linear2 of L consecutive layers (fwd or bwd orientation) into packed[L][ffn_pack_floats(F)]
+int launch_ffn_pack(const float* params, long layer_stride, long off_w1, long off_w2, float* packed, int L, int F, int bwd,
+                    hipStream_t st) {
+    GF_CHECK_ARG(params && packed && aligned16(packed) && L >= 1, "ffn_pack: bad arguments");
+    const int nvec = (F / 32) * UNIT_VEC;
+    hipLaunchKernelGGL(ffn_pack_kernel, dim3((nvec + 255) / 256, L), dim3(256), 0, st, params, layer_stride, off_w1, off_w2,
+                       reinterpret_cast<float4*>(packed), F, bwd, nvec);
     GF_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h,
-                         float* slabs, long slab_stride, int T, int E, int F, float p, uint32_t site, const uint64_t* rng,
-                         uint64_t add, int train, int* splits_out, hipStream_t st) {
+static int launch_ffn(const FfnArgs& a, int splits, int bwd, hipStream_t st) {
+    dim3 grid((a.T + 31) / 32, splits);
+    if (bwd) hipLaunchKernelGGL(ffn_fused_kernel<1>, grid, dim3(128), 0, st, a);
+    else hipLaunchKernelGGL(ffn_fused_kernel<0>, grid, dim3(128), 0, st, a);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_ffn_fused_fwd(const float* x, const float* packed, const float* b1, const float* b2, float* h, float* slabs,
+                         long slab_stride, int T, int E, int F, float p, uint32_t site, const uint64_t* rng, uint64_t add,
+                         int train, int* splits_out, hipStream_t st) {
     GF_CHECK_ARG(ffn_fused_supported(E, F), "ffn_fused: unsupported E=%d F=%d", E, F);
-    GF_CHECK_ARG(x && w1 && b1 && w2 && b2 && slabs && T > 0, "ffn_fused_fwd: null pointer");
-    GF_CHECK_ARG(aligned16(x) && aligned16(w1) && aligned16(w2) && aligned16(b2) && aligned16(slabs) && (!h || aligned16(h)),
+    GF_CHECK_ARG(x && packed && b1 && b2 && slabs && T > 0, "ffn_fused_fwd: null pointer");
+    GF_CHECK_ARG(aligned16(x) && aligned16(packed) && aligned16(b1) && aligned16(b2) && aligned16(slabs) && (!h || aligned16(h)),
                  "ffn_fused_fwd: 16-byte alignment required");
     GF_CHECK_ARG(!(train && p > 0.f) || rng, "ffn_fused_fwd: rng required when dropout is active");
     const int splits = ffn_fused_splits(T, F);
-    FfnArgs a{x, w1, b1, w2, b2, h, nullptr, slabs, slab_stride, T, F, 1.f, p, site, rng, add, train};
+    FfnArgs a{x, reinterpret_cast<const float4*>(packed), b1, b2, h, nullptr, slabs, slab_stride, T, F, ffn_units(T), 1.f, p, site,
+              rng, add, train};
     *splits_out = splits;
     return launch_ffn(a, splits, 0, st);
 }
 
-int launch_ffn_fused_bwd(const float* dy, const float* w1, const float* w2, const float* h, float* dh, float* slabs,
-                         long slab_stride, int T, int E, int F, float mscale, int* splits_out, hipStream_t st) {
+int launch_ffn_fused_bwd(const float* dy, const float* packed, const float* h, float* dh, float* slabs, long slab_stride, int T,
+                         int E, int F, float mscale, int* splits_out, hipStream_t st) {
     GF_CHECK_ARG(ffn_fused_supported(E, F), "ffn_fused: unsupported E=%d F=%d", E, F);
-    GF_CHECK_ARG(dy && w1 && w2 && h && dh && slabs && T > 0, "ffn_fused_bwd: null pointer");
-    GF_CHECK_ARG(aligned16(dy) && aligned16(w1) && aligned16(w2) && aligned16(h) && aligned16(dh) && aligned16(slabs),
+    GF_CHECK_ARG(dy && packed && h && dh && slabs && T > 0, "ffn_fused_bwd: null pointer");
+    GF_CHECK_ARG(aligned16(dy) && aligned16(packed) && aligned16(h) && aligned16(dh) && aligned16(slabs),
                  "ffn_fused_bwd: 16-byte alignment required");
     const int splits = ffn_fused_splits(T, F);
-    FfnArgs a{dy, w1, nullptr, w2, nullptr, const_cast<float*>(h), dh, slabs, slab_stride, T, F, mscale, 0.f, 0, nullptr, 0, 0};
+    FfnArgs a{dy, reinterpret_cast<const float4*>(packed), nullptr, nullptr, const_cast<float*>(h), dh, slabs, slab_stride, T, F,
+              ffn_units(T), mscale, 0.f, 0, nullptr, 0, 0};
     *splits_out = splits;
     return launch_ffn(a, splits, 1, st);
 }

@@ -420,10 +420,17 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(float* __restrict__ C, f
                                                         int nS, int ldc, int N) {
     const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 < nC) {                                     // nC = M * N, N % 4 == 0: a float4 stays inside one row
-        float4 s = *reinterpret_cast<const float4*>(part + i4);
-        for (int z = 1; z < splits; ++z) {
-            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)z * part_stride + i4);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        // slabs in split order; 8 loads in flight at a time (a plain loop waits for every load before the next)
+        for (int z0 = 0; z0 < splits; z0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(part + (size_t)min(z0 + u, splits - 1) * part_stride + i4);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float m = (z0 + u < splits) ? 1.f : 0.f;
+                s.x += m * v[u].x; s.y += m * v[u].y; s.z += m * v[u].z; s.w += m * v[u].w;
+            }
         }
         const long row = i4 / N, col = i4 - row * N;
         float* dst = C + row * ldc + col;

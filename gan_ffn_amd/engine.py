@@ -440,7 +440,7 @@ class GanEngine(_Runner):
         if Dn.has_obj:
             self.d_real.copy_(pd.dx[:, :B])                      # gradient of the real half of the batch
             ops.linear_bwd_raw(self.d_real, batch[who], Dn.w("object.weight"), None, Dn.w("object.weight", True),
-                               Dn.w("object.bias", True), S * B, Dn.obj_in, self.D_h)
+                               Dn.w("object.bias", True), S * B, Dn.obj_in, self.D_h, self.ws)
             if cb is not None:
                 cb(Dn.enc_floats, Dn.enc_floats + Dn.obj_floats, last=True)
         finish()
@@ -696,7 +696,7 @@ class Phase2Engine(GanEngine):
         if train:
             self.fc_grad.zero_()
             ops.linear_bwd_raw(self.dlogits, self.fusion, self.fc_w, self.d_fusion, self.fc_grad[:self.fc_w.numel()],
-                               self.fc_grad[self.fc_off_b:], T, 100, C_)
+                               self.fc_grad[self.fc_off_b:], T, 100, C_, self.ws)
             for k in ("acoustic", "visual", "text"):
                 net = self.G[k]
                 net.grad.zero_()

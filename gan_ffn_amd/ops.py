@@ -141,8 +141,10 @@ def linear_fwd_raw(x, w, b, y, T, K, N):
     _lib.call("ganffn_linear_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(y), T, K, N, _stream())
 
 
-def linear_bwd_raw(dy, x, w, dx, gw, gb, T, K, N):
-    _lib.call("ganffn_linear_bwd", _ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(gw), _ptr(gb), T, K, N, _stream())
+def linear_bwd_raw(dy, x, w, dx, gw, gb, T, K, N, ws=None):
+    """ws: optional scratch tensor (any size; used for the split weight-gradient GEMM when large enough)"""
+    _lib.call("ganffn_linear_bwd", _ptr(dy), _ptr(x), _ptr(w), _ptr(dx), _ptr(gw), _ptr(gb), T, K, N, _ptr(ws),
+              C.c_int64(ws.numel() if ws is not None else 0), _stream())
 
 
 def bce_fwd_raw(prob, target, n, scale, loss, accumulate):

@@ -133,9 +133,12 @@ int ganffn_head_bwd(const ganffn_head_cfg* cfg, const float* d_out, const float*
 /* ---- plain Linear (VisualDiscriminator.object model.py:1355-1356; GAN_FFN.fc model.py:1448) */
 int ganffn_linear_fwd(const float* x, const float* w, const float* b, float* y, int T, int K, int N,
                       void* stream);
-/* dx may be NULL; gw/gb accumulated when non-NULL */
+/* dx may be NULL; gw/gb accumulated (+=) when non-NULL.  workspace (may be NULL; ganffn_linear_bwd_workspace_floats
+ * floats, 16-byte aligned) lets the weight gradient split the token range over more workgroups; the partial results are
+ * reduced in a fixed order, so the result is bit-reproducible with or without it. */
+int64_t ganffn_linear_bwd_workspace_floats(int T, int K, int N);
 int ganffn_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* gw,
-                      float* gb, int T, int K, int N, void* stream);
+                      float* gb, int T, int K, int N, float* workspace, int64_t workspace_floats, void* stream);
 
 /* ---- A10: BCELoss(mean) (train_IEMOCAP.py:300,220-223,248) -------------------------- */
 /* loss_out[0] (+)= scale * mean_i( -(y*max(log p,-100) + (1-y)*max(log(1-p),-100)) ), y = target.
@@ -199,13 +202,18 @@ int ganffn_ffn_linear1_fwd(const float* x, const float* w1, const float* b1, flo
                            float p, uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, int train,
                            void* stream);
 /* Fused feed-forward block for d_model = 100 (ffn.hip): linear1 + ReLU + dropout + linear2 in one kernel, and its
- * dgrad chain.  The output is returned as partial slabs slabs[s][T x E], s < nslab, to be summed by the caller
- * (the LayerNorm kernels do it on the fly).  Test hook: on success these two return -(1000 + nslab). */
+ * dgrad chain (torch TransformerEncoderLayer._ff_block behind model.py:1210).  The kernels read the two weights from a
+ * copy packed in MFMA fragment order; these hooks pack w1 [F x E] / w2 [E x F] into pack_ws (ganffn_ffn_pack_floats(F)
+ * floats, 16-byte aligned) first, which is what ganffn_encoder_fwd / _bwd do once per pass for all layers.  The output is
+ * returned as partial slabs slabs[s][T x E], s < nslab, to be summed by the caller (the LayerNorm kernels do it on the
+ * fly).  Test hooks: on success these two return -(1000 + nslab). */
+int64_t ganffn_ffn_pack_floats(int F);
 int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
-                         float* h /* [T x F] or NULL */, float* slabs /* [16][T x E] */, int T, int E, int F, float p,
-                         uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, int train, void* stream);
+                         float* h /* [T x F] or NULL */, float* slabs /* [16][T x E] */, float* pack_ws, int T, int E,
+                         int F, float p, uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, int train,
+                         void* stream);
 int ganffn_ffn_fused_bwd(const float* dy, const float* w1, const float* w2, const float* h, float* dh,
-                         float* slabs, int T, int E, int F, float mscale, void* stream);
+                         float* slabs, float* pack_ws, int T, int E, int F, float mscale, void* stream);
 /* n (<= 40) independent problems C_i[M_i x N_i] += At_i[K_i x M_i]^T B_i[K_i x N_i] (+ column sums) in ONE launch: the
  * deferred weight-gradient GEMMs of all encoder layers of a backward pass (dense leading dimensions) */
 int ganffn_gemm_tn_grouped(int n, const float* const* At, const float* const* Bm, float* const* C,
@@ -233,8 +241,9 @@ int ganffn_add_dropout_layernorm_bwd(const float* d_out, const float* xhat, cons
 int ganffn_dropout(const float* x, float* out, int R, int C, float p, uint32_t site,
                    const uint64_t* rng, uint64_t rng_offset_add, void* stream);
 
-/* which encoder FFN passes use the fused kernel: bit 0 forward (saving h), bit 1 forward (inference), bit 2 backward */
-int ganffn_debug_set_ffn_mode(int bits);
+/* A/B measurement hook (process-wide): 0 = run the d_model-100 feed-forward block as two GEMMs instead of the fused
+ * kernel (the default, non-zero).  Both paths are parity-tested; results agree to rounding. */
+int ganffn_debug_set_ffn_mode(int fused);
 
 #ifdef __cplusplus
 }

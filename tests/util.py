@@ -94,7 +94,7 @@ def _assert_close(t, ref, rtol, atol, label, outlier_frac=0.02, outlier_mult=100
     return err.max() / scale
 
 
-def check_summary(g, prefix, t, rtol=1e-4, atol=1e-5, what="", strict=False, outlier_frac=0.02):
+def check_summary(g, prefix, t, rtol=1e-4, atol=1e-5, what="", strict=False, outlier_frac=0.02, l2_rtol=1e-3):
     """compare tensor `t` with the fixture summary stored under prefix/..."""
     t = np.asarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t, dtype=np.float64)
     kw = dict(outlier_frac=0.0, outlier_mult=1.0) if strict else dict(outlier_frac=outlier_frac)
@@ -107,5 +107,5 @@ def check_summary(g, prefix, t, rtol=1e-4, atol=1e-5, what="", strict=False, out
     ref = g[prefix + "/sample"].astype(np.float64)
     r = _assert_close(flat[idx], ref, rtol, atol, "%s %s (sample)" % (what, prefix), **kw)
     l2 = float(g[prefix + "/l2"])
-    assert abs(np.sqrt((flat ** 2).sum()) - l2) <= 1e-3 * max(l2, 1e-30) + atol, (what, prefix, "l2")
+    assert abs(np.sqrt((flat ** 2).sum()) - l2) <= l2_rtol * max(l2, 1e-30) + atol, (what, prefix, "l2")
     return r
