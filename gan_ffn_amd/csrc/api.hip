@@ -94,9 +94,12 @@ static int check_cfg(const ganffn_enc_cfg* c) {
     return 0;
 }
 
-// d_model = 100 feed-forward block: the fused kernel (ffn.hip) unless switched off (A/B measurement hook
-// ganffn_debug_set_ffn_mode; both paths are parity-tested)
-int g_ffn_fused = 1;
+// d_model = 100 feed-forward block: two GEMMs (default) or the fused kernel of ffn.hip (ganffn_debug_set_ffn_mode(1)).
+// Both paths are parity-tested.  Measured on MI355X, in-step, single stream (profiles/README.md): fused 48 / 52 us
+// (forward / dgrad, T = 3008) and 88 / 93 us (T = 6016) against 52 / 50 us and 74 / 75 us for the GEMM pairs — the fused
+// kernel streams 30 KB of packed weights per (32 tokens x 32 hidden units) and is bound by L2 -> CU bandwidth
+// (357 MB per launch at T = 6016), so it stays opt-in.
+int g_ffn_fused = 0;
 constexpr int MAX_SPLITS = 16;  // partial-output slabs: fused FFN (16 F splits) / split-K GEMMs (<= 8)
 
 static int64_t a4(int64_t n) { return (n + 3) & ~int64_t(3); }

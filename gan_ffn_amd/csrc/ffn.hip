@@ -96,26 +96,44 @@ struct FfnArgs {
 
 template <int BWD>
 __global__ __launch_bounds__(128, 2) void ffn_fused_kernel(FfnArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[ET * 16 * 64];   // x tile [32][XS] (13.8 KB), later the 16 KB reduce buffer
+    // x tile [32][XS] (13.8 KB), later the 16 KB reduce buffer | linear1 bias of this workgroup's hidden range (<= 256)
+    __shared__ __attribute__((aligned(16))) float smem[ET * 16 * 64 + 256];
+    float* const bias_s = smem + ET * 16 * 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
     const int t = blockIdx.x * 32 + r;
     const bool tok = t < a.T;
     const int ft0 = (blockIdx.y * 2 + w) * a.units;
 
-    // stage the x tile (32 tokens x 100, zero-padded to 108 columns; rows beyond T zero)
+    // stage the x tile (32 tokens x 100, zero-padded to 108 columns; rows beyond T zero): all loads are issued from
+    // clamped addresses before the first LDS write (a load under a branch is waited for on the spot)
     {
-        constexpr int NV = 32 * (XS / 4);                 // 864 float4
+        constexpr int NV = 32 * (XS / 4), NJ = (NV + 127) / 128;      // 864 float4, 7 per thread
+        float4 v[NJ];
 #pragma unroll
-        for (int j = 0; j < (NV + 127) / 128; ++j) {
+        for (int j = 0; j < NJ; ++j) {
+            const int i = min(tid + 128 * j, NV - 1);
+            const int row = i / (XS / 4), c4 = (i - row * (XS / 4)) * 4;
+            const int tt = blockIdx.x * 32 + row;
+            const float4 q = *reinterpret_cast<const float4*>(a.x + (size_t)min(tt, a.T - 1) * FE + min(c4, FE - 4));
+            const float m = (tt < a.T && c4 < FE) ? 1.f : 0.f;
+            v[j] = make_float4(q.x * m, q.y * m, q.z * m, q.w * m);
+        }
+        float bv0 = 0.f, bv1 = 0.f;
+        if (!BWD) {      // this workgroup's 2 * units * 32 bias values (units <= 4)
+            const int nb = 2 * a.units * 32, fb = blockIdx.y * nb;
+            bv0 = a.b1[fb + min(tid, nb - 1)];
+            bv1 = a.b1[fb + min(tid + 128, nb - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
             const int i = tid + 128 * j;
-            if (i < NV) {
+            if (NV % 128 == 0 || i < NV) {
                 const int row = i / (XS / 4), c4 = (i - row * (XS / 4)) * 4;
-                const int tt = blockIdx.x * 32 + row;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (tt < a.T && c4 < FE) v = *reinterpret_cast<const float4*>(a.x + (size_t)tt * FE + c4);
-                *reinterpret_cast<float4*>(smem + row * XS + c4) = v;
+                *reinterpret_cast<float4*>(smem + row * XS + c4) = v[j];
             }
         }
+        bias_s[tid] = bv0;
+        bias_s[tid + 128] = bv1;
     }
 
     floatx16 acc2[ET];
@@ -126,6 +144,7 @@ __global__ __launch_bounds__(128, 2) void ffn_fused_kernel(FfnArgs a) {
 
     DropCtx dc;
     if (!BWD) dc = make_drop(a.rng, a.rng_add, a.site, a.p, a.train);
+    const bool store_h = !BWD && a.h != nullptr && tok;
 
     const float4* pk = a.packed + (size_t)ft0 * UNIT_VEC + lane;
     float4 w1f[KG];
@@ -135,15 +154,23 @@ __global__ __launch_bounds__(128, 2) void ffn_fused_kernel(FfnArgs a) {
 
     for (int j = 0; j < a.units; ++j) {
         const int f0 = (ft0 + j) * 32;
-        // GEMM2's A fragments of this unit, hidden-unit groups gq = 0, 1: in flight under GEMM1 (gq = 2, 3 follow under
-        // GEMM2's first half — holding all 16 vectors at once would spill)
-        float4 wA[ET], wB[ET], wC[ET];
+        // Everything this unit's epilogue and the first half of GEMM2 will need is requested BEFORE GEMM1 and pinned there
+        // (left to itself hipcc sinks the loads to their first use, exposing a full memory round trip each):
+        //   GEMM2's A fragments of hidden-unit groups gq = 0, 1 (gq = 2, 3 follow under GEMM2's first half — all 16
+        //   vectors at once would spill), and the backward epilogue's operand, the saved h tile (linear1's bias sits in LDS)
+        float4 wA[ET], wB[ET], wC[ET], aux[4];
 #pragma unroll
         for (int e = 0; e < ET; ++e) {
             wA[e] = pk[G1_VEC + (e * 4 + 0) * 64];
             wB[e] = pk[G1_VEC + (e * 4 + 1) * 64];
         }
+        if (BWD) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                aux[gq] = *reinterpret_cast<const float4*>(a.h + (size_t)min(t, a.T - 1) * a.F + f0 + 8 * gq + 4 * h);
+        }
         const float4* pk2 = pk + G1_VEC;
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- GEMM1: hidden tile (32 hidden units x 32 tokens), K = 100 (13 groups of 8, last half zero)
         floatx16 acc1;
@@ -179,6 +206,7 @@ __global__ __launch_bounds__(128, 2) void ffn_fused_kernel(FfnArgs a) {
         pk += (j + 1 < a.units) ? UNIT_VEC : 0;
 #pragma unroll
         for (int g = 0; g < KG; ++g) w1f[g] = pk[g * 64];
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- epilogue 1 in registers: register i <-> hidden unit f0 + krow(i, h), this lane's token
         if (!BWD) {
@@ -202,8 +230,8 @@ __global__ __launch_bounds__(128, 2) void ffn_fused_kernel(FfnArgs a) {
             }
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const float4 bb = *reinterpret_cast<const float4*>(a.b1 + f0 + 8 * gq + 4 * h);
-                const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+                const float4 bq = *reinterpret_cast<const float4*>(bias_s + (w * a.units + j) * 32 + 8 * gq + 4 * h);
+                const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int i = 4 * gq + q;
@@ -211,21 +239,23 @@ __global__ __launch_bounds__(128, 2) void ffn_fused_kernel(FfnArgs a) {
                     const bool keep = (mq[q] >> (gq * 4 + (lane & 3))) & 1u;
                     acc1[i] = keep ? v * dc.scale : 0.f;
                 }
-                if (a.h != nullptr && tok)
+            }
+            if (store_h) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
                     *reinterpret_cast<float4*>(a.h + (size_t)t * a.F + f0 + 8 * gq + 4 * h) =
                         make_float4(acc1[4 * gq], acc1[4 * gq + 1], acc1[4 * gq + 2], acc1[4 * gq + 3]);
             }
         } else {
-            float4 hv[4];
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-                hv[gq] = *reinterpret_cast<const float4*>(a.h + (size_t)min(t, a.T - 1) * a.F + f0 + 8 * gq + 4 * h);
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                acc1[4 * gq + 0] = hv[gq].x > 0.f ? acc1[4 * gq + 0] * a.mscale : 0.f;
-                acc1[4 * gq + 1] = hv[gq].y > 0.f ? acc1[4 * gq + 1] * a.mscale : 0.f;
-                acc1[4 * gq + 2] = hv[gq].z > 0.f ? acc1[4 * gq + 2] * a.mscale : 0.f;
-                acc1[4 * gq + 3] = hv[gq].w > 0.f ? acc1[4 * gq + 3] * a.mscale : 0.f;
+                acc1[4 * gq + 0] = aux[gq].x > 0.f ? acc1[4 * gq + 0] * a.mscale : 0.f;
+                acc1[4 * gq + 1] = aux[gq].y > 0.f ? acc1[4 * gq + 1] * a.mscale : 0.f;
+                acc1[4 * gq + 2] = aux[gq].z > 0.f ? acc1[4 * gq + 2] * a.mscale : 0.f;
+                acc1[4 * gq + 3] = aux[gq].w > 0.f ? acc1[4 * gq + 3] * a.mscale : 0.f;
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
                 if (tok)
                     *reinterpret_cast<float4*>(a.dh + (size_t)t * a.F + f0 + 8 * gq + 4 * h) =
                         make_float4(acc1[4 * gq], acc1[4 * gq + 1], acc1[4 * gq + 2], acc1[4 * gq + 3]);
@@ -241,9 +271,12 @@ __global__ __launch_bounds__(128, 2) void ffn_fused_kernel(FfnArgs a) {
         _Pragma("unroll") for (int e = 0; e < ET; ++e) acc2[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(W[e].w, acc1[4 * (GQ) + 3], acc2[e], 0, 0, 0);
 #pragma unroll
         for (int e = 0; e < ET; ++e) wC[e] = pk2[(e * 4 + 2) * 64];
+        __builtin_amdgcn_sched_barrier(0);
         GF_FFN_G2(wA, 0)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < ET; ++e) wA[e] = pk2[(e * 4 + 3) * 64];
+        __builtin_amdgcn_sched_barrier(0);
         GF_FFN_G2(wB, 1)
         GF_FFN_G2(wC, 2)
         GF_FFN_G2(wA, 3)
@@ -259,24 +292,30 @@ __global__ __launch_bounds__(128, 2) void ffn_fused_kernel(FfnArgs a) {
             for (int i = 0; i < 16; ++i) smem[(e * 16 + i) * 64 + lane] = acc2[e][i];
     }
     __syncthreads();
-    if (w == 0 && tok) {
-        float* out = a.slabs + (size_t)blockIdx.y * a.slab_stride + (size_t)t * FE;
+    if (w == 0) {
+        // linear2's bias rides on slab 0: loaded for every tile up front (a load inside the store loop would be waited for
+        // together with the stores before it, once per tile)
+        const float bmul = (!BWD && blockIdx.y == 0) ? 1.f : 0.f;
+        float4 bb[ET][4];
+#pragma unroll
+        for (int e = 0; e < ET; ++e)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int e0 = min(32 * e + 8 * gq + 4 * h, FE - 4);
+                bb[e][gq] = BWD ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.b2 + e0);
+            }
+        float* out = a.slabs + (size_t)blockIdx.y * a.slab_stride + (size_t)min(t, a.T - 1) * FE;
 #pragma unroll
         for (int e = 0; e < ET; ++e) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int e0 = 32 * e + 8 * gq + 4 * h;
-                if (e0 < FE) {
-                    float4 v = make_float4(acc2[e][4 * gq] + smem[(e * 16 + 4 * gq) * 64 + lane],
-                                           acc2[e][4 * gq + 1] + smem[(e * 16 + 4 * gq + 1) * 64 + lane],
-                                           acc2[e][4 * gq + 2] + smem[(e * 16 + 4 * gq + 2) * 64 + lane],
-                                           acc2[e][4 * gq + 3] + smem[(e * 16 + 4 * gq + 3) * 64 + lane]);
-                    if (!BWD && blockIdx.y == 0) {
-                        const float4 bb = *reinterpret_cast<const float4*>(a.b2 + e0);
-                        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-                    }
-                    *reinterpret_cast<float4*>(out + e0) = v;
-                }
+                float4 v = make_float4(acc2[e][4 * gq] + smem[(e * 16 + 4 * gq) * 64 + lane],
+                                       acc2[e][4 * gq + 1] + smem[(e * 16 + 4 * gq + 1) * 64 + lane],
+                                       acc2[e][4 * gq + 2] + smem[(e * 16 + 4 * gq + 2) * 64 + lane],
+                                       acc2[e][4 * gq + 3] + smem[(e * 16 + 4 * gq + 3) * 64 + lane]);
+                v.x += bmul * bb[e][gq].x; v.y += bmul * bb[e][gq].y; v.z += bmul * bb[e][gq].z; v.w += bmul * bb[e][gq].w;
+                if (tok && e0 < FE) *reinterpret_cast<float4*>(out + e0) = v;
             }
         }
     }

@@ -241,8 +241,9 @@ int ganffn_add_dropout_layernorm_bwd(const float* d_out, const float* xhat, cons
 int ganffn_dropout(const float* x, float* out, int R, int C, float p, uint32_t site,
                    const uint64_t* rng, uint64_t rng_offset_add, void* stream);
 
-/* A/B measurement hook (process-wide): 0 = run the d_model-100 feed-forward block as two GEMMs instead of the fused
- * kernel (the default, non-zero).  Both paths are parity-tested; results agree to rounding. */
+/* A/B measurement hook (process-wide): non-zero = run the d_model-100 feed-forward block as the fused kernel of ffn.hip
+ * instead of two GEMMs (the default, 0: measured faster in the step).  Both paths are parity-tested; results agree to
+ * rounding. */
 int ganffn_debug_set_ffn_mode(int fused);
 
 #ifdef __cplusplus

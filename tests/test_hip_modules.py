@@ -192,7 +192,7 @@ def test_cpu_tensor_fails_loudly():
 
 @pytest.mark.parametrize("mode", [0, 1])
 def test_fused_ffn_modes_agree_with_fixture(mode):
-    """the encoder's FFN runs as the fused kernel (mode 1, the default) or as two GEMMs (mode 0): both match the reference"""
+    """the encoder's FFN runs as two GEMMs (mode 0, the default) or as the fused kernel (mode 1): both match the reference"""
     from gan_ffn_amd import _lib
     lib = _lib.load()
     lib.ganffn_debug_set_ffn_mode(mode)
@@ -200,4 +200,4 @@ def test_fused_ffn_modes_agree_with_fixture(mode):
         test_module_matches_reference_fixture(("TextGenerator", 100), (110, 3))
         test_train_mode_matches_oracle_with_same_masks("AcousticDiscriminator", 100, 94, 4)
     finally:
-        lib.ganffn_debug_set_ffn_mode(1)
+        lib.ganffn_debug_set_ffn_mode(0)
