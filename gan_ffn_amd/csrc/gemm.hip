@@ -144,12 +144,39 @@ struct Smem {
 
 // Output stage shared by the LDS-tiled and the register-direct kernels: accumulator register i of tile (a, b) holds
 // row mbase + 32a + (i&3) + 8(i>>2) + 4h, column nbase + 32b + r.
+// dropout keep bits of a wave tile: bit 4 gq + q of keep[a][b] <-> accumulator register 4 gq + q (row rb + q of column col).
+// Data-independent, so gemm_body evaluates it while the first operand tiles are still in flight from memory.
+template <int EPI>
+constexpr bool epi_has_dropout() { return EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU || EPI == EPI_GELU_BWD_DROP; }
+
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void gemm_keep_bits(const GemmArgs& g, const DropCtx& dc, uint32_t (&keep)[TM][TN], const int mbase,
+                                               const int nbase, const int r, const int h) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            uint32_t bits = 0xFFFFu;
+            if (epi_has_dropout<EPI>() && dc.on) {
+                bits = 0;
+                const int col = nbase + b * 32 + r;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int rb = mbase + a * 32 + 8 * gq + 4 * h;
+                    uint32_t w[4];
+                    philox4((uint32_t)(rb >> 2) * (uint32_t)g.N + (uint32_t)col, dc.site, dc.o0, dc.o1, dc.k0, dc.k1, w);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bits |= (w[q] >= dc.thr ? 1u : 0u) << (4 * gq + q);
+                }
+            }
+            keep[a][b] = bits;
+        }
+}
+
 template <int EPI, int TM, int TN>
 __device__ __forceinline__ void gemm_store_epilogue(const GemmArgs& g, floatx16 (&acc)[TM][TN], const int mbase, const int nbase,
-                                                    const int bz, const int r, const int h) {
-    DropCtx dc;
-    if (EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU || EPI == EPI_GELU_BWD_DROP)
-        dc = make_drop(g.ea.rng, g.ea.rng_add, g.ea.site, g.ea.p, g.ea.train);
+                                                    const int bz, const int r, const int h, const DropCtx& dc,
+                                                    const uint32_t (&keep)[TM][TN]) {
 
     // Epilogue operand (residual / saved activation): ALL loads of the wave tile are issued first, from clamped
     // (always valid) offsets — a load under the per-element bounds test makes hipcc wait for it before the next
@@ -193,8 +220,10 @@ __device__ __forceinline__ void gemm_store_epilogue(const GemmArgs& g, floatx16 
             for (int gq = 0; gq < 4; ++gq) {
                 const int rb = mbase + a * 32 + 8 * gq + 4 * h;  // 4 consecutive rows rb..rb+3
                 float mult[4] = {1.f, 1.f, 1.f, 1.f};
-                if (EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU || EPI == EPI_GELU_BWD_DROP)
-                    drop_mult4(dc, (uint32_t)(rb >> 2), (uint32_t)g.N, (uint32_t)col, mult);
+                if (epi_has_dropout<EPI>()) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mult[q] = ((keep[a][b] >> (4 * gq + q)) & 1u) ? dc.scale : 0.f;
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = rb + q;
@@ -339,6 +368,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     if constexpr (PD > 1) gload(std::integral_constant<int, 1>{}, 1);
     if constexpr (PD > 2) gload(std::integral_constant<int, 2>{}, 2);
     if constexpr (PD > 3) gload(std::integral_constant<int, 3>{}, 3);
+    // the epilogue's dropout keep bits (Philox: ~70 VALU instructions per call, 4 calls per tile) depend on indices only:
+    // evaluated here, under the latency of the first global loads, instead of on the critical path after the last MFMA
+    DropCtx dc;
+    uint32_t keep[TM][TN];
+    if constexpr (MODE != MODE_TN) {
+        if (epi_has_dropout<EPI>()) dc = make_drop(g.ea.rng, g.ea.rng_add, g.ea.site, g.ea.p, g.ea.train);
+        else dc.on = 0;
+        gemm_keep_bits<EPI, TM, TN>(g, dc, keep, m0 + wm * WM, n0 + wn * WN, r, h);
+    }
     sstore(std::integral_constant<int, 0>{}, 0);
     __syncthreads();
 
@@ -406,7 +444,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
         return;
     }
 
-    gemm_store_epilogue<EPI, TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, bz, r, h);
+    if constexpr (MODE != MODE_TN) gemm_store_epilogue<EPI, TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, bz, r, h, dc, keep);
 }
 
 template <int MODE, int BM, int BN, int BK, int EPI, int WGM = 2, int WGN = 2>
