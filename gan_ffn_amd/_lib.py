@@ -21,6 +21,19 @@ class HeadCfg(C.Structure):
                 ("p", C.c_float), ("train", C.c_int32)]
 
 
+class DrnnCfg(C.Structure):
+    _fields_ = [("S", C.c_int32), ("B", C.c_int32), ("Dm", C.c_int32), ("H", C.c_int32), ("He", C.c_int32),
+                ("p", C.c_float), ("train", C.c_int32)]
+
+
+DRNN_PARAM_FIELDS = ["g_wih", "g_whh", "g_bih", "g_bhh", "p_wih", "p_whh", "p_bih", "p_bhh", "e_wih", "e_whh", "e_bih",
+                     "e_bhh", "att_w"]
+
+
+class DrnnPtrs(C.Structure):        # ganffn_drnn_params / ganffn_drnn_grads: 13 pointers
+    _fields_ = [(n, C.c_void_p) for n in DRNN_PARAM_FIELDS]
+
+
 _P = C.c_void_p
 _I, _L, _F, _U32, _U64 = C.c_int, C.c_int64, C.c_float, C.c_uint32, C.c_uint64
 _PE, _PH = C.POINTER(EncCfg), C.POINTER(HeadCfg)
@@ -67,6 +80,10 @@ SIGNATURES = {
     "ganffn_general2_attention_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ganffn_general2_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ganffn_debug_set_ffn_mode": (_I, [_I]),
+    "ganffn_drnn_saved_floats": (_L, [C.POINTER(DrnnCfg)]),
+    "ganffn_drnn_workspace_floats": (_L, [C.POINTER(DrnnCfg)]),
+    "ganffn_drnn_fwd": (_I, [C.POINTER(DrnnCfg), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _P]),
+    "ganffn_drnn_bwd": (_I, [C.POINTER(DrnnCfg), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _P]),
     "ganffn_dropout": (_I, [_P, _P, _I, _I, _F, _U32, _P, _U64, _P]),
 }
 

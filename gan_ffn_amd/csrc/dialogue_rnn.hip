@@ -1,0 +1,718 @@
+// dialogue_rnn.hip — the DialogueRNN recurrence of BASELINE.json configs[4] (GAN_FFN_DialogueRNN head) on gfx950.
+//
+// Replaces DialogueRNNCell.forward / DialogueRNN.forward (/root/reference/model.py:828-972) in the configuration
+// train_IEMOCAP_DialogueRNN.py runs (:586 --attention general, :595 listener off; dims :634-642: D_m = 100,
+// D_g = D_p = 500, D_e = 100): per utterance step t and dialogue b
+//     g_t  = drop(GRU_g([U_t, q_{t-1}[spk]], g_{t-1}))                    global state
+//     c_t  = sum_j softmax_j(<W_a U_t, g_j>) g_j,  j < t                   "general" attention over the global history
+//     q_t[spk] = m ? drop(GRU_p([U_t, c_t], q_{t-1}[spk])) : q_{t-1}[spk]  speaker's party state (listener unchanged)
+//     e_t  = drop(GRU_e(q_t[spk], e_{t-1}))                                emotion state
+// (m = qmask[t,b,spk]: 0 on padded steps, where the reference's blend keeps both party states.)
+//
+// Why not one kernel per dialogue: a step needs every cell's full weight matrix (12.7 MB per direction); one workgroup
+// per dialogue would stream that through ONE CU 94 times.  Instead the dialogues are the N axis (<= 32 per tile) of
+// skinny matrix products that spread a cell's weight rows over ~100-200 workgroups, and the S steps are a chain of small
+// launches (7 per step, both directions of BiModel in the same launches):
+//   * everything that depends on U alone is hoisted out of the recurrence into three ordinary GEMMs over all steps
+//     (x-parts of the g / p cells incl. b_ih, and the attention query W_a U_t);
+//   * skinny_nt / skinny_nn: C[B x N] = A[B x K] W^T resp. A W on v_mfma_f32_16x16x4_f32 (exact fp32): a workgroup owns
+//     16 weight rows (columns) and all dialogues, its waves split K and are summed through LDS in a fixed order;
+//   * gate kernels (elementwise GRU math + Philox dropout + party select/update), attention kernels (one workgroup
+//     per dialogue, history in L2);
+//   * backward mirrors it step by step in reverse; all weight gradients are deferred: the per-step gate gradients are
+//     kept and ONE grouped TN GEMM launch (gemm.hip, owner-accumulated, no atomics) computes the 12 products at the end.
+// Everything is deterministic (no atomics).  Dropout follows the Philox contract of common.h with rows t*B + b.
+#include "common.h"
+
+namespace ganffn {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+enum : uint32_t { SITE_DRNN_G = 8, SITE_DRNN_P = 9, SITE_DRNN_E = 10 };   // + 4 for the second direction
+
+// ------------------------------------------------------------------------------------------
+// skinny products: M <= 32 rows of A (dialogues) against a weight matrix
+// ------------------------------------------------------------------------------------------
+struct SkinnyProb {
+    const float* A; int lda;      // [M x K]
+    const float* W; int ldw;      // NT: [N x K];  NN: [K x N]
+    const float* Cin; int ldcin;  // optional addend [M x N]
+    const float* bias;            // optional [N]
+    float* C; int ldc;            // [M x N]
+    int M, N, K;
+};
+struct SkinnyGroup {
+    SkinnyProb p[4];
+};
+
+// NT: C[b][n] = sum_k A[b][k] W[n][k] (+ Cin[b][n] + bias[n]).  Workgroup = 16 weight rows x 32 dialogues, 4 waves split K.
+// MFMA tile D[m = weight row][n' = dialogue]: A-operand = W rows, B-operand = A rows; both are float4 loads along k
+// (k block of 16 per 4 MFMAs: step i contracts k = kb + 4g + i, identically on both operands).
+__global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyGroup grp) {
+    __shared__ __attribute__((aligned(16))) float red[4][2][4][64];
+    const SkinnyProb& q = grp.p[blockIdx.z];
+    const int n0 = blockIdx.x * 16;
+    if (n0 >= q.N) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int KQ = (((q.K + 3) / 4) + 15) / 16 * 16;     // k range per wave, multiple of 16
+    const int kbeg = w * KQ, kend = min(q.K, kbeg + KQ);
+    const float* wrow = q.W + (size_t)min(n0 + c, q.N - 1) * q.ldw;
+    const float* a0 = q.A + (size_t)min(c, q.M - 1) * q.lda;
+    const float* a1 = q.A + (size_t)min(16 + c, q.M - 1) * q.lda;
+    floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int kb = kbeg; kb < kend; kb += 32) {
+        float4 wv[2], x0[2], x1[2];
+        float f[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = kb + 16 * u + 4 * g;             // K % 4 == 0: a float4 never straddles the end
+            f[u] = k < kend ? 1.f : 0.f;
+            const int kc = max(min(k, q.K - 4), 0);
+            wv[u] = *reinterpret_cast<const float4*>(wrow + kc);
+            x0[u] = *reinterpret_cast<const float4*>(a0 + kc);
+            x1[u] = *reinterpret_cast<const float4*>(a1 + kc);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float wx = wv[u].x * f[u], wy = wv[u].y * f[u], wz = wv[u].z * f[u], ww = wv[u].w * f[u];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wx, x0[u].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wx, x1[u].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wy, x0[u].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wy, x1[u].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz, x0[u].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wz, x1[u].z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww, x0[u].w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww, x1[u].w, acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[w][0][r][lane] = acc0[r];
+        red[w][1][r][lane] = acc1[r];
+    }
+    __syncthreads();
+    // thread -> (dialogue tile mt, lane): sums the 4 waves in order; lane holds C[b = 16 mt + c][n0 + 4g .. 4g+3]
+    if (threadIdx.x < 128) {
+        const int mt = threadIdx.x >> 6;
+        const int b = 16 * mt + c, n = n0 + 4 * g;
+        if (b < q.M && n < q.N) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = ((red[0][mt][r][lane] + red[1][mt][r][lane]) + red[2][mt][r][lane]) + red[3][mt][r][lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (n + r < q.N) {
+                    float o = v[r];
+                    if (q.Cin) o += q.Cin[(size_t)b * q.ldcin + n + r];
+                    if (q.bias) o += q.bias[n + r];
+                    q.C[(size_t)b * q.ldc + n + r] = o;
+                }
+            }
+        }
+    }
+}
+
+// NN: C[b][n] = sum_k A[b][k] W[k][n] (+ Cin).  Workgroup = 16 output columns x 32 dialogues, 8 waves split K.
+// MFMA tile D[m = dialogue][n' = column]: A-operand = A rows (float4 along k), B-operand = W[k][n0 + n'] (one dword per
+// step: 16 consecutive columns of a row = 64 contiguous bytes).
+__global__ __launch_bounds__(512) void skinny_nn_kernel(SkinnyGroup grp) {
+    __shared__ __attribute__((aligned(16))) float red[8][2][4][64];
+    const SkinnyProb& q = grp.p[blockIdx.z];
+    const int n0 = blockIdx.x * 16;
+    if (n0 >= q.N) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int KQ = (((q.K + 7) / 8) + 15) / 16 * 16;
+    const int kbeg = w * KQ, kend = min(q.K, kbeg + KQ);
+    const float* a0 = q.A + (size_t)min(c, q.M - 1) * q.lda;
+    const float* a1 = q.A + (size_t)min(16 + c, q.M - 1) * q.lda;
+    const float* wcol = q.W + min(n0 + c, q.N - 1);
+    floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int kb = kbeg; kb < kend; kb += 16) {
+        const int k = kb + 4 * g;
+        const float f = k < kend ? 1.f : 0.f;
+        const int kc = max(min(k, q.K - 4), 0);
+        const float4 x0 = *reinterpret_cast<const float4*>(a0 + kc);
+        const float4 x1 = *reinterpret_cast<const float4*>(a1 + kc);
+        float wv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wv[i] = wcol[(size_t)(kc + i) * q.ldw] * f;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, wv[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, wv[0], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, wv[1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, wv[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, wv[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, wv[2], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, wv[3], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, wv[3], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[w][0][r][lane] = acc0[r];
+        red[w][1][r][lane] = acc1[r];
+    }
+    __syncthreads();
+    // accumulator register r of tile mt at lane (c, g) = C[b = 16 mt + 4g + r][n0 + c]
+    if (threadIdx.x < 128) {
+        const int mt = threadIdx.x >> 6;
+        const int n = n0 + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = 16 * mt + 4 * g + r;
+            if (b < q.M && n < q.N) {
+                float o = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) o += red[ww][mt][r][lane];
+                if (q.Cin) o += q.Cin[(size_t)b * q.ldcin + n];
+                q.C[(size_t)b * q.ldc + n] = o;
+            }
+        }
+    }
+}
+
+static int launch_skinny(const SkinnyGroup& grp, int nprob, bool nn, hipStream_t st) {
+    int maxN = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const SkinnyProb& q = grp.p[i];
+        GF_CHECK_ARG(q.M >= 1 && q.M <= 32 && (q.K & 3) == 0 && (q.lda & 3) == 0 && aligned16(q.A) && (nn || ((q.ldw & 3) == 0 && aligned16(q.W))),
+                     "drnn skinny product: M=%d K=%d lda=%d ldw=%d unsupported", q.M, q.K, q.lda, q.ldw);
+        maxN = q.N > maxN ? q.N : maxN;
+    }
+    if (nn) hipLaunchKernelGGL(skinny_nn_kernel, dim3((maxN + 15) / 16, 1, nprob), dim3(512), 0, st, grp);
+    else hipLaunchKernelGGL(skinny_nt_kernel, dim3((maxN + 15) / 16, 1, nprob), dim3(256), 0, st, grp);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// GRU gate math (torch.nn.GRUCell: r, z, n row blocks; n = tanh(i_n + r * h_n); h' = (1 - z) n + z h)
+// ------------------------------------------------------------------------------------------
+struct GateDir {
+    const float* GI; const float* GH;     // [B x 3H] pre-activations (biases included)
+    const float* hprev;                   // [B x H]
+    float* R; float* Z; float* N; float* HN;   // saved gates of this step [B x H]
+    float* hout;                          // g / e cells: state after dropout [B x H]
+    // party cell only:
+    const int* spk; const int* spk_next;  // [B] speaker of this / the next step (spk_next NULL on the last step)
+    const float* mval;                    // [B] 1 on valid steps, 0 on padding
+    const float* Qprev; float* Qnext;     // [B x 2 x H] party states before / after this step
+    float* QN; float* QSnext;             // [B x H] q_t[spk_t]; q_t[spk_{t+1}] (next step's g / p cell input)
+    uint32_t site;
+};
+struct GateArgs {
+    GateDir d[2];
+    int B, H, row0;        // row0 = t * B: dropout row of dialogue 0
+    float p; int train;
+    const uint64_t* rng; uint64_t add;
+};
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+template <int PARTY>
+__global__ __launch_bounds__(256) void gru_gate_fwd_kernel(GateArgs a) {
+    const GateDir& d = a.d[blockIdx.z];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.B * a.H) return;
+    const int b = idx / a.H, u = idx - b * a.H, H3 = 3 * a.H;
+    const float* gi = d.GI + (size_t)b * H3;
+    const float* gh = d.GH + (size_t)b * H3;
+    const float h = d.hprev[idx];
+    const float r = sigm(gi[u] + gh[u]);
+    const float z = sigm(gi[a.H + u] + gh[a.H + u]);
+    const float hn = gh[2 * a.H + u];
+    const float n = tanhf(gi[2 * a.H + u] + r * hn);
+    float hnew = (1.0f - z) * n + z * h;
+    d.R[idx] = r; d.Z[idx] = z; d.N[idx] = n; d.HN[idx] = hn;
+    const DropCtx dc = make_drop(a.rng, a.add, d.site, a.p, a.train);
+    hnew *= drop_mult1(dc, (uint32_t)(a.row0 + b), (uint32_t)a.H, (uint32_t)u);
+    if (!PARTY) {
+        d.hout[idx] = hnew;
+    } else {
+        // q_t[spk] = m ? qs : q_{t-1}[spk]; the other party keeps its state (listener_state False, model.py:888-893)
+        const int s = d.spk[b];
+        const float m = d.mval[b];
+        const float qs = m != 0.f ? hnew : h;
+        const float other = d.Qprev[((size_t)b * 2 + (1 - s)) * a.H + u];
+        d.Qnext[((size_t)b * 2 + s) * a.H + u] = qs;
+        d.Qnext[((size_t)b * 2 + (1 - s)) * a.H + u] = other;
+        d.QN[idx] = qs;
+        if (d.spk_next) d.QSnext[idx] = d.spk_next[b] == s ? qs : other;
+    }
+}
+
+struct GateBwdDir {
+    const float* dh;        // [B x H] gradient wrt the cell output AFTER dropout (g / e cells) or wrt Q[t+1][spk] (party cell)
+    const float* dh2;       // optional second addend (e cell: upstream dE_out[t])
+    const float* R; const float* Z; const float* N; const float* HN;
+    const float* hprev;
+    float* dGI; float* dGH; // [B x 3H] gate gradients (kept for the weight-gradient GEMMs)
+    float* dhdir;           // [B x H] direct path to hprev: dh' * z (+ (1 - m) dq for the party cell)
+    const float* mval;      // party cell: [B]
+    uint32_t site;
+};
+struct GateBwdArgs {
+    GateBwdDir d[2];
+    int B, H, row0;
+    float p; int train;
+    const uint64_t* rng; uint64_t add;
+};
+
+template <int PARTY>
+__global__ __launch_bounds__(256) void gru_gate_bwd_kernel(GateBwdArgs a) {
+    const GateBwdDir& d = a.d[blockIdx.z];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.B * a.H) return;
+    const int b = idx / a.H, u = idx - b * a.H, H3 = 3 * a.H;
+    float dout = d.dh[idx];
+    if (d.dh2) dout += d.dh2[idx];
+    float pass = 0.f;
+    if (PARTY) {
+        const float m = d.mval[b];
+        pass = m != 0.f ? 0.f : dout;      // padded step: q_t[spk] = q_{t-1}[spk]
+        dout = m != 0.f ? dout : 0.f;
+    }
+    const DropCtx dc = make_drop(a.rng, a.add, d.site, a.p, a.train);
+    const float dhn = dout * drop_mult1(dc, (uint32_t)(a.row0 + b), (uint32_t)a.H, (uint32_t)u);   // grad wrt h' (pre-dropout)
+    const float r = d.R[idx], z = d.Z[idx], n = d.N[idx], hn = d.HN[idx], h = d.hprev[idx];
+    const float dn = dhn * (1.0f - z);
+    const float dz = dhn * (h - n);
+    const float dnp = dn * (1.0f - n * n);
+    const float drp = dnp * hn * r * (1.0f - r);
+    const float dzp = dz * z * (1.0f - z);
+    float* gi = d.dGI + (size_t)b * H3;
+    float* gh = d.dGH + (size_t)b * H3;
+    gi[u] = drp; gi[a.H + u] = dzp; gi[2 * a.H + u] = dnp;
+    gh[u] = drp; gh[a.H + u] = dzp; gh[2 * a.H + u] = dnp * r;
+    d.dhdir[idx] = dhn * z + pass;
+}
+
+// ------------------------------------------------------------------------------------------
+// "general" context attention of step t over the global history g_0 .. g_{t-1} (model.py:161-164,193)
+// one workgroup per (dialogue, direction); G rows are (S+1) blocks of B: block j+1 = g_j
+// ------------------------------------------------------------------------------------------
+constexpr int DR_MAXS = 112;
+struct AttnDir {
+    const float* XA;     // [B x H] query W_a U_t of this step
+    const float* G;      // [(S+1) B x H]
+    float* CT;           // [B x H] context
+    float* alpha;        // [B x S x S], row t
+};
+struct AttnArgs { AttnDir d[2]; int B, H, S, t; };
+
+__global__ __launch_bounds__(256) void drnn_attn_fwd_kernel(AttnArgs a) {
+    __shared__ float sc[DR_MAXS];
+    __shared__ float red[4];
+    const AttnDir& d = a.d[blockIdx.z];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, t = a.t;
+    const float* x = d.XA + (size_t)b * a.H;
+    for (int j = w; j < t; j += 4) {
+        const float* gj = d.G + ((size_t)(j + 1) * a.B + b) * a.H;
+        float s = 0.f;
+        for (int k = lane; k < a.H; k += 64) s += x[k] * gj[k];
+        s = wave_sum(s);
+        if (lane == 0) sc[j] = s;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = tid; j < t; j += 256) m = fmaxf(m, sc[j]);
+    m = wave_max(m);
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float e = 0.f;
+    if (tid < t) { e = __expf(sc[tid] - m); sc[tid] = e; }
+    e = wave_sum(e);
+    if (lane == 0) red[w] = e;
+    __syncthreads();
+    const float inv = 1.0f / (((red[0] + red[1]) + red[2]) + red[3]);
+    if (tid < t) {
+        const float al = sc[tid] * inv;
+        sc[tid] = al;
+        d.alpha[((size_t)b * a.S + t) * a.S + tid] = al;
+    }
+    __syncthreads();
+    for (int k = tid; k < a.H; k += 256) {
+        float c = 0.f;
+        for (int j = 0; j < t; ++j) c += sc[j] * d.G[((size_t)(j + 1) * a.B + b) * a.H + k];
+        d.CT[(size_t)b * a.H + k] = c;
+    }
+}
+
+struct AttnBwdDir {
+    const float* dCT;    // [B x H]
+    const float* XA;     // [B x H]
+    const float* G;      // [(S+1) B x H]
+    const float* alpha;  // [B x S x S]
+    float* dG;           // [(S+1) B x H] accumulated gradient wrt g_j (block j+1)
+    float* dXA;          // [B x H]
+};
+struct AttnBwdArgs { AttnBwdDir d[2]; int B, H, S, t; };
+
+__global__ __launch_bounds__(256) void drnn_attn_bwd_kernel(AttnBwdArgs a) {
+    __shared__ float da[DR_MAXS];
+    __shared__ float al[DR_MAXS];
+    __shared__ float red[4];
+    const AttnBwdDir& d = a.d[blockIdx.z];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, t = a.t;
+    const float* dc = d.dCT + (size_t)b * a.H;
+    for (int j = w; j < t; j += 4) {
+        const float* gj = d.G + ((size_t)(j + 1) * a.B + b) * a.H;
+        float s = 0.f;
+        for (int k = lane; k < a.H; k += 64) s += dc[k] * gj[k];
+        s = wave_sum(s);
+        if (lane == 0) da[j] = s;
+    }
+    if (tid < t) al[tid] = d.alpha[((size_t)b * a.S + t) * a.S + tid];
+    __syncthreads();
+    float dot = tid < t ? al[tid] * da[tid] : 0.f;
+    dot = wave_sum(dot);
+    if (lane == 0) red[w] = dot;
+    __syncthreads();
+    const float tot = ((red[0] + red[1]) + red[2]) + red[3];
+    __syncthreads();
+    if (tid < t) da[tid] = al[tid] * (da[tid] - tot);      // d score_j
+    __syncthreads();
+    const float* x = d.XA + (size_t)b * a.H;
+    for (int k = tid; k < a.H; k += 256) {
+        const float dck = dc[k], xk = x[k];
+        float dx = 0.f;
+        for (int j = 0; j < t; ++j) {
+            const size_t o = ((size_t)(j + 1) * a.B + b) * a.H + k;
+            dx += da[j] * d.G[o];
+            d.dG[o] += al[j] * dck + da[j] * xk;             // this (dialogue, k) is owned by this thread: no race
+        }
+        d.dXA[(size_t)b * a.H + k] = dx;
+    }
+}
+
+// out[b][s][:] (+)= in[b][:] into party s = spk[b] of a [B x 2 x H] tensor; the other party is copied from `other`
+struct PartyAddArgs {
+    const float* dQ[2];       // [B x 2 x H] gradient wrt Q[t+1]
+    const float* dQSp[2];     // [B x H] gradient wrt Q[t][spk] from the party cell (h path + direct)
+    const float* dQSg[2];     // [B x H] gradient wrt Q[t][spk] from the global cell's x path
+    float* dQout[2];          // [B x 2 x H] gradient wrt Q[t]
+    const int* spk[2];
+    int B, H;
+};
+__global__ __launch_bounds__(256) void drnn_party_grad_kernel(PartyAddArgs a) {
+    const int z = blockIdx.z, idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.B * a.H) return;
+    const int b = idx / a.H, u = idx - b * a.H, s = a.spk[z][b];
+    a.dQout[z][((size_t)b * 2 + s) * a.H + u] = a.dQSp[z][idx] + a.dQSg[z][idx];
+    a.dQout[z][((size_t)b * 2 + (1 - s)) * a.H + u] = a.dQ[z][((size_t)b * 2 + (1 - s)) * a.H + u];
+}
+// gather dq_spk[b][:] = dQ[b][spk[b]][:] + add[b][:]
+struct PartySelArgs { const float* dQ[2]; const float* add[2]; float* out[2]; const int* spk[2]; int B, H; };
+__global__ __launch_bounds__(256) void drnn_party_sel_kernel(PartySelArgs a) {
+    const int z = blockIdx.z, idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.B * a.H) return;
+    const int b = idx / a.H, u = idx - b * a.H;
+    a.out[z][idx] = a.dQ[z][((size_t)b * 2 + a.spk[z][b]) * a.H + u] + a.add[z][idx];
+}
+
+// ------------------------------------------------------------------------------------------
+// layouts
+// ------------------------------------------------------------------------------------------
+struct DrnnSaved {
+    int64_t XG, XP, XA, G, Q, E, QS, CT, QN, Rg, Zg, Ng, HNg, Rp, Zp, Np, HNp, Re, Ze, Ne, HNe, total;
+};
+static DrnnSaved drnn_saved(const ganffn_drnn_cfg* c) {
+    DrnnSaved s;
+    const int64_t T = (int64_t)c->S * c->B, T1 = (int64_t)(c->S + 1) * c->B, H = c->H, He = c->He;
+    int64_t p = 0;
+    auto take = [&](int64_t n) { int64_t r = p; p += (n + 3) & ~int64_t(3); return r; };
+    s.XG = take(T * 3 * H); s.XP = take(T * 3 * H); s.XA = take(T * H);
+    s.G = take(T1 * H); s.Q = take(T1 * 2 * H); s.E = take(T1 * He);
+    s.QS = take(T1 * H); s.CT = take(T * H); s.QN = take(T * H);
+    s.Rg = take(T * H); s.Zg = take(T * H); s.Ng = take(T * H); s.HNg = take(T * H);
+    s.Rp = take(T * H); s.Zp = take(T * H); s.Np = take(T * H); s.HNp = take(T * H);
+    s.Re = take(T * He); s.Ze = take(T * He); s.Ne = take(T * He); s.HNe = take(T * He);
+    s.total = p;
+    return s;
+}
+struct DrnnWs {
+    int64_t GI, GH, dGIg, dGHg, dGIp, dGHp, dGIe, dGHe, dXA, dCT, dG, dQa, dQb, dEa, dEb, dQsel, dQSp, dQSg, dhdir, dQN, total;
+};
+static DrnnWs drnn_ws(const ganffn_drnn_cfg* c) {
+    DrnnWs w;
+    const int64_t T = (int64_t)c->S * c->B, T1 = (int64_t)(c->S + 1) * c->B, B = c->B, H = c->H, He = c->He;
+    int64_t p = 0;
+    auto take = [&](int64_t n) { int64_t r = p; p += (n + 3) & ~int64_t(3); return r; };
+    w.GI = take(B * 3 * H); w.GH = take(B * 3 * H);
+    w.dGIg = take(T * 3 * H); w.dGHg = take(T * 3 * H); w.dGIp = take(T * 3 * H); w.dGHp = take(T * 3 * H);
+    w.dGIe = take(T * 3 * He); w.dGHe = take(T * 3 * He);
+    w.dXA = take(T * H); w.dCT = take(B * H); w.dG = take(T1 * H);
+    w.dQa = take(B * 2 * H); w.dQb = take(B * 2 * H); w.dEa = take(B * He); w.dEb = take(B * He);
+    w.dQsel = take(B * H); w.dQSp = take(B * H); w.dQSg = take(B * H); w.dhdir = take(B * H); w.dQN = take(B * H);
+    w.total = p;
+    return w;
+}
+
+static int check_drnn(const ganffn_drnn_cfg* c, int ndir) {
+    GF_CHECK_ARG(c, "null drnn cfg");
+    GF_CHECK_ARG(ndir == 1 || ndir == 2, "drnn: ndir=%d", ndir);
+    GF_CHECK_ARG(c->S >= 1 && c->S <= DR_MAXS && c->B >= 1 && c->B <= 32, "drnn: S=%d (<= %d), B=%d (<= 32)", c->S, DR_MAXS, c->B);
+    GF_CHECK_ARG(c->Dm >= 4 && (c->Dm & 3) == 0 && c->H >= 4 && (c->H & 3) == 0 && c->He >= 4 && (c->He & 3) == 0,
+                 "drnn: D_m=%d, D_g=D_p=%d, D_e=%d must be multiples of 4", c->Dm, c->H, c->He);
+    GF_CHECK_ARG(c->p >= 0.f && c->p < 1.f, "drnn: dropout p out of [0,1)");
+    return 0;
+}
+
+static int memset_f(float* p, int64_t n, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(p, 0, (size_t)n * sizeof(float), st);
+    if (e != hipSuccess) return fail((int)e, "drnn: memset failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+}  // namespace ganffn
+
+using namespace ganffn;
+
+extern "C" int64_t ganffn_drnn_saved_floats(const ganffn_drnn_cfg* c) { return check_drnn(c, 1) ? -1 : drnn_saved(c).total; }
+extern "C" int64_t ganffn_drnn_workspace_floats(const ganffn_drnn_cfg* c) { return check_drnn(c, 1) ? -1 : drnn_ws(c).total; }
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+extern "C" int ganffn_drnn_fwd(const ganffn_drnn_cfg* c, int ndir, const float* const* U, const int32_t* const* spk,
+                               const float* const* mval, const ganffn_drnn_params* prm, float* const* e_out,
+                               float* const* alpha, float* const* saved, float* const* workspace, const uint64_t* rng,
+                               uint64_t add, void* stream) {
+    GF_TRY(check_drnn(c, ndir));
+    GF_CHECK_ARG(U && spk && mval && prm && e_out && alpha && saved && workspace, "drnn_fwd: null pointer");
+    GF_CHECK_ARG(!(c->train && c->p > 0.f) || rng, "drnn_fwd: rng required in train mode");
+    hipStream_t st = (hipStream_t)stream;
+    const int S = c->S, B = c->B, Dm = c->Dm, H = c->H, He = c->He, T = S * B;
+    const DrnnSaved so = drnn_saved(c);
+    const DrnnWs wo = drnn_ws(c);
+    for (int z = 0; z < ndir; ++z) {
+        GF_CHECK_ARG(U[z] && spk[z] && mval[z] && e_out[z] && alpha[z] && saved[z] && workspace[z] && aligned16(U[z]) &&
+                     aligned16(saved[z]) && aligned16(workspace[z]), "drnn_fwd: direction %d: null or misaligned buffer", z);
+        float* sv = saved[z];
+        // U-only terms for all steps: XG = U Wih_g[:, :Dm]^T + bih_g, XP likewise, XA = U Watt^T
+        EpiArgs e;
+        e.bias = prm[z].g_bih;
+        GF_TRY(launch_gemm_nt(U[z], Dm, prm[z].g_wih, Dm + H, sv + so.XG, 3 * H, T, 3 * H, Dm, EPI_NONE, e, st));
+        e.bias = prm[z].p_bih;
+        GF_TRY(launch_gemm_nt(U[z], Dm, prm[z].p_wih, Dm + H, sv + so.XP, 3 * H, T, 3 * H, Dm, EPI_NONE, e, st));
+        e.bias = nullptr;
+        GF_TRY(launch_gemm_nt(U[z], Dm, prm[z].att_w, Dm, sv + so.XA, H, T, H, Dm, EPI_NONE, e, st));
+        // zero initial states: G[0], Q[0], E[0], QS[0], CT[0]; alpha (entries j >= t stay zero)
+        GF_TRY(memset_f(sv + so.G, (int64_t)B * H, st));
+        GF_TRY(memset_f(sv + so.Q, (int64_t)B * 2 * H, st));
+        GF_TRY(memset_f(sv + so.E, (int64_t)B * He, st));
+        GF_TRY(memset_f(sv + so.QS, (int64_t)B * H, st));
+        GF_TRY(memset_f(sv + so.CT, (int64_t)B * H, st));
+        GF_TRY(memset_f(alpha[z], (int64_t)B * S * S, st));
+    }
+    const dim3 gH((B * H + 255) / 256, 1, ndir), gHe((B * He + 255) / 256, 1, ndir);
+    for (int t = 0; t < S; ++t) {
+        const int64_t r0 = (int64_t)t * B, r1 = (int64_t)(t + 1) * B;
+        SkinnyGroup sg;
+        // ---- global cell: GI = XG[t] + QS[t] Wih_g[:, Dm:]^T ; GH = G[t] Whh_g^T + bhh_g
+        for (int z = 0; z < ndir; ++z) {
+            float* sv = saved[z]; float* ws = workspace[z];
+            sg.p[2 * z] = SkinnyProb{sv + so.QS + r0 * H, H, prm[z].g_wih + Dm, Dm + H, sv + so.XG + r0 * 3 * H, 3 * H, nullptr,
+                                     ws + wo.GI, 3 * H, B, 3 * H, H};
+            sg.p[2 * z + 1] = SkinnyProb{sv + so.G + r0 * H, H, prm[z].g_whh, H, nullptr, 0, prm[z].g_bhh, ws + wo.GH, 3 * H, B, 3 * H, H};
+        }
+        GF_TRY(launch_skinny(sg, 2 * ndir, false, st));
+        GateArgs ga;
+        ga.B = B; ga.H = H; ga.row0 = (int)r0; ga.p = c->p; ga.train = c->train; ga.rng = rng; ga.add = add;
+        for (int z = 0; z < ndir; ++z) {
+            float* sv = saved[z]; float* ws = workspace[z];
+            ga.d[z] = GateDir{ws + wo.GI, ws + wo.GH, sv + so.G + r0 * H, sv + so.Rg + r0 * H, sv + so.Zg + r0 * H, sv + so.Ng + r0 * H,
+                              sv + so.HNg + r0 * H, sv + so.G + r1 * H, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              SITE_DRNN_G + 4u * z};
+        }
+        hipLaunchKernelGGL(gru_gate_fwd_kernel<0>, gH, dim3(256), 0, st, ga);
+        GF_LAUNCH_CHECK();
+        // ---- context attention over g_0 .. g_{t-1}
+        if (t > 0) {
+            AttnArgs aa;
+            aa.B = B; aa.H = H; aa.S = S; aa.t = t;
+            for (int z = 0; z < ndir; ++z)
+                aa.d[z] = AttnDir{saved[z] + so.XA + r0 * H, saved[z] + so.G, saved[z] + so.CT + r0 * H, alpha[z]};
+            hipLaunchKernelGGL(drnn_attn_fwd_kernel, dim3(B, 1, ndir), dim3(256), 0, st, aa);
+            GF_LAUNCH_CHECK();
+        }
+        // ---- party cell (speaker): GI = XP[t] + CT[t] Wih_p[:, Dm:]^T ; GH = QS[t] Whh_p^T + bhh_p
+        for (int z = 0; z < ndir; ++z) {
+            float* sv = saved[z]; float* ws = workspace[z];
+            sg.p[2 * z] = SkinnyProb{sv + so.CT + r0 * H, H, prm[z].p_wih + Dm, Dm + H, sv + so.XP + r0 * 3 * H, 3 * H, nullptr,
+                                     ws + wo.GI, 3 * H, B, 3 * H, H};
+            sg.p[2 * z + 1] = SkinnyProb{sv + so.QS + r0 * H, H, prm[z].p_whh, H, nullptr, 0, prm[z].p_bhh, ws + wo.GH, 3 * H, B, 3 * H, H};
+        }
+        GF_TRY(launch_skinny(sg, 2 * ndir, false, st));
+        for (int z = 0; z < ndir; ++z) {
+            float* sv = saved[z]; float* ws = workspace[z];
+            ga.d[z] = GateDir{ws + wo.GI, ws + wo.GH, sv + so.QS + r0 * H, sv + so.Rp + r0 * H, sv + so.Zp + r0 * H, sv + so.Np + r0 * H,
+                              sv + so.HNp + r0 * H, nullptr, spk[z] + r0, t + 1 < S ? spk[z] + r1 : nullptr, mval[z] + r0,
+                              sv + so.Q + r0 * 2 * H, sv + so.Q + r1 * 2 * H, sv + so.QN + r0 * H, sv + so.QS + r1 * H,
+                              SITE_DRNN_P + 4u * z};
+        }
+        hipLaunchKernelGGL(gru_gate_fwd_kernel<1>, gH, dim3(256), 0, st, ga);
+        GF_LAUNCH_CHECK();
+        // ---- emotion cell: GI = QN[t] Wih_e^T + bih_e ; GH = E[t] Whh_e^T + bhh_e
+        for (int z = 0; z < ndir; ++z) {
+            float* sv = saved[z]; float* ws = workspace[z];
+            sg.p[2 * z] = SkinnyProb{sv + so.QN + r0 * H, H, prm[z].e_wih, H, nullptr, 0, prm[z].e_bih, ws + wo.GI, 3 * He, B, 3 * He, H};
+            sg.p[2 * z + 1] = SkinnyProb{sv + so.E + r0 * He, He, prm[z].e_whh, He, nullptr, 0, prm[z].e_bhh, ws + wo.GH, 3 * He, B, 3 * He, He};
+        }
+        GF_TRY(launch_skinny(sg, 2 * ndir, false, st));
+        ga.H = He;
+        for (int z = 0; z < ndir; ++z) {
+            float* sv = saved[z]; float* ws = workspace[z];
+            ga.d[z] = GateDir{ws + wo.GI, ws + wo.GH, sv + so.E + r0 * He, sv + so.Re + r0 * He, sv + so.Ze + r0 * He, sv + so.Ne + r0 * He,
+                              sv + so.HNe + r0 * He, sv + so.E + r1 * He, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              SITE_DRNN_E + 4u * z};
+        }
+        hipLaunchKernelGGL(gru_gate_fwd_kernel<0>, gHe, dim3(256), 0, st, ga);
+        GF_LAUNCH_CHECK();
+    }
+    for (int z = 0; z < ndir; ++z) {
+        hipError_t er = hipMemcpyAsync(e_out[z], saved[z] + so.E + (int64_t)B * He, (size_t)T * He * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (er != hipSuccess) return fail((int)er, "drnn_fwd: memcpy failed: %s", hipGetErrorString(er));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------
+extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* const* d_e, const float* const* U,
+                               const int32_t* const* spk, const float* const* mval, const ganffn_drnn_params* prm,
+                               const ganffn_drnn_grads* grd, float* const* dU, const float* const* alpha,
+                               const float* const* saved, float* const* workspace, const uint64_t* rng, uint64_t add,
+                               void* stream) {
+    GF_TRY(check_drnn(c, ndir));
+    GF_CHECK_ARG(d_e && U && spk && mval && prm && grd && dU && alpha && saved && workspace, "drnn_bwd: null pointer");
+    GF_CHECK_ARG(!(c->train && c->p > 0.f) || rng, "drnn_bwd: rng required in train mode");
+    hipStream_t st = (hipStream_t)stream;
+    const int S = c->S, B = c->B, Dm = c->Dm, H = c->H, He = c->He, T = S * B;
+    const DrnnSaved so = drnn_saved(c);
+    const DrnnWs wo = drnn_ws(c);
+    for (int z = 0; z < ndir; ++z) {
+        GF_CHECK_ARG(d_e[z] && U[z] && dU[z] && saved[z] && workspace[z] && alpha[z], "drnn_bwd: direction %d: null buffer", z);
+        float* ws = workspace[z];
+        GF_TRY(memset_f(ws + wo.dG, (int64_t)(S + 1) * B * H, st));
+        GF_TRY(memset_f(ws + wo.dQa, (int64_t)B * 2 * H, st));
+        GF_TRY(memset_f(ws + wo.dEa, (int64_t)B * He, st));
+        GF_TRY(memset_f(ws + wo.dXA, (int64_t)B * H, st));          // step 0 has no attention: dXA[0] = 0
+    }
+    const dim3 gH((B * H + 255) / 256, 1, ndir), gHe((B * He + 255) / 256, 1, ndir);
+    for (int t = S - 1; t >= 0; --t) {
+        const int64_t r0 = (int64_t)t * B, r1 = (int64_t)(t + 1) * B;
+        const bool even = ((S - 1 - t) & 1) == 0;            // ping-pong of the recurrent gradients
+        const int64_t dQin = even ? wo.dQa : wo.dQb, dQout = even ? wo.dQb : wo.dQa;
+        const int64_t dEin = even ? wo.dEa : wo.dEb, dEout = even ? wo.dEb : wo.dEa;
+        SkinnyGroup sg;
+        GateBwdArgs gb;
+        gb.B = B; gb.row0 = (int)r0; gb.p = c->p; gb.train = c->train; gb.rng = rng; gb.add = add;
+        // ---- emotion cell
+        gb.H = He;
+        for (int z = 0; z < ndir; ++z) {
+            const float* sv = saved[z]; float* ws = workspace[z];
+            gb.d[z] = GateBwdDir{ws + dEin, d_e[z] + r0 * He, sv + so.Re + r0 * He, sv + so.Ze + r0 * He, sv + so.Ne + r0 * He,
+                                 sv + so.HNe + r0 * He, sv + so.E + r0 * He, ws + wo.dGIe + r0 * 3 * He, ws + wo.dGHe + r0 * 3 * He,
+                                 ws + wo.dhdir, nullptr, SITE_DRNN_E + 4u * z};
+        }
+        hipLaunchKernelGGL(gru_gate_bwd_kernel<0>, gHe, dim3(256), 0, st, gb);
+        GF_LAUNCH_CHECK();
+        for (int z = 0; z < ndir; ++z) {
+            float* ws = workspace[z];
+            // dQN[t] = dGI_e Wih_e ; dE_rec = dGH_e Whh_e + dhdir
+            sg.p[2 * z] = SkinnyProb{ws + wo.dGIe + r0 * 3 * He, 3 * He, prm[z].e_wih, H, nullptr, 0, nullptr, ws + wo.dQN, H, B, H, 3 * He};
+            sg.p[2 * z + 1] = SkinnyProb{ws + wo.dGHe + r0 * 3 * He, 3 * He, prm[z].e_whh, He, ws + wo.dhdir, He, nullptr, ws + dEout, He, B,
+                                         He, 3 * He};
+        }
+        GF_TRY(launch_skinny(sg, 2 * ndir, true, st));
+        // ---- party cell: dq_spk = dQ[t+1][spk] + dQN
+        PartySelArgs ps;
+        ps.B = B; ps.H = H;
+        for (int z = 0; z < ndir; ++z) {
+            float* ws = workspace[z];
+            ps.dQ[z] = ws + dQin; ps.add[z] = ws + wo.dQN; ps.out[z] = ws + wo.dQsel; ps.spk[z] = spk[z] + r0;
+        }
+        hipLaunchKernelGGL(drnn_party_sel_kernel, gH, dim3(256), 0, st, ps);
+        GF_LAUNCH_CHECK();
+        gb.H = H;
+        for (int z = 0; z < ndir; ++z) {
+            const float* sv = saved[z]; float* ws = workspace[z];
+            gb.d[z] = GateBwdDir{ws + wo.dQsel, nullptr, sv + so.Rp + r0 * H, sv + so.Zp + r0 * H, sv + so.Np + r0 * H, sv + so.HNp + r0 * H,
+                                 sv + so.QS + r0 * H, ws + wo.dGIp + r0 * 3 * H, ws + wo.dGHp + r0 * 3 * H, ws + wo.dhdir, mval[z] + r0,
+                                 SITE_DRNN_P + 4u * z};
+        }
+        hipLaunchKernelGGL(gru_gate_bwd_kernel<1>, gH, dim3(256), 0, st, gb);
+        GF_LAUNCH_CHECK();
+        for (int z = 0; z < ndir; ++z) {
+            float* ws = workspace[z];
+            // dCT[t] = dGI_p Wih_p[:, Dm:] ; dQS_p = dGH_p Whh_p + dhdir
+            sg.p[2 * z] = SkinnyProb{ws + wo.dGIp + r0 * 3 * H, 3 * H, prm[z].p_wih + Dm, Dm + H, nullptr, 0, nullptr, ws + wo.dCT, H, B, H, 3 * H};
+            sg.p[2 * z + 1] = SkinnyProb{ws + wo.dGHp + r0 * 3 * H, 3 * H, prm[z].p_whh, H, ws + wo.dhdir, H, nullptr, ws + wo.dQSp, H, B, H, 3 * H};
+        }
+        GF_TRY(launch_skinny(sg, 2 * ndir, true, st));
+        // ---- attention
+        if (t > 0) {
+            AttnBwdArgs ab;
+            ab.B = B; ab.H = H; ab.S = S; ab.t = t;
+            for (int z = 0; z < ndir; ++z)
+                ab.d[z] = AttnBwdDir{workspace[z] + wo.dCT, saved[z] + so.XA + r0 * H, saved[z] + so.G, alpha[z], workspace[z] + wo.dG,
+                                     workspace[z] + wo.dXA + r0 * H};
+            hipLaunchKernelGGL(drnn_attn_bwd_kernel, dim3(B, 1, ndir), dim3(256), 0, st, ab);
+            GF_LAUNCH_CHECK();
+        }
+        // ---- global cell: dg_t = dG[t+1] (attention uses at later steps + the recurrent path, both already added)
+        for (int z = 0; z < ndir; ++z) {
+            const float* sv = saved[z]; float* ws = workspace[z];
+            gb.d[z] = GateBwdDir{ws + wo.dG + r1 * H, nullptr, sv + so.Rg + r0 * H, sv + so.Zg + r0 * H, sv + so.Ng + r0 * H, sv + so.HNg + r0 * H,
+                                 sv + so.G + r0 * H, ws + wo.dGIg + r0 * 3 * H, ws + wo.dGHg + r0 * 3 * H, ws + wo.dhdir, nullptr,
+                                 SITE_DRNN_G + 4u * z};
+        }
+        hipLaunchKernelGGL(gru_gate_bwd_kernel<0>, gH, dim3(256), 0, st, gb);
+        GF_LAUNCH_CHECK();
+        for (int z = 0; z < ndir; ++z) {
+            float* ws = workspace[z];
+            // dQS_g = dGI_g Wih_g[:, Dm:] ; dG[t] += dGH_g Whh_g + dhdir   (Cin = dG[t] + ... : two addends -> use dhdir first)
+            sg.p[2 * z] = SkinnyProb{ws + wo.dGIg + r0 * 3 * H, 3 * H, prm[z].g_wih + Dm, Dm + H, nullptr, 0, nullptr, ws + wo.dQSg, H, B, H, 3 * H};
+            sg.p[2 * z + 1] = SkinnyProb{ws + wo.dGHg + r0 * 3 * H, 3 * H, prm[z].g_whh, H, ws + wo.dhdir, H, nullptr, ws + wo.dQN, H, B, H, 3 * H};
+        }
+        GF_TRY(launch_skinny(sg, 2 * ndir, true, st));
+        for (int z = 0; z < ndir; ++z)                      // dG[t] += (dGH_g Whh_g + dhdir), held in the dQN scratch
+            GF_TRY(launch_add_inplace(workspace[z] + wo.dG + r0 * H, workspace[z] + wo.dQN, (int64_t)B * H, st));
+        // ---- gradient wrt Q[t]
+        PartyAddArgs pa;
+        pa.B = B; pa.H = H;
+        for (int z = 0; z < ndir; ++z) {
+            float* ws = workspace[z];
+            pa.dQ[z] = ws + dQin; pa.dQSp[z] = ws + wo.dQSp; pa.dQSg[z] = ws + wo.dQSg; pa.dQout[z] = ws + dQout; pa.spk[z] = spk[z] + r0;
+        }
+        hipLaunchKernelGGL(drnn_party_grad_kernel, gH, dim3(256), 0, st, pa);
+        GF_LAUNCH_CHECK();
+    }
+    // ---- dU and the deferred weight gradients (all steps at once)
+    for (int z = 0; z < ndir; ++z) {
+        const float* sv = saved[z]; float* ws = workspace[z];
+        const ganffn_drnn_grads& g = grd[z];
+        EpiArgs e0, e1;
+        GF_TRY(launch_gemm_nn(ws + wo.dGIg, 3 * H, prm[z].g_wih, Dm + H, dU[z], Dm, T, Dm, 3 * H, EPI_NONE, e0, st));
+        e1.aux_in = dU[z];
+        GF_TRY(launch_gemm_nn(ws + wo.dGIp, 3 * H, prm[z].p_wih, Dm + H, dU[z], Dm, T, Dm, 3 * H, EPI_NONE, e1, st));
+        GF_TRY(launch_gemm_nn(ws + wo.dXA, H, prm[z].att_w, Dm, dU[z], Dm, T, Dm, H, EPI_NONE, e1, st));
+        if (g.g_wih) {
+            TnDesc tn[12];
+            int n = 0;
+            tn[n++] = TnDesc{ws + wo.dGIg, 3 * H, U[z], Dm, g.g_wih, Dm + H, g.g_bih, 3 * H, Dm, T};
+            tn[n++] = TnDesc{ws + wo.dGIg, 3 * H, sv + so.QS, H, g.g_wih + Dm, Dm + H, nullptr, 3 * H, H, T};
+            tn[n++] = TnDesc{ws + wo.dGHg, 3 * H, sv + so.G, H, g.g_whh, H, g.g_bhh, 3 * H, H, T};
+            tn[n++] = TnDesc{ws + wo.dGIp, 3 * H, U[z], Dm, g.p_wih, Dm + H, g.p_bih, 3 * H, Dm, T};
+            tn[n++] = TnDesc{ws + wo.dGIp, 3 * H, sv + so.CT, H, g.p_wih + Dm, Dm + H, nullptr, 3 * H, H, T};
+            tn[n++] = TnDesc{ws + wo.dGHp, 3 * H, sv + so.QS, H, g.p_whh, H, g.p_bhh, 3 * H, H, T};
+            tn[n++] = TnDesc{ws + wo.dGIe, 3 * He, sv + so.QN, H, g.e_wih, H, g.e_bih, 3 * He, H, T};
+            tn[n++] = TnDesc{ws + wo.dGHe, 3 * He, sv + so.E, He, g.e_whh, He, g.e_bhh, 3 * He, He, T};
+            tn[n++] = TnDesc{ws + wo.dXA, H, U[z], Dm, g.att_w, Dm, nullptr, H, Dm, T};
+            GF_TRY(launch_gemm_tn_grouped(tn, n, st));
+        }
+    }
+    return 0;
+}

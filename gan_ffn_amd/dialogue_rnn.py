@@ -5,8 +5,10 @@ Mirrors the module interface of /root/reference/model.py:134-194 (MatchingAttent
 (DialogueRNNCell, DialogueRNN, BiModel) and :1465-1528 (GAN_FFN_DialogueRNN): same constructor arguments, same
 parameter names and shapes (reference state_dicts load), same forward signatures and return tuples.
 
-Round-1 form: the recurrence runs on PyTorch-ROCm device ops (GRU cells are rocBLAS GEMMs + pointwise kernels, S
-sequential steps per direction); the pieces with no sequential dependence are batched instead of looped:
+On the GPU, in the configuration the reference script runs (general context attention, no listener), the recurrence is
+the HIP path of csrc/dialogue_rnn.hip (ops.DialogueRNNFn: both directions of BiModel through one chain of launches, forward
+and backward); other configurations (simple attention, listener state) and CPU tensors take the torch-op restatement
+below, which is also what the reference-fixture parity tests pin.  The pieces with no sequential dependence are batched:
   * party selection is a gather, sequence reversal one index gather per tensor (the reference loops over dialogues),
   * BiModel's second attention — one masked `general2` MatchingAttention query per time step in the reference — is ONE
     batched masked attention over all (dialogue, query step) pairs (`general2_all_queries`).
@@ -145,6 +147,10 @@ class DialogueRNN(nn.Module):
 
     def forward(self, U, qmask):
         """U (S, B, D_m), qmask (S, B, P) -> emotions (S, B, D_e), [alpha_t (B, t)] for t >= 1"""
+        from . import ops
+        if ops.dialogue_rnn_supported(self.dialogue_cell, U, qmask):
+            # the HIP recurrence (csrc/dialogue_rnn.hip): the configuration train_IEMOCAP_DialogueRNN.py runs
+            return ops.dialogue_rnn_run([self.dialogue_cell], [U], [qmask], self.training)[0]
         S, B, P = qmask.shape
         g_steps, e_steps, alpha = [], [], []
         q_ = U.new_zeros(B, P, self.D_p)
@@ -194,9 +200,17 @@ class BiModel(nn.Module):
         return reverse_valid_prefix(X, mask)
 
     def forward(self, U, qmask, umask, att2=True):
-        emotions_f, alpha_f = self.dialog_rnn_f(U, qmask)
+        from . import ops
+        rev_U, rev_qmask = self._reverse_seq(U, umask), self._reverse_seq(qmask, umask)
+        cf, cr = self.dialog_rnn_f.dialogue_cell, self.dialog_rnn_r.dialogue_cell
+        if ops.dialogue_rnn_supported(cf, U, qmask) and ops.dialogue_rnn_supported(cr, rev_U, rev_qmask) and rev_U.shape == U.shape:
+            # both directions through the same chain of launches (csrc/dialogue_rnn.hip)
+            (emotions_f, alpha_f), (emotions_b, alpha_b) = ops.dialogue_rnn_run([cf, cr], [U, rev_U], [qmask, rev_qmask],
+                                                                                self.training)
+        else:
+            emotions_f, alpha_f = self.dialog_rnn_f(U, qmask)
+            emotions_b, alpha_b = self.dialog_rnn_r(rev_U, rev_qmask)
         emotions_f = self.dropout_rec(emotions_f)
-        emotions_b, alpha_b = self.dialog_rnn_r(self._reverse_seq(U, umask), self._reverse_seq(qmask, umask))
         emotions_b = self.dropout_rec(self._reverse_seq(emotions_b, umask))
         emotions = torch.cat([emotions_f, emotions_b], dim=-1)
         if att2:

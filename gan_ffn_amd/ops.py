@@ -404,3 +404,115 @@ class General2AttnFn(torch.autograd.Function):
         _lib.call("ganffn_general2_attention_bwd", _ptr(g), _ptr(xc), _ptr(mc), _ptr(kc), _ptr(alpha), _ptr(ts), _ptr(du),
                   _ptr(dx), _ptr(dm), S, B, D, _stream())
         return dx, dm, None
+
+
+# ----------------------------------------------------------------------------------------------
+# N2: DialogueRNN recurrence (include/ganffn.h "N2 (config 5)")
+# ----------------------------------------------------------------------------------------------
+DRNN_KEYS = ["g_cell.weight_ih", "g_cell.weight_hh", "g_cell.bias_ih", "g_cell.bias_hh",
+             "p_cell.weight_ih", "p_cell.weight_hh", "p_cell.bias_ih", "p_cell.bias_hh",
+             "e_cell.weight_ih", "e_cell.weight_hh", "e_cell.bias_ih", "e_cell.bias_hh", "attention.transform.weight"]
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
+
+
+def _drnn_ptrs(tensors):
+    s = _lib.DrnnPtrs()
+    for name, t in zip(_lib.DRNN_PARAM_FIELDS, tensors):
+        setattr(s, name, t.data_ptr() if t is not None else None)
+    return s
+
+
+class DialogueRNNFn(torch.autograd.Function):
+    """ndir (1 or 2) DialogueRNNs (general attention, no listener) through one chain of launches.
+    apply(cfg_dict, U_0, spk_0, mval_0, *13 params_0 [, U_1, spk_1, mval_1, *13 params_1]) ->
+    (e_0 (S,B,D_e), alpha_0 (B,S,S) [, e_1, alpha_1]).  alpha is an inspection output (non-differentiable)."""
+
+    @staticmethod
+    def forward(ctx, meta, *args):
+        ndir = len(args) // 16
+        assert len(args) == 16 * ndir and ndir in (1, 2)
+        U = [_f32c(args[16 * z]) for z in range(ndir)]
+        spk = [args[16 * z + 1].to(torch.int32).contiguous() for z in range(ndir)]
+        mval = [_f32c(args[16 * z + 2]) for z in range(ndir)]
+        prm = [[_f32c(p) for p in args[16 * z + 3:16 * z + 16]] for z in range(ndir)]
+        _need_gpu(*U)
+        S, B, Dm = U[0].shape
+        H, He = prm[0][1].shape[1], prm[0][9].shape[1]
+        train = bool(meta["train"]) and meta["p"] > 0.0
+        cfg = _lib.DrnnCfg(S, B, Dm, H, He, float(meta["p"]), 1 if train else 0)
+        lib = _lib.load()
+        n_saved, n_ws = int(lib.ganffn_drnn_saved_floats(C.byref(cfg))), int(lib.ganffn_drnn_workspace_floats(C.byref(cfg)))
+        if n_saved < 0 or n_ws < 0:
+            _lib.check(-1, "ganffn_drnn_*_floats")
+        dev = U[0].device
+        saved = [torch.empty(n_saved, device=dev) for _ in range(ndir)]
+        ws = [torch.empty(n_ws, device=dev) for _ in range(ndir)]
+        e = [torch.empty(S, B, He, device=dev) for _ in range(ndir)]
+        alpha = [torch.empty(B, S, S, device=dev) for _ in range(ndir)]
+        rng = DeviceRng.get(dev)
+        add = rng.next_add() if train else 0
+        P = (_lib.DrnnPtrs * ndir)(*[_drnn_ptrs(p) for p in prm])
+        _lib.call("ganffn_drnn_fwd", C.byref(cfg), ndir, _ptr_array(U), _ptr_array(spk), _ptr_array(mval), P, _ptr_array(e),
+                  _ptr_array(alpha), _ptr_array(saved), _ptr_array(ws), _ptr(rng.state), C.c_uint64(add), _stream())
+        ctx.cfg, ctx.ndir, ctx.add, ctx.rng_state = cfg, ndir, add, rng.state
+        ctx.keep = (U, spk, mval, prm, alpha, saved, ws)
+        out = []
+        for z in range(ndir):
+            out += [e[z], alpha[z]]
+            ctx.mark_non_differentiable(alpha[z])
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        U, spk, mval, prm, alpha, saved, ws = ctx.keep
+        ndir, cfg = ctx.ndir, ctx.cfg
+        d_e = [_f32c(douts[2 * z]) if douts[2 * z] is not None else torch.zeros_like(U[z][..., :cfg.He]) for z in range(ndir)]
+        dU = [torch.empty_like(U[z]) for z in range(ndir)]
+        grads = [[torch.zeros_like(p) for p in prm[z]] for z in range(ndir)]
+        P = (_lib.DrnnPtrs * ndir)(*[_drnn_ptrs(p) for p in prm])
+        G = (_lib.DrnnPtrs * ndir)(*[_drnn_ptrs(g) for g in grads])
+        _lib.call("ganffn_drnn_bwd", C.byref(cfg), ndir, _ptr_array(d_e), _ptr_array(U), _ptr_array(spk), _ptr_array(mval), P, G,
+                  _ptr_array(dU), _ptr_array(alpha), _ptr_array(saved), _ptr_array(ws), _ptr(ctx.rng_state), C.c_uint64(ctx.add),
+                  _stream())
+        out = [None]
+        for z in range(ndir):
+            out += [dU[z], None, None] + grads[z]
+        return tuple(out)
+
+
+def dialogue_rnn_supported(cell, U, qmask):
+    """the configuration the HIP recurrence implements: general attention, no listener, two parties, dims % 4, on a GPU"""
+    return (U.is_cuda and not cell.listener_state and getattr(cell.attention, "att_type", None) == "general"
+            and qmask.size(2) == 2 and cell.D_g == cell.D_p and cell.D_m % 4 == 0 and cell.D_g % 4 == 0 and cell.D_e % 4 == 0
+            and U.size(0) <= 112)
+
+
+def dialogue_rnn_run(cells, Us, qmasks, training):
+    """cells / Us / qmasks: one entry per direction.  -> [(emotions (S,B,D_e), [alpha_t (B,t)] for t >= 1)] per direction.
+    Dialogues run in chunks of 32 (the kernels' tile); chunks are independent."""
+    ndir = len(cells)
+    S, B = Us[0].shape[:2]
+    e_parts, a_parts = [[] for _ in range(ndir)], [[] for _ in range(ndir)]
+    for b0 in range(0, B, 32):
+        b1 = min(B, b0 + 32)
+        args = []
+        for z in range(ndir):
+            qm = qmasks[z][:, b0:b1]
+            spk = torch.argmax(qm, 2)
+            mval = qm.gather(2, spk.unsqueeze(2)).squeeze(2)
+            sd = dict(cells[z].named_parameters())
+            args += [Us[z][:, b0:b1].contiguous(), spk, mval] + [sd[k] for k in DRNN_KEYS]
+        meta = {"p": float(cells[0].dropout.p), "train": bool(training)}
+        out = DialogueRNNFn.apply(meta, *args)
+        for z in range(ndir):
+            e_parts[z].append(out[2 * z])
+            a_parts[z].append(out[2 * z + 1])
+    res = []
+    for z in range(ndir):
+        e = torch.cat(e_parts[z], 1) if len(e_parts[z]) > 1 else e_parts[z][0]
+        al = torch.cat(a_parts[z], 0) if len(a_parts[z]) > 1 else a_parts[z][0]
+        res.append((e, [al[:, t, :t] for t in range(1, S)]))
+    return res

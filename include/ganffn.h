@@ -187,6 +187,45 @@ int ganffn_general2_attention_bwd(const float* d_att, const float* x, const floa
                                   const float* alpha, const float* tanh_s, float* du_ws, float* dx,
                                   float* dmem, int S, int B, int D, void* stream);
 
+/* ---- N2 (config 5): the DialogueRNN recurrence ------------------------------------------ */
+/* Replaces DialogueRNN.forward / DialogueRNNCell.forward (model.py:828-972) in the configuration
+ * train_IEMOCAP_DialogueRNN.py runs: context_attention = "general" (:586), listener_state = False (:595), two parties.
+ * One call runs ndir (1 or 2) independent DialogueRNNs — BiModel's forward and reverse directions (model.py:1025-1033)
+ * — through the same launches.  Per direction:
+ *   U [S x B x D_m] (the reverse direction gets the reversed sequences, as BiModel._reverse_seq builds them),
+ *   spk [S x B] int32 = argmax(qmask, party), mval [S x B] = qmask[s, b, spk] (0 on padded steps),
+ *   e_out [S x B x D_e] emotion states (after dropout), alpha [B x S x S]: row t = attention weights of step t over the
+ *   global history g_0 .. g_{t-1} (zero elsewhere; the reference's per-step alpha list is alpha[:, t, :t]).
+ * Dropout (p = dropout_rec, train != 0) on g, the speaker's party state and e, Philox rows t*B + b. */
+typedef struct ganffn_drnn_cfg {
+    int32_t S, B;        /* steps (<= 112), dialogues (<= 32) */
+    int32_t Dm, H, He;   /* D_m, D_g = D_p, D_e  (100, 500, 100; multiples of 4) */
+    float p;             /* dropout_rec */
+    int32_t train;
+} ganffn_drnn_cfg;
+/* the 13 parameter tensors of one DialogueRNNCell (state_dict names under dialogue_cell.): g_cell / p_cell / e_cell
+ * weight_ih [3H x (D_m+H)] | [3H x (D_m+H)] | [3He x H], weight_hh [3H x H] | [3H x H] | [3He x He], bias_ih, bias_hh,
+ * attention.transform.weight [H x D_m] */
+typedef struct ganffn_drnn_params {
+    const float *g_wih, *g_whh, *g_bih, *g_bhh, *p_wih, *p_whh, *p_bih, *p_bhh, *e_wih, *e_whh, *e_bih, *e_bhh, *att_w;
+} ganffn_drnn_params;
+typedef struct ganffn_drnn_grads {   /* accumulated into (+=); all NULL = input gradient only */
+    float *g_wih, *g_whh, *g_bih, *g_bhh, *p_wih, *p_whh, *p_bih, *p_bhh, *e_wih, *e_whh, *e_bih, *e_bhh, *att_w;
+} ganffn_drnn_grads;
+int64_t ganffn_drnn_saved_floats(const ganffn_drnn_cfg* cfg);      /* per direction */
+int64_t ganffn_drnn_workspace_floats(const ganffn_drnn_cfg* cfg);  /* per direction; fwd and bwd */
+/* every array argument has ndir entries */
+int ganffn_drnn_fwd(const ganffn_drnn_cfg* cfg, int ndir, const float* const* U, const int32_t* const* spk,
+                    const float* const* mval, const ganffn_drnn_params* params, float* const* e_out,
+                    float* const* alpha, float* const* saved, float* const* workspace, const uint64_t* rng,
+                    uint64_t rng_offset_add, void* stream);
+/* d_e [S x B x D_e] -> dU [S x B x D_m] (written), parameter gradients accumulated */
+int ganffn_drnn_bwd(const ganffn_drnn_cfg* cfg, int ndir, const float* const* d_e, const float* const* U,
+                    const int32_t* const* spk, const float* const* mval, const ganffn_drnn_params* params,
+                    const ganffn_drnn_grads* grads, float* const* dU, const float* const* alpha,
+                    const float* const* saved, float* const* workspace, const uint64_t* rng,
+                    uint64_t rng_offset_add, void* stream);
+
 /* ---- building blocks exported for unit tests ----------------------------------------- */
 /* C[M x N] = A[M x K] * W[N x K]^T + bias (bias may be NULL) */
 int ganffn_gemm_nt(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,

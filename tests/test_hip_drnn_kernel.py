@@ -1,0 +1,137 @@
+"""N2 on the GPU: the HIP DialogueRNN recurrence (csrc/dialogue_rnn.hip; general context attention, no listener — the
+configuration train_IEMOCAP_DialogueRNN.py runs) against the torch restatement of model.py:828-972 in fp64 on the CPU:
+emotions, attention weights, input gradient and every parameter gradient; eval mode and train mode with the SAME Philox
+dropout masks; ragged dialogues (padded steps keep the party states); more than 32 dialogues (chunked)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox
+
+pytestmark = pytest.mark.gpu
+
+DIMS = dict(D_m=100, D_g=500, D_p=500, D_e=100)
+
+
+def make_inputs(S, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(max(1, S // 3), S + 1, (B,), generator=g)
+    lens[0] = S
+    valid = (torch.arange(S).unsqueeze(1) < lens.unsqueeze(0)).float()            # (S, B)
+    U = (torch.rand(S, B, 100, generator=g) - 0.3) * valid.unsqueeze(2)
+    spk = torch.randint(0, 2, (S, B), generator=g)
+    qmask = torch.nn.functional.one_hot(spk, 2).float() * valid.unsqueeze(2)
+    return U, qmask
+
+
+def build(seed=7, dropout=0.1):
+    from gan_ffn_amd import dialogue_rnn as DR
+    torch.manual_seed(seed)
+    m = DR.DialogueRNN(context_attention="general", listener_state=False, dropout=dropout, **DIMS)
+    with torch.no_grad():                       # livelier recurrent weights than the default init
+        for p in m.parameters():
+            p.mul_(1.5)
+    return m
+
+
+class _MaskSeq(torch.nn.Module):
+    """stands in for DialogueRNNCell.dropout on the CPU: multiplies by the next prepared mask (call order per step:
+    g (B,H), qs (B,P,H), e (B,He))"""
+
+    def __init__(self, masks):
+        super().__init__()
+        self.masks, self.i = masks, 0
+        self.p = 0.0
+
+    def forward(self, x):
+        m = self.masks[self.i]
+        self.i += 1
+        return x * m
+
+
+def philox_masks(S, B, H, He, p, seed, offset, direction=0):
+    out = []
+    kg = torch.from_numpy(philox.keep_mask(S * B, H, p, 8 + 4 * direction, seed, offset)).double().view(S, B, H) / (1 - p)
+    kp = torch.from_numpy(philox.keep_mask(S * B, H, p, 9 + 4 * direction, seed, offset)).double().view(S, B, H) / (1 - p)
+    ke = torch.from_numpy(philox.keep_mask(S * B, He, p, 10 + 4 * direction, seed, offset)).double().view(S, B, He) / (1 - p)
+    for t in range(S):
+        out += [kg[t], kp[t].unsqueeze(1).expand(-1, 2, -1), ke[t]]
+    return out
+
+
+def compare(m_gpu, m_cpu, U, qmask, e_tol=2e-5, g_tol=3e-4):
+    Ug = U.cuda().requires_grad_(True)
+    e, alpha = m_gpu(Ug, qmask.cuda())
+    Uc = U.double().requires_grad_(True)
+    e_ref, alpha_ref = m_cpu(Uc, qmask.double())
+    S, B = U.shape[:2]
+    assert e.shape == e_ref.shape and len(alpha) == len(alpha_ref) == S - 1
+
+    def rel(a, b):
+        return float((a.detach().cpu().double() - b.detach()).abs().max() / b.detach().abs().max().clamp_min(1e-30))
+    assert rel(e, e_ref) < e_tol
+    for t, (a, ar) in enumerate(zip(alpha, alpha_ref)):
+        assert a.shape == ar.shape and float((a.detach().cpu().double() - ar.detach()).abs().max()) < 2e-5, t
+    gy = torch.rand(e_ref.shape, generator=torch.Generator().manual_seed(3)) - 0.5
+    (e * gy.cuda()).sum().backward()
+    (e_ref * gy.double()).sum().backward()
+    assert rel(Ug.grad, Uc.grad) < g_tol
+    pc = dict(m_cpu.named_parameters())
+    for k, p in m_gpu.named_parameters():
+        assert p.grad is not None, k
+        if pc[k].grad is None:          # S = 1: no attention step, torch leaves the transform's gradient unset
+            assert float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert rel(p.grad, pc[k].grad) < g_tol, k
+
+
+@pytest.mark.parametrize("S,B", [(7, 3), (23, 5), (94, 30), (33, 40), (1, 2), (110, 4)])
+def test_eval_mode_matches_torch_restatement(S, B):
+    import copy
+    U, qmask = make_inputs(S, B, seed=S * 100 + B)
+    m_cpu = build().double().eval()
+    m_gpu = copy.deepcopy(m_cpu).float().cuda().eval()
+    compare(m_gpu, m_cpu, U, qmask)
+
+
+@pytest.mark.parametrize("S,B", [(9, 4), (94, 30)])
+def test_train_mode_matches_torch_restatement_with_the_same_philox_masks(S, B):
+    import copy
+    from gan_ffn_amd import ops
+    U, qmask = make_inputs(S, B, seed=S + B)
+    p, seed = 0.1, 20261004
+    m_cpu = build(dropout=p).double().train()
+    m_gpu = copy.deepcopy(m_cpu).float().cuda().train()
+    m_cpu.dialogue_cell.dropout = _MaskSeq(philox_masks(S, B, 500, 100, p, seed, 0))
+    ops.manual_seed(seed)                       # the call below takes rng offset 0
+    compare(m_gpu, m_cpu, U, qmask)
+
+
+def test_bimodel_uses_the_hip_recurrence_and_matches_its_cpu_self():
+    """BiModel on the GPU (both directions through one chain of launches) == the same module on the CPU (torch ops),
+    forward and every gradient, ragged batch"""
+    import copy
+    from gan_ffn_amd import dialogue_rnn as DR
+    torch.manual_seed(2)
+    m_cpu = DR.BiModel(D_m=100, D_g=500, D_p=500, D_e=100, D_h=100, n_classes=6, context_attention="general", listener_state=False,
+                       dropout_rec=0.1, dropout=0.6).double().eval()
+    m_gpu = copy.deepcopy(m_cpu).float().cuda().eval()
+    S, B = 19, 6
+    U, qmask = make_inputs(S, B, seed=77)
+    umask = (qmask.sum(2) > 0).float().t().contiguous()
+    Ug = U.cuda().requires_grad_(True)
+    lp, alpha, af, ab = m_gpu(Ug, qmask.cuda(), umask.cuda())
+    Uc = U.double().requires_grad_(True)
+    lp_r, alpha_r, af_r, ab_r = m_cpu(Uc, qmask.double(), umask.double())
+    assert float((lp.detach().cpu().double() - lp_r.detach()).abs().max()) < 5e-5
+    for a, ar in zip(af + ab, af_r + ab_r):
+        assert float((a.detach().cpu().double() - ar.detach()).abs().max()) < 2e-5
+    gy = torch.rand(lp_r.shape, generator=torch.Generator().manual_seed(5)) - 0.5
+    (lp * gy.cuda()).sum().backward()
+    (lp_r * gy.double()).sum().backward()
+    sc = float(Uc.grad.abs().max())
+    assert float((Ug.grad.cpu().double() - Uc.grad).abs().max()) < 5e-4 * sc
+    pc = dict(m_cpu.named_parameters())
+    for k, p in m_gpu.named_parameters():
+        ref = pc[k].grad
+        assert float((p.grad.cpu().double() - ref).abs().max()) < 5e-4 * max(float(ref.abs().max()), 1e-30), k
