@@ -142,6 +142,57 @@ def time_dominant_kernel(S, B, reps=3, config="iemocap"):
     return e0.elapsed_time(e1) * 1e-3 / (reps * n), flops, n
 
 
+def time_linear1_kernel(S, B, reps=3):
+    """Live HIP-event timing (launch stream = torch's current stream) of the heavy kernel that sits lowest on its roofline:
+    the d_model-100 feed-forward linear1 GEMM with its fused bias + ReLU + dropout epilogue, `gemm_kernel<0,64,64,16,1,2,2,1>`
+    ([T x 100] x [2048 x 100]^T; K = 100 is seven 16-wide K tiles per workgroup).  One iteration launches it 112 times at
+    T = S*B (4 generator + 6 frozen-discriminator + 4 no-save generator passes x 8 layers) and 48 times at T = 2*S*B (the
+    six batched [real | fake] discriminator passes).  Returns (avg seconds per launch, avg algorithmic flops per launch, launches)."""
+    from gan_ffn_amd import _lib, ops
+    st = ops._stream()
+    E, F = 100, 2048
+    rng = torch.tensor([3407, 0], dtype=torch.int64, device="cuda")
+    calls = []
+    for T, cnt in ((S * B, 112), (2 * S * B, 48)):
+        x = torch.rand(T, E, device="cuda") - 0.5
+        w1, b1 = (torch.rand(F, E, device="cuda") - 0.5) * 0.2, torch.zeros(F, device="cuda")
+        h = torch.empty(T, F, device="cuda")
+        calls.append((cnt, T, (x, w1, b1, h)))
+
+    def one_iteration():
+        for cnt, T, (x, w1, b1, h) in calls:
+            for _ in range(cnt):
+                _lib.call("ganffn_ffn_linear1_fwd", ops._ptr(x), ops._ptr(w1), ops._ptr(b1), ops._ptr(h), T, E, F, C.c_float(0.1),
+                          C.c_uint32(18), ops._ptr(rng), C.c_uint64(0), 1, st)
+    one_iteration()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        one_iteration()
+    e1.record()
+    torch.cuda.synchronize()
+    n = sum(c[0] for c in calls)
+    flops = sum(c[0] * 2.0 * c[1] * E * F for c in calls) / n
+    return e0.elapsed_time(e1) * 1e-3 / (reps * n), flops, n
+
+
+IN_STEP_FILE = "profiles/r02_bench_streams1_by_launch_shape.txt"
+
+
+def in_step_kernel_us(symbol_prefix, grid):
+    """average duration of a (kernel, grid) row of the committed single-stream rocprofv3 summary, or None"""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), IN_STEP_FILE)
+    try:
+        for line in open(path):
+            f = line.split()
+            if len(f) >= 5 and f[3] == grid and " ".join(f[4:]).startswith(symbol_prefix):
+                return float(f[2])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(S, B_sample, threads, dropout=True, config="iemocap"):
     """Stock-PyTorch CPU execution (oracle/stock_modules.py: nn.TransformerEncoder stacks, train-mode dropout,
     the reference's sub-step logic) of ONE full 12-sub-step iteration on a bounded sample: B_sample dialogues of
@@ -341,7 +392,9 @@ def main():
                        "step_frac_of_fp32_mfma_peak": round(step_tflops * 1e12 / (FP32_MFMA_PEAK * world), 4),
                        "last_losses": {k: round(v, 4) for k, v in losses.items()}},
             "roofline": {"bound": "mfma", "kernel": "gemm_tn_grouped_kernel (all 32 weight-gradient GEMMs of one encoder backward pass in one "
-                                                     "launch, split-K + fp32 atomics); %d launches per iteration, largest share of GPU time" % klaunch,
+                                                     "launch: one owner workgroup per output tile over the whole token range, no atomics); "
+                                                     "%d launches per iteration; the (kernel, launch shape) with the largest share of GPU "
+                                                     "time in the single-stream profile" % klaunch,
                          "achieved": round(kflop / kt / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": round(kflop / kt / FP32_MFMA_PEAK, 4), "traffic": traffic,
                          "traffic_unit": "bytes per launch (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE, separate "
@@ -350,6 +403,20 @@ def main():
                          "avg_kernel_us": round(kt * 1e6, 2), "avg_gflop_per_launch": round(kflop / 1e9, 4),
                          "how": "HIP events around one iteration's launch mix of this kernel replayed in isolation on the launch stream"},
         }
+        if cfgname == "iemocap":
+            # the heavy kernel (>= 5 % of GPU time in profiles/r02_bench_streams1_*) that sits LOWEST on its roofline
+            lt, lflop, ln = time_linear1_kernel(S, B)
+            ins = in_step_kernel_us("gemm_kernel<0, 64, 64, 16, 1, 2, 2, 1>", "(32,47,1)") if (S, B) == (94, 32) else None
+            out["roofline_worst"] = {
+                "bound": "mfma", "kernel": "gemm_kernel<0,64,64,16,1,2,2,1> = linear1 of the d_model-100 feed-forward block with fused "
+                                           "bias + ReLU + dropout ([T x 100] x [2048 x 100]^T, K = 100); %d launches per iteration" % ln,
+                "achieved": round(lflop / lt / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": round(lflop / lt / FP32_MFMA_PEAK, 4), "avg_kernel_us": round(lt * 1e6, 2),
+                "avg_gflop_per_launch": round(lflop / 1e9, 4), "traffic": None,
+                "in_step_avg_us_T%d" % (S * B): ins,
+                "in_step_frac_T%d" % (S * B): round(2.0 * S * B * 100 * 2048 / (ins * 1e-6) / FP32_MFMA_PEAK, 4) if ins else None,
+                "how": "HIP events around one iteration's launch mix of this kernel replayed in isolation on the launch stream; "
+                       "in_step_* = the same kernel's average inside the step, from the committed rocprofv3 summary " + IN_STEP_FILE}
         if world == 1 and not args.no_cpu_baseline:
             threads = host_threads()
             cv, cdt, cutts = cpu_baseline(S, args.cpu_sample_batch, threads, config=cfgname)

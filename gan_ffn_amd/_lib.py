@@ -63,6 +63,8 @@ SIGNATURES = {
     "ganffn_bce2_fwd": (_I, [_P, _F, _F, _I, _I, _I, _F, _P, _I, _P]),
     "ganffn_bce2_bwd": (_I, [_P, _F, _F, _I, _I, _I, _F, _P, _P]),
     "ganffn_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P]),
+    "ganffn_adam_update": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P]),
+    "ganffn_adam_bump": (_I, [_P, _P]),
     "ganffn_add3": (_I, [_P, _P, _P, _P, _L, _P]),
     "ganffn_logsoftmax_nll": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ganffn_gemm_nt": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

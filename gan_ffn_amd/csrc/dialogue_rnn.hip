@@ -37,6 +37,7 @@ struct SkinnyProb {
     const float* A; int lda;      // [M x K]
     const float* W; int ldw;      // NT: [N x K];  NN: [K x N]
     const float* Cin; int ldcin;  // optional addend [M x N]
+    const float* Cin2;            // optional second addend [M x N], leading dimension ldc (may be C itself: in-place +=)
     const float* bias;            // optional [N]
     float* C; int ldc;            // [M x N]
     int M, N, K;
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyGroup grp) {
                 if (n + r < q.N) {
                     float o = v[r];
                     if (q.Cin) o += q.Cin[(size_t)b * q.ldcin + n + r];
+                    if (q.Cin2) o += q.Cin2[(size_t)b * q.ldc + n + r];
                     if (q.bias) o += q.bias[n + r];
                     q.C[(size_t)b * q.ldc + n + r] = o;
                 }
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(512) void skinny_nn_kernel(SkinnyGroup grp) {
 #pragma unroll
                 for (int ww = 0; ww < 8; ++ww) o += red[ww][mt][r][lane];
                 if (q.Cin) o += q.Cin[(size_t)b * q.ldcin + n];
+                if (q.Cin2) o += q.Cin2[(size_t)b * q.ldc + n];
                 q.C[(size_t)b * q.ldc + n] = o;
             }
         }
@@ -247,6 +250,7 @@ struct GateBwdDir {
     float* dGI; float* dGH; // [B x 3H] gate gradients (kept for the weight-gradient GEMMs)
     float* dhdir;           // [B x H] direct path to hprev: dh' * z (+ (1 - m) dq for the party cell)
     const float* mval;      // party cell: [B]
+    const int* spk;         // party cell: [B]; dh is then the [B x 2 x H] gradient wrt Q[t+1], read at party spk[b]
     uint32_t site;
 };
 struct GateBwdArgs {
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(GateBwdArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.B * a.H) return;
     const int b = idx / a.H, u = idx - b * a.H, H3 = 3 * a.H;
-    float dout = d.dh[idx];
+    float dout = PARTY ? d.dh[((size_t)b * 2 + d.spk[b]) * a.H + u] : d.dh[idx];
     if (d.dh2) dout += d.dh2[idx];
     float pass = 0.f;
     if (PARTY) {
@@ -298,44 +302,82 @@ struct AttnDir {
 };
 struct AttnArgs { AttnDir d[2]; int B, H, S, t; };
 
-__global__ __launch_bounds__(256) void drnn_attn_fwd_kernel(AttnArgs a) {
-    __shared__ float sc[DR_MAXS];
-    __shared__ float red[4];
+// 1024 threads per (dialogue, direction).  The work is tiny (t x H multiply-adds) and latency-bound, so every phase keeps
+// many independent loads in flight: 16 waves take 2 history steps each per pass for the scores, and the pooling splits
+// the history in two halves per column with 8 loads in flight per thread.
+constexpr int DR_AT = 1024;
+__device__ __forceinline__ void drnn_scores(const float* __restrict__ q, const float* __restrict__ G, int B, int H, int b, int t,
+                                            float* __restrict__ out, int lane, int w) {
+    float qr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qr[i] = lane + 64 * i < H ? q[lane + 64 * i] : 0.f;
+    for (int j0 = w; j0 < t; j0 += 32) {
+        const int j1 = min(j0 + 16, t - 1);
+        const float* g0 = G + ((size_t)(j0 + 1) * B + b) * H;
+        const float* g1 = G + ((size_t)(j1 + 1) * B + b) * H;
+        float v0[8], v1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = min(lane + 64 * i, H - 1);
+            v0[i] = g0[k];
+            v1[i] = g1[k];
+        }
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s0 += qr[i] * v0[i]; s1 += qr[i] * v1[i]; }
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        if (lane == 0) {
+            out[j0] = s0;
+            if (j0 + 16 < t) out[j0 + 16] = s1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(DR_AT) void drnn_attn_fwd_kernel(AttnArgs a) {
+    __shared__ float sc[DR_MAXS + 16];
+    __shared__ float red[2];
+    __shared__ float part[512];
     const AttnDir& d = a.d[blockIdx.z];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, t = a.t;
-    const float* x = d.XA + (size_t)b * a.H;
-    for (int j = w; j < t; j += 4) {
-        const float* gj = d.G + ((size_t)(j + 1) * a.B + b) * a.H;
-        float s = 0.f;
-        for (int k = lane; k < a.H; k += 64) s += x[k] * gj[k];
-        s = wave_sum(s);
-        if (lane == 0) sc[j] = s;
-    }
+    drnn_scores(d.XA + (size_t)b * a.H, d.G, a.B, a.H, b, t, sc, lane, w);     // H <= 512 (checked on the host)
     __syncthreads();
-    float m = -INFINITY;
-    for (int j = tid; j < t; j += 256) m = fmaxf(m, sc[j]);
-    m = wave_max(m);
-    if (lane == 0) red[w] = m;
+    // softmax over t <= 112 scores: the first two waves
+    float v = tid < t ? sc[tid] : -INFINITY;
+    float m = wave_max(v);
+    if (tid < 128 && lane == 0) red[w] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    m = fmaxf(red[0], red[1]);
     __syncthreads();
-    float e = 0.f;
-    if (tid < t) { e = __expf(sc[tid] - m); sc[tid] = e; }
-    e = wave_sum(e);
-    if (lane == 0) red[w] = e;
+    float e = tid < t ? __expf(v - m) : 0.f;
+    const float es = wave_sum(e);
+    if (tid < 128 && lane == 0) red[w] = es;
     __syncthreads();
-    const float inv = 1.0f / (((red[0] + red[1]) + red[2]) + red[3]);
+    const float inv = 1.0f / (red[0] + red[1]);
     if (tid < t) {
-        const float al = sc[tid] * inv;
+        const float al = e * inv;
         sc[tid] = al;
         d.alpha[((size_t)b * a.S + t) * a.S + tid] = al;
     }
     __syncthreads();
-    for (int k = tid; k < a.H; k += 256) {
-        float c = 0.f;
-        for (int j = 0; j < t; ++j) c += sc[j] * d.G[((size_t)(j + 1) * a.B + b) * a.H + k];
-        d.CT[(size_t)b * a.H + k] = c;
+    // context: c_k = sum_j alpha_j g_j[k]; thread (k, half) sums its half of the history, 8 loads in flight
+    const int k = tid & 511, half = tid >> 9, jmid = (t + 1) >> 1;
+    const int jb = half ? jmid : 0, je = half ? t : jmid;
+    float c = 0.f;
+    if (k < a.H) {
+        const float* gk = d.G + ((size_t)a.B + b) * a.H + k;          // g_0[k]; step j adds j * B * H
+        const size_t st = (size_t)a.B * a.H;
+        for (int j = jb; j < je; j += 8) {
+            float g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g[u] = gk[(size_t)min(j + u, je - 1) * st];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c += (j + u < je ? sc[j + u] : 0.f) * g[u];
+        }
     }
+    if (half) part[k] = c;
+    __syncthreads();
+    if (!half && k < a.H) d.CT[(size_t)b * a.H + k] = c + part[k];
 }
 
 struct AttnBwdDir {
@@ -348,41 +390,53 @@ struct AttnBwdDir {
 };
 struct AttnBwdArgs { AttnBwdDir d[2]; int B, H, S, t; };
 
-__global__ __launch_bounds__(256) void drnn_attn_bwd_kernel(AttnBwdArgs a) {
-    __shared__ float da[DR_MAXS];
-    __shared__ float al[DR_MAXS];
-    __shared__ float red[4];
+__global__ __launch_bounds__(DR_AT) void drnn_attn_bwd_kernel(AttnBwdArgs a) {
+    __shared__ float da[DR_MAXS + 16];
+    __shared__ float al[DR_MAXS + 16];
+    __shared__ float red[2];
+    __shared__ float part[512];
     const AttnBwdDir& d = a.d[blockIdx.z];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, t = a.t;
     const float* dc = d.dCT + (size_t)b * a.H;
-    for (int j = w; j < t; j += 4) {
-        const float* gj = d.G + ((size_t)(j + 1) * a.B + b) * a.H;
-        float s = 0.f;
-        for (int k = lane; k < a.H; k += 64) s += dc[k] * gj[k];
-        s = wave_sum(s);
-        if (lane == 0) da[j] = s;
-    }
+    drnn_scores(dc, d.G, a.B, a.H, b, t, da, lane, w);                 // d alpha_j = <dc, g_j>
     if (tid < t) al[tid] = d.alpha[((size_t)b * a.S + t) * a.S + tid];
     __syncthreads();
     float dot = tid < t ? al[tid] * da[tid] : 0.f;
     dot = wave_sum(dot);
-    if (lane == 0) red[w] = dot;
+    if (tid < 128 && lane == 0) red[w] = dot;
     __syncthreads();
-    const float tot = ((red[0] + red[1]) + red[2]) + red[3];
+    const float tot = red[0] + red[1];
     __syncthreads();
-    if (tid < t) da[tid] = al[tid] * (da[tid] - tot);      // d score_j
+    if (tid < t) da[tid] = al[tid] * (da[tid] - tot);                  // d score_j
     __syncthreads();
-    const float* x = d.XA + (size_t)b * a.H;
-    for (int k = tid; k < a.H; k += 256) {
-        const float dck = dc[k], xk = x[k];
-        float dx = 0.f;
-        for (int j = 0; j < t; ++j) {
-            const size_t o = ((size_t)(j + 1) * a.B + b) * a.H + k;
-            dx += da[j] * d.G[o];
-            d.dG[o] += al[j] * dck + da[j] * xk;             // this (dialogue, k) is owned by this thread: no race
+    // dXA_k = sum_j dscore_j g_j[k];  dG[j][k] += alpha_j dc_k + dscore_j x_k.  Thread (k, half) owns column k of its half of
+    // the history: no other thread touches those dG elements (no race, no atomics).
+    const int k = tid & 511, half = tid >> 9, jmid = (t + 1) >> 1;
+    const int jb = half ? jmid : 0, je = half ? t : jmid;
+    float dx = 0.f;
+    if (k < a.H) {
+        const float dck = dc[k], xk = d.XA[(size_t)b * a.H + k];
+        const size_t st = (size_t)a.B * a.H, base = ((size_t)a.B + b) * a.H + k;
+        for (int j = jb; j < je; j += 8) {
+            float g[8], og[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const size_t o = base + (size_t)min(j + u, je - 1) * st;
+                g[u] = d.G[o];
+                og[u] = d.dG[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j + u < je) {
+                    dx += da[j + u] * g[u];
+                    d.dG[base + (size_t)(j + u) * st] = og[u] + al[j + u] * dck + da[j + u] * xk;
+                }
+            }
         }
-        d.dXA[(size_t)b * a.H + k] = dx;
     }
+    if (half) part[k] = dx;
+    __syncthreads();
+    if (!half && k < a.H) d.dXA[(size_t)b * a.H + k] = dx + part[k];
 }
 
 // out[b][s][:] (+)= in[b][:] into party s = spk[b] of a [B x 2 x H] tensor; the other party is copied from `other`
@@ -401,15 +455,6 @@ __global__ __launch_bounds__(256) void drnn_party_grad_kernel(PartyAddArgs a) {
     a.dQout[z][((size_t)b * 2 + s) * a.H + u] = a.dQSp[z][idx] + a.dQSg[z][idx];
     a.dQout[z][((size_t)b * 2 + (1 - s)) * a.H + u] = a.dQ[z][((size_t)b * 2 + (1 - s)) * a.H + u];
 }
-// gather dq_spk[b][:] = dQ[b][spk[b]][:] + add[b][:]
-struct PartySelArgs { const float* dQ[2]; const float* add[2]; float* out[2]; const int* spk[2]; int B, H; };
-__global__ __launch_bounds__(256) void drnn_party_sel_kernel(PartySelArgs a) {
-    const int z = blockIdx.z, idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.B * a.H) return;
-    const int b = idx / a.H, u = idx - b * a.H;
-    a.out[z][idx] = a.dQ[z][((size_t)b * 2 + a.spk[z][b]) * a.H + u] + a.add[z][idx];
-}
-
 // ------------------------------------------------------------------------------------------
 // layouts
 // ------------------------------------------------------------------------------------------
@@ -454,6 +499,7 @@ static int check_drnn(const ganffn_drnn_cfg* c, int ndir) {
     GF_CHECK_ARG(c->S >= 1 && c->S <= DR_MAXS && c->B >= 1 && c->B <= 32, "drnn: S=%d (<= %d), B=%d (<= 32)", c->S, DR_MAXS, c->B);
     GF_CHECK_ARG(c->Dm >= 4 && (c->Dm & 3) == 0 && c->H >= 4 && (c->H & 3) == 0 && c->He >= 4 && (c->He & 3) == 0,
                  "drnn: D_m=%d, D_g=D_p=%d, D_e=%d must be multiples of 4", c->Dm, c->H, c->He);
+    GF_CHECK_ARG(c->H <= 512, "drnn: D_g = D_p = %d > 512 (attention kernels hold one column per thread)", c->H);
     GF_CHECK_ARG(c->p >= 0.f && c->p < 1.f, "drnn: dropout p out of [0,1)");
     return 0;
 }
@@ -512,9 +558,8 @@ extern "C" int ganffn_drnn_fwd(const ganffn_drnn_cfg* c, int ndir, const float* 
         // ---- global cell: GI = XG[t] + QS[t] Wih_g[:, Dm:]^T ; GH = G[t] Whh_g^T + bhh_g
         for (int z = 0; z < ndir; ++z) {
             float* sv = saved[z]; float* ws = workspace[z];
-            sg.p[2 * z] = SkinnyProb{sv + so.QS + r0 * H, H, prm[z].g_wih + Dm, Dm + H, sv + so.XG + r0 * 3 * H, 3 * H, nullptr,
-                                     ws + wo.GI, 3 * H, B, 3 * H, H};
-            sg.p[2 * z + 1] = SkinnyProb{sv + so.G + r0 * H, H, prm[z].g_whh, H, nullptr, 0, prm[z].g_bhh, ws + wo.GH, 3 * H, B, 3 * H, H};
+            sg.p[2 * z] = SkinnyProb{sv + so.QS + r0 * H, H, prm[z].g_wih + Dm, Dm + H, sv + so.XG + r0 * 3 * H, 3 * H, nullptr, nullptr, ws + wo.GI, 3 * H, B, 3 * H, H};
+            sg.p[2 * z + 1] = SkinnyProb{sv + so.G + r0 * H, H, prm[z].g_whh, H, nullptr, 0, nullptr, prm[z].g_bhh, ws + wo.GH, 3 * H, B, 3 * H, H};
         }
         GF_TRY(launch_skinny(sg, 2 * ndir, false, st));
         GateArgs ga;
@@ -533,15 +578,14 @@ extern "C" int ganffn_drnn_fwd(const ganffn_drnn_cfg* c, int ndir, const float* 
             aa.B = B; aa.H = H; aa.S = S; aa.t = t;
             for (int z = 0; z < ndir; ++z)
                 aa.d[z] = AttnDir{saved[z] + so.XA + r0 * H, saved[z] + so.G, saved[z] + so.CT + r0 * H, alpha[z]};
-            hipLaunchKernelGGL(drnn_attn_fwd_kernel, dim3(B, 1, ndir), dim3(256), 0, st, aa);
+            hipLaunchKernelGGL(drnn_attn_fwd_kernel, dim3(B, 1, ndir), dim3(DR_AT), 0, st, aa);
             GF_LAUNCH_CHECK();
         }
         // ---- party cell (speaker): GI = XP[t] + CT[t] Wih_p[:, Dm:]^T ; GH = QS[t] Whh_p^T + bhh_p
         for (int z = 0; z < ndir; ++z) {
             float* sv = saved[z]; float* ws = workspace[z];
-            sg.p[2 * z] = SkinnyProb{sv + so.CT + r0 * H, H, prm[z].p_wih + Dm, Dm + H, sv + so.XP + r0 * 3 * H, 3 * H, nullptr,
-                                     ws + wo.GI, 3 * H, B, 3 * H, H};
-            sg.p[2 * z + 1] = SkinnyProb{sv + so.QS + r0 * H, H, prm[z].p_whh, H, nullptr, 0, prm[z].p_bhh, ws + wo.GH, 3 * H, B, 3 * H, H};
+            sg.p[2 * z] = SkinnyProb{sv + so.CT + r0 * H, H, prm[z].p_wih + Dm, Dm + H, sv + so.XP + r0 * 3 * H, 3 * H, nullptr, nullptr, ws + wo.GI, 3 * H, B, 3 * H, H};
+            sg.p[2 * z + 1] = SkinnyProb{sv + so.QS + r0 * H, H, prm[z].p_whh, H, nullptr, 0, nullptr, prm[z].p_bhh, ws + wo.GH, 3 * H, B, 3 * H, H};
         }
         GF_TRY(launch_skinny(sg, 2 * ndir, false, st));
         for (int z = 0; z < ndir; ++z) {
@@ -556,8 +600,8 @@ extern "C" int ganffn_drnn_fwd(const ganffn_drnn_cfg* c, int ndir, const float* 
         // ---- emotion cell: GI = QN[t] Wih_e^T + bih_e ; GH = E[t] Whh_e^T + bhh_e
         for (int z = 0; z < ndir; ++z) {
             float* sv = saved[z]; float* ws = workspace[z];
-            sg.p[2 * z] = SkinnyProb{sv + so.QN + r0 * H, H, prm[z].e_wih, H, nullptr, 0, prm[z].e_bih, ws + wo.GI, 3 * He, B, 3 * He, H};
-            sg.p[2 * z + 1] = SkinnyProb{sv + so.E + r0 * He, He, prm[z].e_whh, He, nullptr, 0, prm[z].e_bhh, ws + wo.GH, 3 * He, B, 3 * He, He};
+            sg.p[2 * z] = SkinnyProb{sv + so.QN + r0 * H, H, prm[z].e_wih, H, nullptr, 0, nullptr, prm[z].e_bih, ws + wo.GI, 3 * He, B, 3 * He, H};
+            sg.p[2 * z + 1] = SkinnyProb{sv + so.E + r0 * He, He, prm[z].e_whh, He, nullptr, 0, nullptr, prm[z].e_bhh, ws + wo.GH, 3 * He, B, 3 * He, He};
         }
         GF_TRY(launch_skinny(sg, 2 * ndir, false, st));
         ga.H = He;
@@ -615,41 +659,32 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
             const float* sv = saved[z]; float* ws = workspace[z];
             gb.d[z] = GateBwdDir{ws + dEin, d_e[z] + r0 * He, sv + so.Re + r0 * He, sv + so.Ze + r0 * He, sv + so.Ne + r0 * He,
                                  sv + so.HNe + r0 * He, sv + so.E + r0 * He, ws + wo.dGIe + r0 * 3 * He, ws + wo.dGHe + r0 * 3 * He,
-                                 ws + wo.dhdir, nullptr, SITE_DRNN_E + 4u * z};
+                                 ws + wo.dhdir, nullptr, nullptr, SITE_DRNN_E + 4u * z};
         }
         hipLaunchKernelGGL(gru_gate_bwd_kernel<0>, gHe, dim3(256), 0, st, gb);
         GF_LAUNCH_CHECK();
         for (int z = 0; z < ndir; ++z) {
             float* ws = workspace[z];
             // dQN[t] = dGI_e Wih_e ; dE_rec = dGH_e Whh_e + dhdir
-            sg.p[2 * z] = SkinnyProb{ws + wo.dGIe + r0 * 3 * He, 3 * He, prm[z].e_wih, H, nullptr, 0, nullptr, ws + wo.dQN, H, B, H, 3 * He};
-            sg.p[2 * z + 1] = SkinnyProb{ws + wo.dGHe + r0 * 3 * He, 3 * He, prm[z].e_whh, He, ws + wo.dhdir, He, nullptr, ws + dEout, He, B,
-                                         He, 3 * He};
+            sg.p[2 * z] = SkinnyProb{ws + wo.dGIe + r0 * 3 * He, 3 * He, prm[z].e_wih, H, nullptr, 0, nullptr, nullptr, ws + wo.dQN, H, B, H, 3 * He};
+            sg.p[2 * z + 1] = SkinnyProb{ws + wo.dGHe + r0 * 3 * He, 3 * He, prm[z].e_whh, He, ws + wo.dhdir, He, nullptr, nullptr, ws + dEout, He, B, He, 3 * He};
         }
         GF_TRY(launch_skinny(sg, 2 * ndir, true, st));
-        // ---- party cell: dq_spk = dQ[t+1][spk] + dQN
-        PartySelArgs ps;
-        ps.B = B; ps.H = H;
-        for (int z = 0; z < ndir; ++z) {
-            float* ws = workspace[z];
-            ps.dQ[z] = ws + dQin; ps.add[z] = ws + wo.dQN; ps.out[z] = ws + wo.dQsel; ps.spk[z] = spk[z] + r0;
-        }
-        hipLaunchKernelGGL(drnn_party_sel_kernel, gH, dim3(256), 0, st, ps);
-        GF_LAUNCH_CHECK();
+        // ---- party cell: gradient wrt Q[t+1][spk] = dQ[t+1][spk] + dQN (selected inside the gate kernel)
         gb.H = H;
         for (int z = 0; z < ndir; ++z) {
             const float* sv = saved[z]; float* ws = workspace[z];
-            gb.d[z] = GateBwdDir{ws + wo.dQsel, nullptr, sv + so.Rp + r0 * H, sv + so.Zp + r0 * H, sv + so.Np + r0 * H, sv + so.HNp + r0 * H,
+            gb.d[z] = GateBwdDir{ws + dQin, ws + wo.dQN, sv + so.Rp + r0 * H, sv + so.Zp + r0 * H, sv + so.Np + r0 * H, sv + so.HNp + r0 * H,
                                  sv + so.QS + r0 * H, ws + wo.dGIp + r0 * 3 * H, ws + wo.dGHp + r0 * 3 * H, ws + wo.dhdir, mval[z] + r0,
-                                 SITE_DRNN_P + 4u * z};
+                                 spk[z] + r0, SITE_DRNN_P + 4u * z};
         }
         hipLaunchKernelGGL(gru_gate_bwd_kernel<1>, gH, dim3(256), 0, st, gb);
         GF_LAUNCH_CHECK();
         for (int z = 0; z < ndir; ++z) {
             float* ws = workspace[z];
             // dCT[t] = dGI_p Wih_p[:, Dm:] ; dQS_p = dGH_p Whh_p + dhdir
-            sg.p[2 * z] = SkinnyProb{ws + wo.dGIp + r0 * 3 * H, 3 * H, prm[z].p_wih + Dm, Dm + H, nullptr, 0, nullptr, ws + wo.dCT, H, B, H, 3 * H};
-            sg.p[2 * z + 1] = SkinnyProb{ws + wo.dGHp + r0 * 3 * H, 3 * H, prm[z].p_whh, H, ws + wo.dhdir, H, nullptr, ws + wo.dQSp, H, B, H, 3 * H};
+            sg.p[2 * z] = SkinnyProb{ws + wo.dGIp + r0 * 3 * H, 3 * H, prm[z].p_wih + Dm, Dm + H, nullptr, 0, nullptr, nullptr, ws + wo.dCT, H, B, H, 3 * H};
+            sg.p[2 * z + 1] = SkinnyProb{ws + wo.dGHp + r0 * 3 * H, 3 * H, prm[z].p_whh, H, ws + wo.dhdir, H, nullptr, nullptr, ws + wo.dQSp, H, B, H, 3 * H};
         }
         GF_TRY(launch_skinny(sg, 2 * ndir, true, st));
         // ---- attention
@@ -659,7 +694,7 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
             for (int z = 0; z < ndir; ++z)
                 ab.d[z] = AttnBwdDir{workspace[z] + wo.dCT, saved[z] + so.XA + r0 * H, saved[z] + so.G, alpha[z], workspace[z] + wo.dG,
                                      workspace[z] + wo.dXA + r0 * H};
-            hipLaunchKernelGGL(drnn_attn_bwd_kernel, dim3(B, 1, ndir), dim3(256), 0, st, ab);
+            hipLaunchKernelGGL(drnn_attn_bwd_kernel, dim3(B, 1, ndir), dim3(DR_AT), 0, st, ab);
             GF_LAUNCH_CHECK();
         }
         // ---- global cell: dg_t = dG[t+1] (attention uses at later steps + the recurrent path, both already added)
@@ -667,19 +702,18 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
             const float* sv = saved[z]; float* ws = workspace[z];
             gb.d[z] = GateBwdDir{ws + wo.dG + r1 * H, nullptr, sv + so.Rg + r0 * H, sv + so.Zg + r0 * H, sv + so.Ng + r0 * H, sv + so.HNg + r0 * H,
                                  sv + so.G + r0 * H, ws + wo.dGIg + r0 * 3 * H, ws + wo.dGHg + r0 * 3 * H, ws + wo.dhdir, nullptr,
-                                 SITE_DRNN_G + 4u * z};
+                                 nullptr, SITE_DRNN_G + 4u * z};
         }
         hipLaunchKernelGGL(gru_gate_bwd_kernel<0>, gH, dim3(256), 0, st, gb);
         GF_LAUNCH_CHECK();
         for (int z = 0; z < ndir; ++z) {
             float* ws = workspace[z];
-            // dQS_g = dGI_g Wih_g[:, Dm:] ; dG[t] += dGH_g Whh_g + dhdir   (Cin = dG[t] + ... : two addends -> use dhdir first)
-            sg.p[2 * z] = SkinnyProb{ws + wo.dGIg + r0 * 3 * H, 3 * H, prm[z].g_wih + Dm, Dm + H, nullptr, 0, nullptr, ws + wo.dQSg, H, B, H, 3 * H};
-            sg.p[2 * z + 1] = SkinnyProb{ws + wo.dGHg + r0 * 3 * H, 3 * H, prm[z].g_whh, H, ws + wo.dhdir, H, nullptr, ws + wo.dQN, H, B, H, 3 * H};
+            // dQS_g = dGI_g Wih_g[:, Dm:] ; dG[t] += dGH_g Whh_g + dhdir (in place: second addend = the output block itself)
+            sg.p[2 * z] = SkinnyProb{ws + wo.dGIg + r0 * 3 * H, 3 * H, prm[z].g_wih + Dm, Dm + H, nullptr, 0, nullptr, nullptr, ws + wo.dQSg, H, B, H, 3 * H};
+            sg.p[2 * z + 1] = SkinnyProb{ws + wo.dGHg + r0 * 3 * H, 3 * H, prm[z].g_whh, H, ws + wo.dhdir, H, ws + wo.dG + r0 * H, nullptr,
+                                         ws + wo.dG + r0 * H, H, B, H, 3 * H};
         }
         GF_TRY(launch_skinny(sg, 2 * ndir, true, st));
-        for (int z = 0; z < ndir; ++z)                      // dG[t] += (dGH_g Whh_g + dhdir), held in the dQN scratch
-            GF_TRY(launch_add_inplace(workspace[z] + wo.dG + r0 * H, workspace[z] + wo.dQN, (int64_t)B * H, st));
         // ---- gradient wrt Q[t]
         PartyAddArgs pa;
         pa.B = B; pa.H = H;

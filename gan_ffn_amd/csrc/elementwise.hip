@@ -804,10 +804,24 @@ extern "C" int ganffn_bce2_bwd(const float* prob, float target_a, float target_b
     return 0;
 }
 
+extern "C" int ganffn_adam_bump(int32_t* step, void* stream) {
+    GF_CHECK_ARG(step, "adam_bump: null step");
+    hipLaunchKernelGGL(adam_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ganffn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t* step,
                                 int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                                 float grad_scale, void* stream) {
-    GF_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && step && n > 0, "adam_step: bad arguments");
+    GF_TRY(ganffn_adam_update(params, grads, exp_avg, exp_avg_sq, step, n, lr, beta1, beta2, eps, weight_decay, grad_scale, stream));
+    return ganffn_adam_bump(step, stream);
+}
+
+extern "C" int ganffn_adam_update(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int32_t* step,
+                                  int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  float grad_scale, void* stream) {
+    GF_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && step && n > 0, "adam_update: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const bool vec = aligned16(params) && aligned16(grads) && aligned16(exp_avg) && aligned16(exp_avg_sq);
     const long n4 = vec ? ((long)n & ~3L) : 0;
@@ -822,8 +836,6 @@ extern "C" int ganffn_adam_step(float* params, const float* grads, float* exp_av
                            weight_decay, grad_scale);
         GF_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(adam_step_inc, dim3(1), dim3(1), 0, st, step);
-    GF_LAUNCH_CHECK();
     return 0;
 }
 

@@ -96,12 +96,17 @@ class GradReducer:
         self.world = dist.get_world_size(process_group)
         self.works = []
 
-    def reduce_async(self, flat_slice):
-        self.works.append(self.dist.all_reduce(flat_slice, op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True))
+    def reduce_async(self, flat_slice, lo=None, hi=None):
+        w = self.dist.all_reduce(flat_slice, op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self.works.append((w, lo, hi))
 
-    def finish(self):
-        for w in self.works:
+    def finish(self, on_bucket=None):
+        """wait for the buckets in issue order; on_bucket(lo, hi) runs right after a bucket's all-reduce has been waited
+        for (the engine applies Adam to that slice there, so only the LAST bucket's reduce is exposed)"""
+        for w, lo, hi in self.works:
             w.wait()
+            if on_bucket is not None and lo is not None:
+                on_bucket(lo, hi)
         self.works = []
 
 
@@ -403,16 +408,30 @@ class GanEngine(_Runner):
         ops.adam_step_raw(net.slab, net.grad, net.exp_avg, net.exp_avg_sq, net.step, net.total, net.lr,
                           net.betas[0], net.betas[1], 1e-8, net.wd, 1.0 / self.world)
 
+    def _adam_slice(self, net, lo, hi):
+        ops.adam_update_raw(net.slab[lo:hi], net.grad[lo:hi], net.exp_avg[lo:hi], net.exp_avg_sq[lo:hi], net.step, hi - lo,
+                            net.lr, net.betas[0], net.betas[1], 1e-8, net.wd, 1.0 / self.world)
+
     def _make_reducer(self, net):
-        """returns (callback, finish): async all-reduce (sum) of grad-slab slices on RCCL's own stream,
-        overlapping the rest of backward; Adam divides by world (grad_scale)."""
+        """returns (callback, finish_and_step): async all-reduce (sum) of grad-slab slices on RCCL's own stream,
+        overlapping the rest of backward.  finish_and_step(net_key) waits bucket by bucket and applies Adam (which
+        divides by world: grad_scale) to each slice as soon as its reduce is done; without a process group it is the
+        plain whole-slab Adam step."""
         if self.pg is None:
-            return None, (lambda: None)
+            def plain(net_key):
+                self._pre_write(net_key)
+                self._adam(net)
+            return None, plain
         red = GradReducer(getattr(self, "_cur_pg", None) or self.pg)
 
         def cb(lo, hi, last):
-            red.reduce_async(net.grad[lo:hi])
-        return cb, red.finish
+            red.reduce_async(net.grad[lo:hi], lo, hi)
+
+        def finish_and_step(net_key):
+            self._pre_write(net_key)            # other streams' readers of these parameters first (WAR)
+            red.finish(lambda lo, hi: self._adam_slice(net, lo, hi) if hi > lo else None)
+            ops.adam_bump_raw(net.step)
+        return cb, finish_and_step
 
     # ------------------------------------------------------------------------------------------
     def train_disc(self, who, partner, batch, loss_slot):
@@ -443,9 +462,7 @@ class GanEngine(_Runner):
                                Dn.w("object.bias", True), S * B, Dn.obj_in, self.D_h, self.ws)
             if cb is not None:
                 cb(Dn.enc_floats, Dn.enc_floats + Dn.obj_floats, last=True)
-        finish()
-        self._pre_write(("D", who))
-        self._adam(Dn)
+        finish(("D", who))
 
     def train_gen(self, who, partner, batch, loss_slot):
         """train_IEMOCAP.py:230-252."""
@@ -461,9 +478,7 @@ class GanEngine(_Runner):
         Gn.grad.zero_()
         cb, finish = self._make_reducer(Gn)
         self._net_bwd(Gn, pg_, pd.dx, True, g_adds, True, cb)
-        finish()
-        self._pre_write(("G", who))
-        self._adam(Gn)
+        finish(("G", who))
 
     def _pre_write(self, net_key):
         """called right before a sub-step's Adam: wait for other streams' readers of that network (WAR)"""
@@ -702,8 +717,7 @@ class Phase2Engine(GanEngine):
                 net.grad.zero_()
                 cb, finish = self._make_reducer(net)
                 self._net_bwd(net, self.pass_G[k], self.d_fusion, True, adds[k], True, cb)
-                finish()
-                self._adam(net)
+                finish(("G", k))
             if self.pg is not None:
                 red = GradReducer(self.pg)
                 red.reduce_async(self.fc_grad)

@@ -161,6 +161,16 @@ def adam_step_raw(p, g, m, v, step, n, lr, b1, b2, eps=1e-8, wd=0.0, gscale=1.0)
               C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(wd), C.c_float(gscale), _stream())
 
 
+def adam_update_raw(p, g, m, v, step, n, lr, b1, b2, eps=1e-8, wd=0.0, gscale=1.0):
+    """Adam on a slice, step counter untouched (see ganffn_adam_update)"""
+    _lib.call("ganffn_adam_update", _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(step), C.c_int64(n), C.c_float(lr),
+              C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(wd), C.c_float(gscale), _stream())
+
+
+def adam_bump_raw(step):
+    _lib.call("ganffn_adam_bump", _ptr(step), _stream())
+
+
 def rng_advance_raw(rng, delta):
     _lib.call("ganffn_rng_advance", _ptr(rng), C.c_uint64(delta), _stream())
 

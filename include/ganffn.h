@@ -161,6 +161,13 @@ int ganffn_bce2_bwd(const float* prob, float target_a, float target_b, int perio
 int ganffn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                      int32_t* step, int64_t n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, float grad_scale, void* stream);
+/* The same update on a SLICE of the slabs with t = *step + 1 and the counter left alone, and the bump on its own:
+ * data-parallel training applies Adam bucket by bucket, each as soon as its gradient all-reduce has finished
+ * (ganffn_adam_update per bucket, then one ganffn_adam_bump) — identical to one ganffn_adam_step over the whole slab. */
+int ganffn_adam_update(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                       const int32_t* step, int64_t n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float grad_scale, void* stream);
+int ganffn_adam_bump(int32_t* step, void* stream);
 
 /* ---- A11: phase 2 (model.py:1441-1449, :74-81) --------------------------------------- */
 /* fusion = a + b + c (elementwise, n floats) */

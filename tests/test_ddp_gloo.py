@@ -68,9 +68,19 @@ def _worker(rank, world, port, tmp):
 
     red = GradReducer(dist.group.WORLD)
     for lo, hi in ranges:
-        red.reduce_async(g_local[lo:hi])
-    red.finish()
+        red.reduce_async(g_local[lo:hi], lo, hi)
+    # per-bucket optimizer step: the callback runs bucket by bucket, in issue order, right after that bucket's
+    # all-reduce has been waited for (the engine applies Adam to the slice there); stand-in update: p -= 0.1 * g / world
+    param = torch.zeros_like(g_local)
+    seen = []
+
+    def on_bucket(lo, hi):
+        seen.append((lo, hi))
+        param[lo:hi] -= 0.1 * g_local[lo:hi] / red.world
+    red.finish(on_bucket)
+    assert seen == list(ranges) and red.works == []
     g_avg = g_local / red.world                       # Adam's grad_scale = 1/world
+    assert torch.equal(param, -0.1 * g_avg)           # bucket-wise update == whole-slab update
 
     g_full, _ = flat_grad(full["text"])               # what one process would compute on the global batch
     err = float((g_avg - g_full).abs().max() / g_full.abs().max())
