@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP32_MFMA_PEAK = 157.3e12      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 # algorithmic FLOPs of one iteration per padded token at S = 94: fwd 409.5 + bwd 544.8 MFLOP
 FLOP_PER_TOKEN_ITER = 954.3e6
@@ -72,7 +73,7 @@ def wgrad_groups(S, B, config="iemocap"):
             (2, [(m, n, T1) for _ in range(8) for (m, n) in e512])]
 
 
-TRAFFIC_FILE = "profiles/r01_wgrad_traffic.json"
+TRAFFIC_FILE = "profiles/r02_wgrad_traffic.json"
 
 
 def wgrad_algorithmic_bytes(S, B, config="iemocap"):
@@ -250,6 +251,110 @@ def build_workload(config, dev):
     return engine.build_networks(device=dev, seed=3407)       # random init of the reference architecture
 
 
+def time_skinny_kernel(B, reps=20):
+    """the recurrence's skinny product at the party-cell shape of configuration 5 (both directions' W_ih and W_hh
+    products in one launch: 4 problems of [B x 500] x [500 x 1500]), timed with HIP events on the launch stream.
+    Returns (avg seconds per launch, algorithmic bytes per launch)."""
+    from gan_ffn_amd import _lib, ops
+    M, N, K = B, 1500, 500
+    A = torch.randn(M, K, device="cuda")
+    W = torch.randn(4, K, N, device="cuda")
+    C = torch.empty(4, M, N, device="cuda")
+    run = lambda: _lib.call("ganffn_drnn_skinny", 1, 4, ops._ptr(A), ops._ptr(W), ops._ptr(C), M, N, K, ops._stream())
+    run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # launches go to torch's current stream
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps, 4.0 * (4 * K * N + M * K + 4 * M * N)
+
+
+def run_drnn(args, dev, pg, rank, world):
+    """BASELINE.json configs[4] on the GPUs given: GAN_FFN_DialogueRNN (three generators -> sum -> bidirectional
+    DialogueRNN -> matching attention -> 6-class head; model.py:1485-1534) forward + MaskedNLLLoss + backward + Adam at
+    the reference's batch of 30 dialogues (train_IEMOCAP_DialogueRNN.py:580), every piece on the HIP path.  Data
+    parallel = one batch per rank, gradients averaged by one flat all-reduce (no reference counterpart: the reference
+    is single-device)."""
+    from gan_ffn_amd import model as M, ops
+    torch.manual_seed(3407)
+    net = M.GAN_FFN_DialogueRNN(M.AcousticGenerator(100), M.VisualGenerator(100), M.TextGenerator(100), 100, 500, 500, 100, 100,
+                                100, n_classes=6, listener_state=False, context_attention="general", dropout_rec=0.1,
+                                dropout=0.6).to(dev).train()          # train_IEMOCAP_DialogueRNN.py:556-607, 705-721 defaults
+    ops.manual_seed(3407 + 1000 * rank, dev)
+    batch = make_batch("iemocap", args.batch, args.seq, 3407 + rank, dev)
+    S, B = batch["text"].shape[:2]
+    w = torch.tensor([1.2, 0.60072, 0.38066, 0.94019, 0.67924, 0.34332], device=dev)      # train_IEMOCAP_DialogueRNN.py:738
+    loss_fn = M.MaskedNLLLoss(w)
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-5)
+    if pg is not None:
+        import torch.distributed as dist
+        for p in params:
+            dist.broadcast(p.data, src=0)
+
+    def step():
+        opt.zero_grad(set_to_none=False)
+        lp = net(batch["acoustic"], batch["visual"], batch["text"], batch["qmask"], batch["umask"])[0]
+        loss = loss_fn(lp.transpose(0, 1).contiguous().view(-1, 6), batch["label"].view(-1), batch["umask"])
+        loss.backward()
+        if pg is not None:
+            gs = [p.grad for p in params if p.grad is not None]
+            flat = torch._utils._flatten_dense_tensors(gs)
+            dist.all_reduce(flat)
+            flat.div_(world)
+            for g, f in zip(gs, torch._utils._unflatten_dense_tensors(flat, gs)):
+                g.copy_(f)
+        opt.step()
+        return loss
+
+    def sync():
+        torch.cuda.synchronize()
+        if pg is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    utts = float(batch["umask"].sum())
+    if pg is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        u = torch.tensor([utts], device=dev, dtype=torch.float64)
+        dist.all_reduce(u)
+        dt, utts = float(t), float(u)
+    if rank == 0:
+        kt, kbytes = time_skinny_kernel(B)
+        print(json.dumps({
+            "metric": "utterances/sec per phase-2 train step, IEMOCAP GAN-FFN + DialogueRNN", "value": round(utts * args.steps / dt, 2),
+            "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "IEMOCAP GAN-FFN + DialogueRNN (BASELINE.json configs[4]): 3 generators -> bidirectional "
+                                   "DialogueRNN (D_g = D_p = 500, D_e = 100, general attention) -> matching attention -> "
+                                   "6-class head, forward + MaskedNLLLoss + backward + Adam, batch=%d per GPU fp32 on "
+                                   "%dxMI355X" % (B, world),
+                       "dialogues_per_gpu": B, "seq_len": S, "parallelism": "dp%d" % world, "launch": "eager",
+                       "last_loss": round(float(loss), 4)},
+            "roofline": {"bound": "hbm", "kernel": "skinny_nn_kernel (backward of one recurrence step's gate products, both directions: "
+                                                   "4 x ([B x 500] x [500 x 1500]); the kernel with the largest share of GPU time in "
+                                                   "profiles/r02_drnn_by_launch_shape.txt)",
+                         "achieved": round(kbytes / kt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(kbytes / kt / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": round(kbytes), "avg_kernel_us": round(kt * 1e6, 2),
+                         "how": "HIP events around 20 back-to-back launches on the launch stream; the 12 MB of weights stay "
+                                "L2 / MALL-resident between launches, so the bound that applies is the L2 -> CU path, priced "
+                                "here against the HBM peak as the contract asks"}}), flush=True)
+
+
 def host_threads():
     """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota (a 1-GPU box
     exposes many cores but grants a 16-core share)."""
@@ -275,10 +380,11 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="dialogues per GPU (reference hard-codes 32, train_IEMOCAP.py:603)")
     ap.add_argument("--seq", type=int, default=None, help="padded dialogue length S (default 94, model.py:1437; "
                     "--config meld: 33, MELD's longest dialogue [public, not stated by the reference])")
-    ap.add_argument("--config", choices=["iemocap", "meld"], default="iemocap",
+    ap.add_argument("--config", choices=["iemocap", "meld", "drnn"], default="iemocap",
                     help="iemocap = BASELINE.json configs[1] (the headline metric's workload); meld = configs[2], the "
                          "generic G/D stack at MELD's feature widths on the bi-modal schedule (extension: the reference "
-                         "has no GAN path for MELD)")
+                         "has no GAN path for MELD); drnn = configs[4], the phase-2 GAN-FFN + DialogueRNN "
+                         "classifier step at batch 30")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams running independent sub-steps concurrently")
@@ -290,6 +396,8 @@ def main():
     args = ap.parse_args()
     if args.seq is None:
         args.seq = 33 if args.config == "meld" else 94
+    if args.config == "drnn" and args.batch == 32:
+        args.batch = 30                                              # train_IEMOCAP_DialogueRNN.py:580
     if args.cpu_sample_batch is None:
         args.cpu_sample_batch = args.batch
     cfgname = args.config
@@ -312,6 +420,13 @@ def main():
         pg = dist.group.WORLD
 
     from gan_ffn_amd import _lib, engine, ops
+    if args.config == "drnn":
+        _lib.load()
+        run_drnn(args, dev, pg, rank, world)
+        if pg is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.replay_dominant_only:
         kt, kflop, klaunch = time_dominant_kernel(args.seq, args.batch, reps=1, config=cfgname)
         print(json.dumps({"avg_kernel_us": kt * 1e6, "launches": klaunch}), flush=True)

@@ -514,6 +514,16 @@ static int memset_f(float* p, int64_t n, hipStream_t st) {
 
 using namespace ganffn;
 
+// test / measurement hook: one skinny product C[M x N] = A[M x K] W^T (nn = 0, W [N x K]) or A W (nn = 1, W [K x N]),
+// replicated `copies` (<= 4) times in one launch like a step of the recurrence (2 directions x 2 products)
+extern "C" int ganffn_drnn_skinny(int nn, int copies, const float* A, const float* W, float* C, int M, int N, int K, void* stream) {
+    GF_CHECK_ARG(A && W && C && copies >= 1 && copies <= 4, "drnn_skinny: bad arguments");
+    SkinnyGroup sg;
+    for (int i = 0; i < copies; ++i)
+        sg.p[i] = SkinnyProb{A, K, W + (size_t)i * N * K, nn ? N : K, nullptr, 0, nullptr, nullptr, C + (size_t)i * M * N, N, M, N, K};
+    return launch_skinny(sg, copies, nn != 0, (hipStream_t)stream);
+}
+
 extern "C" int64_t ganffn_drnn_saved_floats(const ganffn_drnn_cfg* c) { return check_drnn(c, 1) ? -1 : drnn_saved(c).total; }
 extern "C" int64_t ganffn_drnn_workspace_floats(const ganffn_drnn_cfg* c) { return check_drnn(c, 1) ? -1 : drnn_ws(c).total; }
 

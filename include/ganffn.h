@@ -233,6 +233,11 @@ int ganffn_drnn_bwd(const ganffn_drnn_cfg* cfg, int ndir, const float* const* d_
                     const float* const* saved, float* const* workspace, const uint64_t* rng,
                     uint64_t rng_offset_add, void* stream);
 
+/* one launch of the recurrence's skinny product, `copies` (<= 4) independent problems sharing A: C_i[M x N] = A[M x K]
+ * W_i^T (nn = 0, W_i [N x K]) or A W_i (nn = 1, W_i [K x N]); W / C hold the copies back to back; M <= 32 (unit tests and
+ * the roofline leg of bench.py --config drnn) */
+int ganffn_drnn_skinny(int nn, int copies, const float* A, const float* W, float* C, int M, int N, int K, void* stream);
+
 /* ---- building blocks exported for unit tests ----------------------------------------- */
 /* C[M x N] = A[M x K] * W[N x K]^T + bias (bias may be NULL) */
 int ganffn_gemm_nt(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM-side traffic of the roofline kernel (gemm_tn_grouped_kernel), per MI355X_MICROARCH.md "HBM": FETCH_SIZE and
 # WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (kernel trace only), FETCH_SIZE doubled on gfx950.  Run from the repo
-# root on the GPU box; writes profiles/r01_wgrad_traffic.json (+ the two raw per-dispatch CSVs under gpurun_out/).
+# root on the GPU box; writes gpurun_out/r02_wgrad_traffic.json (copied into profiles/ afterwards) (+ the two raw per-dispatch CSVs under gpurun_out/).
 set -e
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
@@ -25,6 +25,6 @@ out = {"kernel": "gemm_tn_grouped_kernel", "seq_len": 94, "dialogues_per_gpu": 3
        "method": "rocprofv3 --kernel-trace --pmc <one counter per pass> -- python3 bench.py --replay-dominant-only; "
                  "averages over the launches of one iteration's mix (6 x T=6016 d=100, 4 x T=3008 d=100, 2 x T=3008 d=512), "
                  "warm-up pass included; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B)"}
-json.dump(out, open("profiles/r01_wgrad_traffic.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r02_wgrad_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
