@@ -296,7 +296,7 @@ def run_drnn(args, dev, pg, rank, world):
             dist.broadcast(p.data, src=0)
 
     def step():
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad()
         lp = net(batch["acoustic"], batch["visual"], batch["text"], batch["qmask"], batch["umask"])[0]
         loss = loss_fn(lp.transpose(0, 1).contiguous().view(-1, 6), batch["label"].view(-1), batch["umask"])
         loss.backward()

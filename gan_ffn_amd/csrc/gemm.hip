@@ -173,17 +173,16 @@ __device__ __forceinline__ void gemm_keep_bits(const GemmArgs& g, const DropCtx&
         }
 }
 
-template <int EPI, int TM, int TN>
-__device__ __forceinline__ void gemm_store_epilogue(const GemmArgs& g, floatx16 (&acc)[TM][TN], const int mbase, const int nbase,
-                                                    const int bz, const int r, const int h, const DropCtx& dc,
-                                                    const uint32_t (&keep)[TM][TN]) {
+template <int EPI>
+constexpr bool epi_has_aux() { return EPI == EPI_NONE || EPI == EPI_MASK_POS || EPI == EPI_GELU_BWD_DROP || EPI == EPI_GELU_BWD; }
 
-    // Epilogue operand (residual / saved activation): ALL loads of the wave tile are issued first, from clamped
-    // (always valid) offsets — a load under the per-element bounds test makes hipcc wait for it before the next
-    // one is issued (16 serialised round trips per tile in the first version of this epilogue).
-    constexpr bool HAS_AUX = EPI == EPI_NONE || EPI == EPI_MASK_POS || EPI == EPI_GELU_BWD_DROP || EPI == EPI_GELU_BWD;
-    float aux[TM][TN][16];
-    if (HAS_AUX) {
+// Epilogue operand (residual / saved activation): ALL loads of the wave tile are issued together, from clamped
+// (always valid) offsets — a load under the per-element bounds test makes hipcc wait for it before the next
+// one is issued (16 serialised round trips per tile in the first version of this epilogue).
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void gemm_load_aux(const GemmArgs& g, float (&aux)[TM][TN][16], const int mbase, const int nbase,
+                                              const int bz, const int r, const int h) {
+    if (epi_has_aux<EPI>()) {
         const bool want = (EPI == EPI_NONE) ? (g.ea.aux_in != nullptr && bz == 0) : true;   // wave-uniform
         if (want) {
 #pragma unroll
@@ -206,7 +205,13 @@ __device__ __forceinline__ void gemm_store_epilogue(const GemmArgs& g, floatx16 
                     for (int i = 0; i < 16; ++i) aux[a][b][i] = 0.f;
         }
     }
+}
 
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void gemm_apply_store(const GemmArgs& g, floatx16 (&acc)[TM][TN], const float (&aux)[TM][TN][16],
+                                                 const int mbase, const int nbase, const int bz, const int r, const int h,
+                                                 const DropCtx& dc, const uint32_t (&keep)[TM][TN]) {
+    constexpr bool HAS_AUX = epi_has_aux<EPI>();
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -253,6 +258,15 @@ __device__ __forceinline__ void gemm_store_epilogue(const GemmArgs& g, floatx16 
                 }
             }
         }
+}
+
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void gemm_store_epilogue(const GemmArgs& g, floatx16 (&acc)[TM][TN], const int mbase, const int nbase,
+                                                    const int bz, const int r, const int h, const DropCtx& dc,
+                                                    const uint32_t (&keep)[TM][TN]) {
+    float aux[TM][TN][16];
+    gemm_load_aux<EPI, TM, TN>(g, aux, mbase, nbase, bz, r, h);
+    gemm_apply_store<EPI, TM, TN>(g, acc, aux, mbase, nbase, bz, r, h, dc, keep);
 }
 
 template <int MODE, int BM, int BN, int BK, int EPI, int WGM, int WGN>

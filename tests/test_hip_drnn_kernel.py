@@ -152,3 +152,66 @@ def test_skinny_products(nn, M, N, K):
     for i in range(4):
         ref = A.double() @ (W[i].double() if nn else W[i].double().T)
         assert float((Cd[i].cpu().double() - ref).abs().max() / ref.abs().max()) < 3e-6 * max(1.0, K ** 0.5)
+
+
+class _SeededDrop(torch.nn.Module):
+    """stands in for nn.Dropout on BOTH sides of the composite test: inverted dropout with a mask drawn on the CPU from
+    a seeded generator (call order is the same on both sides)"""
+
+    def __init__(self, p, seed):
+        super().__init__()
+        self.p, self.g = p, torch.Generator().manual_seed(seed)
+
+    def forward(self, x):
+        keep = (torch.rand(x.shape, generator=self.g) >= self.p).to(x.device, x.dtype)
+        return x * keep / (1.0 - self.p)
+
+
+@pytest.mark.parametrize("S,B", [(23, 5), (94, 30)])
+def test_composite_train_mode_step_matches_cpu_bimodel_on_the_same_fusion_and_masks(S, B):
+    """configuration 5 in TRAIN mode on the device (three HIP generators with dropout -> HIP bidirectional recurrence
+    with Philox dropout -> general2 attention -> head; train_IEMOCAP_DialogueRNN.py:705-721 settings) against the
+    fp64 CPU BiModel mirror fed the SAME fusion tensor and the SAME dropout masks: log-probabilities, loss, the gradient
+    arriving at the fusion (what the generators back-propagate) and every BiModel parameter gradient"""
+    import copy
+    from gan_ffn_amd import data as D, model as M, ops
+    torch.manual_seed(11)
+    net = M.GAN_FFN_DialogueRNN(M.AcousticGenerator(100), M.VisualGenerator(100), M.TextGenerator(100), 100, 500, 500, 100, 100,
+                                100, n_classes=6, listener_state=False, context_attention="general", dropout_rec=0.1,
+                                dropout=0.6).cuda().train()
+    cpu = copy.deepcopy(net.bi_model).double().cpu().train()
+    for bm in (net.bi_model, cpu):
+        bm.dropout_rec, bm.dropout = _SeededDrop(0.75, 5), _SeededDrop(0.6, 6)
+    b = D.synthetic_batch(B=B, S_max=S, seed=S + B, device="cuda")
+    seed, seen = 20261004, {}
+
+    def grab(mod, args):
+        seen["add"] = ops.DeviceRng.get(args[0].device).counter      # the rng offset the recurrence is about to take
+        args[0].retain_grad()
+        seen["fusion"] = args[0]
+    net.bi_model.register_forward_pre_hook(grab)
+    ops.manual_seed(seed)
+    lp = net(b["acoustic"], b["visual"], b["text"], b["qmask"], b["umask"])[0]
+    w = torch.tensor([1.2, 0.60072, 0.38066, 0.94019, 0.67924, 0.34332])
+    loss = M.MaskedNLLLoss(w.cuda())(lp.transpose(0, 1).contiguous().view(-1, 6), b["label"].view(-1), b["umask"])
+    loss.backward()
+    for g in (net.acoustic_generator, net.visual_generator, net.text_generator):
+        assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for p in g.parameters())
+
+    # CPU mirror: same fusion, per-direction Philox masks of the recurrence, same seeded head masks
+    S_, B_ = seen["fusion"].shape[:2]
+    cpu.dialog_rnn_f.dialogue_cell.dropout = _MaskSeq(philox_masks(S_, B_, 500, 100, 0.1, seed, seen["add"], 0))
+    cpu.dialog_rnn_r.dialogue_cell.dropout = _MaskSeq(philox_masks(S_, B_, 500, 100, 0.1, seed, seen["add"], 1))
+    Uc = seen["fusion"].detach().cpu().double().requires_grad_(True)
+    lp_r = cpu(Uc, b["qmask"].cpu().double(), b["umask"].cpu().double())[0]
+    loss_r = M.MaskedNLLLoss(w.double())(lp_r.transpose(0, 1).contiguous().view(-1, 6), b["label"].cpu().view(-1), b["umask"].cpu().double())
+    loss_r.backward()
+    assert float((lp.detach().cpu().double() - lp_r.detach()).abs().max()) < 1e-4
+    assert abs(float(loss) - float(loss_r)) < 1e-5 * max(1.0, abs(float(loss_r)))
+
+    def rel(a, ref):
+        return float((a.cpu().double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+    assert rel(seen["fusion"].grad, Uc.grad) < 1e-3
+    pc = dict(cpu.named_parameters())
+    for k, p in net.bi_model.named_parameters():
+        assert rel(p.grad, pc[k].grad) < 1e-3, k
