@@ -28,6 +28,13 @@ int fail(int code, const char* fmt, ...);
                                   hipGetErrorString(e__));                             \
     } while (0)
 
+#define GF_HIP(expr)                                                                                \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess)                                                                      \
+            return ::ganffn::fail((int)e__, "%s:%d %s: %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+    } while (0)
+
 #define GF_TRY(expr)              \
     do {                          \
         int r__ = (expr);         \

@@ -133,6 +133,77 @@ struct KmTile {
     }
 };
 
+// Full-tile loaders for the steady state of the K loop: no bounds arithmetic and no 0/1 factor — fp32 MFMAs execute on
+// the SIMD's vector ALU (tools/lab/mfma_valu.hip: VALU instructions issued between a wave's MFMAs ADD to its time, and
+// other waves' VALU work overlaps them only ~25 %), so every VALU instruction in the K loop is paid for in MFMA time.
+// The per-thread element offsets (clamped rows / columns) are computed once; per tile only the uniform base pointer moves
+// (scalar ALU), and the K tail — the one tile that needs zero-filling — is loaded once, up front, by the masked loaders.
+template <int ROWS, int BK, int NTH>
+struct KcFull {
+    static constexpr int KV = BK / 4, TOTALV = ROWS * KV, NV = (TOTALV + NTH - 1) / NTH;
+    float4 v[NV];
+    static __device__ __forceinline__ void offsets(uint32_t (&off)[NV], int ld, int row0, int nrows, int tid) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = min(tid + j * NTH, TOTALV - 1);
+            off[j] = (uint32_t)min(row0 + i / KV, nrows - 1) * (uint32_t)ld + (uint32_t)((i % KV) << 2);
+        }
+    }
+    __device__ __forceinline__ void load(const float* __restrict__ Pk, const uint32_t (&off)[NV]) {   // Pk = P + k0 (uniform)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const float4*>(Pk + off[j]);
+    }
+    __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * NTH;
+            if (TOTALV % NTH == 0 || i < TOTALV) *reinterpret_cast<float4*>(S + kc_off<BK>(i / KV, i % KV)) = v[j];
+        }
+    }
+};
+
+template <int COLS, int BK, int NTH>
+struct KmFull {
+    static constexpr int TOTALV = COLS * BK / 4, NV = (TOTALV + NTH - 1) / NTH, LD = COLS + 4;
+    float4 v[NV];
+    static __device__ __forceinline__ void offsets(uint32_t (&off)[NV], int ld, int col0, int ncols, int tid) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = min(tid + j * NTH, TOTALV - 1);
+            off[j] = (uint32_t)(i / (COLS / 4)) * (uint32_t)ld + (uint32_t)max(min(col0 + ((i % (COLS / 4)) << 2), ncols - 4), 0);
+        }
+    }
+    __device__ __forceinline__ void load(const float* __restrict__ Pk, const uint32_t (&off)[NV]) {   // Pk = P + k0 * ld (uniform)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const float4*>(Pk + off[j]);
+    }
+    __device__ __forceinline__ void add_to(float4& s4, int tid) const {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (TOTALV % NTH == 0 || tid + j * NTH < TOTALV) { s4.x += v[j].x; s4.y += v[j].y; s4.z += v[j].z; s4.w += v[j].w; }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * NTH;
+            if (TOTALV % NTH == 0 || i < TOTALV) *reinterpret_cast<float4*>(S + (i / (COLS / 4)) * LD + ((i % (COLS / 4)) << 2)) = v[j];
+        }
+    }
+};
+
+// prefetch-queue slots as NAMED members (an array of slot structs indexed by the unrolled step ended up in scratch memory)
+template <class T>
+struct Slots4 {
+    T s0, s1, s2, s3;
+    template <int U>
+    __device__ __forceinline__ T& get() {
+        if constexpr (U == 0) return s0;
+        else if constexpr (U == 1) return s1;
+        else if constexpr (U == 2) return s2;
+        else return s3;
+    }
+};
+
 template <int MODE, int BM, int BN, int BK>
 struct Smem {
     static constexpr int LDK = BK;
@@ -260,6 +331,41 @@ __device__ __forceinline__ void gemm_apply_store(const GemmArgs& g, floatx16 (&a
         }
 }
 
+// gemm_apply_store for ONE wave tile that lies fully inside the matrix (wave-uniform precondition: mbase + 32 <= M,
+// nbase + 32 <= N), bias preloaded by the caller: straight-line code, no per-element bounds test.
+template <int EPI>
+__device__ __forceinline__ void gemm_apply_store_full(const GemmArgs& g, const floatx16& acc, const float (&aux)[16], const float bias,
+                                                      const int mbase, const int nbase, const int r, const int h,
+                                                      const DropCtx& dc, const uint32_t keep) {
+    constexpr bool HAS_AUX = epi_has_aux<EPI>();
+    float* const cp = g.C + (size_t)(mbase + 4 * h) * g.ldc + nbase + r;
+    float* const up = (EPI == EPI_DROP_GELU) ? g.ea.aux_out + (size_t)(mbase + 4 * h) * g.ldc + nbase + r : nullptr;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int dr = (i & 3) + 8 * (i >> 2);
+        const float mult = epi_has_dropout<EPI>() ? (((keep >> i) & 1u) ? dc.scale : 0.f) : 1.f;
+        float v = acc[i], u = 0.f;
+        const float ax = HAS_AUX ? aux[i] : 0.f;
+        if (EPI == EPI_NONE) {
+            v += bias;
+            v += ax;
+        } else if (EPI == EPI_RELU_DROP) {
+            v = fmaxf(v + bias, 0.f) * mult;
+        } else if (EPI == EPI_DROP_GELU) {
+            u = (v + bias) * mult;
+            v = gelu_f(u);
+        } else if (EPI == EPI_MASK_POS) {
+            v = (ax > 0.f) ? v * g.ea.mscale : 0.f;
+        } else if (EPI == EPI_GELU_BWD_DROP) {
+            v = v * mult * gelu_grad_f(ax);
+        } else if (EPI == EPI_GELU_BWD) {
+            v = v * gelu_grad_f(ax);
+        }
+        if (EPI == EPI_DROP_GELU) up[(size_t)dr * g.ldc] = u;
+        cp[(size_t)dr * g.ldc] = v;
+    }
+}
+
 template <int EPI, int TM, int TN>
 __device__ __forceinline__ void gemm_store_epilogue(const GemmArgs& g, floatx16 (&acc)[TM][TN], const int mbase, const int nbase,
                                                     const int bz, const int r, const int h, const DropCtx& dc,
@@ -284,7 +390,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = bz * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
-    const int nt = (kend - kbeg + BK - 1) / BK;
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -294,45 +399,78 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    // Register prefetch queue: PD tiles in flight.  The loads of tile t+PD are issued at iteration t, the tile
+    // Register prefetch queue: PD FULL tiles in flight.  The loads of tile t+PD are issued at iteration t, the tile
     // written to LDS at iteration t is the one loaded PD-1 iterations ago, so a K loop pays the global-load
     // latency once instead of once per tile (measured: the 1-deep version was load-latency-bound at 1-2 waves/SIMD).
+    // Tiles 0 .. nfull-1 are full; the K tail (if any) is tile nfull: it is loaded once, before the loop, by the masked
+    // loaders (zero-filled beyond kend) and goes to LDS when its turn comes.  Prefetches beyond the last full tile
+    // re-read that tile (uniform clamp of the tile index): valid memory, never consumed.
     constexpr int PD = (BM * BN / (WGM * WGN) >= 64 * 64) ? 2 : 4;   // bigger per-wave tiles: fewer tiles in flight (VGPRs)
-    KcTile<BM, BK, NTH> ta_kc[PD];
-    KmTile<BM, BK, NTH> ta_km[PD];
-    KcTile<BN, BK, NTH> tb_kc[PD];
-    KmTile<BN, BK, NTH> tb_km[PD];
+    const int nfull = (kend - kbeg) / BK;
+    const int nt = nfull + (((kend - kbeg) % BK) ? 1 : 0);
+    // One float4 of each operand per thread and tile (64 x 16 floats / 256 threads); the queue slots are plain named
+    // vectors (arrays / structs of slots indexed by the unrolled step were left in scratch memory by hipcc).
+    static_assert(BM * BK / 4 == NTH && BN * BK / 4 == NTH, "queue code assumes one vector per thread, operand and tile");
+    float4 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
+    // per-thread element offset inside a tile's rows (clamped at the matrix edge) and LDS slot, loop-invariant
+    uint32_t offa, offb;
+    int ldsa, ldsb;
+    if constexpr (MODE == MODE_TN) {          // K-major: tile row = k, thread covers columns 4 * (tid % (BM/4)) ..
+        const int kr = tid / (BM / 4), c4 = (tid % (BM / 4)) << 2;
+        offa = (uint32_t)kr * (uint32_t)g.lda + (uint32_t)max(min(m0 + c4, g.M - 4), 0);
+        ldsa = kr * (BM + 4) + c4;
+    } else {                                  // K-contiguous: tile row = matrix row
+        const int row = tid / (BK / 4), sl = tid % (BK / 4);
+        offa = (uint32_t)min(m0 + row, g.M - 1) * (uint32_t)g.lda + (uint32_t)(sl << 2);
+        ldsa = kc_off<BK>(row, sl);
+    }
+    if constexpr (MODE == MODE_NT) {
+        const int row = tid / (BK / 4), sl = tid % (BK / 4);
+        offb = (uint32_t)min(n0 + row, g.N - 1) * (uint32_t)g.ldb + (uint32_t)(sl << 2);
+        ldsb = kc_off<BK>(row, sl);
+    } else {
+        const int kr = tid / (BN / 4), c4 = (tid % (BN / 4)) << 2;
+        offb = (uint32_t)kr * (uint32_t)g.ldb + (uint32_t)max(min(n0 + c4, g.N - 4), 0);
+        ldsb = kr * (BN + 4) + c4;
+    }
+    if (nfull == 0) offa = offb = 0;          // K range shorter than one tile: the (never consumed) queue loads read element 0
+    KcTile<BM, BK, NTH> tail_a_kc; KmTile<BM, BK, NTH> tail_a_km;      // the K-tail tile (all zeros when there is none)
+    KcTile<BN, BK, NTH> tail_b_kc; KmTile<BN, BK, NTH> tail_b_km;
 
     // TN bias gradient: column sums of At over k, taken from the registers on their way to LDS (workgroups bx == 0)
     const bool want_colsum = MODE == MODE_TN && g.colsum != nullptr && bx == 0;
     float4 colsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
     static_assert(MODE != MODE_TN || (NTH % (BM / 4) == 0), "colsum: a thread's vectors must share their columns");
 
-    auto gload = [&](auto slot, int t) {
-        constexpr int u = decltype(slot)::value;
-        const int k0 = kbeg + t * BK;     // beyond kend -> the tile loads zeros (no memory access)
-        if (MODE == MODE_TN) ta_km[u].load(g.A, g.lda, m0, g.M, k0, kend, tid);
-        else ta_kc[u].load(g.A, g.lda, m0, g.M, k0, kend, tid);
-        if (MODE == MODE_NT) tb_kc[u].load(g.B, g.ldb, n0, g.N, k0, kend, tid);
-        else tb_km[u].load(g.B, g.ldb, n0, g.N, k0, kend, tid);
-    };
-    auto sstore = [&](auto slot, int buf) {
-        constexpr int u = decltype(slot)::value;
+    const size_t kstride_a = (MODE == MODE_TN) ? (size_t)g.lda : 1, kstride_b = (MODE == MODE_NT) ? 1 : (size_t)g.ldb;
+#define GF_GLOAD(U, T)                                                                                   \
+    {                                                                                                    \
+        const int k0 = kbeg + max(min((T), nfull - 1), 0) * BK;        /* uniform: scalar ALU */         \
+        qa##U = *reinterpret_cast<const float4*>(g.A + (size_t)k0 * kstride_a + offa);                   \
+        qb##U = *reinterpret_cast<const float4*>(g.B + (size_t)k0 * kstride_b + offb);                   \
+    }
+#define GF_SSTORE_FULL(U, BUF)                                                                           \
+    {                                                                                                    \
+        float* const sa = smem + (BUF) * SM::STAGE;                                                      \
+        *reinterpret_cast<float4*>(sa + ldsa) = qa##U;                                                   \
+        *reinterpret_cast<float4*>(sa + SM::A_FLOATS + ldsb) = qb##U;                                    \
+        if (want_colsum) { colsum4.x += qa##U.x; colsum4.y += qa##U.y; colsum4.z += qa##U.z; colsum4.w += qa##U.w; } \
+    }
+    auto sstore_tail = [&](int buf) __attribute__((always_inline)) {
         float* sa = smem + buf * SM::STAGE;
         float* sb = sa + SM::A_FLOATS;
         if (MODE == MODE_TN) {
-            ta_km[u].store(sa, tid);
-            if (want_colsum) ta_km[u].add_to(colsum4, tid);   // every tile passes here exactly once
+            tail_a_km.store(sa, tid);
+            if (want_colsum) tail_a_km.add_to(colsum4, tid);
         } else {
-            ta_kc[u].store(sa, tid);
+            tail_a_kc.store(sa, tid);
         }
-        if (MODE == MODE_NT) tb_kc[u].store(sb, tid); else tb_km[u].store(sb, tid);
+        if (MODE == MODE_NT) tail_b_kc.store(sb, tid); else tail_b_km.store(sb, tid);
     };
-
 
     // One K tile: ALL operand fragments of the tile are read from LDS first (BK/8 groups x (TM + TN) reads), then the
     // BK/2 x TM x TN MFMAs run back to back.  No run-time condition in here: a K tail is zero-filled by the loaders.
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const float* sa = smem + buf * SM::STAGE;
         const float* sb = sa + SM::A_FLOATS;
         constexpr int NG = BK / 8;
@@ -377,11 +515,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
                     }
     };
 
-    // prologue: PD tiles in flight, tile 0 to LDS
-    gload(std::integral_constant<int, 0>{}, 0);
-    if constexpr (PD > 1) gload(std::integral_constant<int, 1>{}, 1);
-    if constexpr (PD > 2) gload(std::integral_constant<int, 2>{}, 2);
-    if constexpr (PD > 3) gload(std::integral_constant<int, 3>{}, 3);
+    // prologue: the tail tile and PD full tiles in flight, tile 0 to LDS
+    {
+        const int k0 = kbeg + nfull * BK;      // >= kend when there is no tail: the masked loaders then produce zeros
+        if (MODE == MODE_TN) tail_a_km.load(g.A, g.lda, m0, g.M, k0, kend, tid); else tail_a_kc.load(g.A, g.lda, m0, g.M, k0, kend, tid);
+        if (MODE == MODE_NT) tail_b_kc.load(g.B, g.ldb, n0, g.N, k0, kend, tid); else tail_b_km.load(g.B, g.ldb, n0, g.N, k0, kend, tid);
+    }
+    GF_GLOAD(0, 0)
+    if constexpr (PD > 1) GF_GLOAD(1, 1)
+    if constexpr (PD > 2) GF_GLOAD(2, 2)
+    if constexpr (PD > 3) GF_GLOAD(3, 3)
     // the epilogue's dropout keep bits (Philox: ~70 VALU instructions per call, 4 calls per tile) depend on indices only:
     // evaluated here, under the latency of the first global loads, instead of on the critical path after the last MFMA
     DropCtx dc;
@@ -391,26 +534,35 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
         else dc.on = 0;
         gemm_keep_bits<EPI, TM, TN>(g, dc, keep, m0 + wm * WM, n0 + wn * WN, r, h);
     }
-    sstore(std::integral_constant<int, 0>{}, 0);
+    if (nfull > 0) GF_SSTORE_FULL(0, 0) else sstore_tail(0);
     __syncthreads();
 
     // Steady state, iteration t: issue the global loads of tile t+PD, run tile t from LDS stage t&1, write tile t+1
-    // (loaded PD-1 iterations ago) to the other stage, barrier.  The step body is straight-line code; the only branch
-    // is the wave-uniform "is there a tile t" around a whole step.  Tiles at or beyond nt load as zeros.
-#define GF_STEP(U)                                                                      \
+    // (loaded PD-1 iterations ago) to the other stage, barrier.  The step body is straight-line code; the only branches
+    // are the wave-uniform "is there a tile t" around a whole step and "is tile t+1 the tail" around its LDS stores.
+#define GF_STEP(U, UN)                                                                  \
     if (t0 + U < nt) {                                                                  \
-        gload(std::integral_constant<int, U>{}, t0 + U + PD);   /* slot U is free */    \
+        GF_GLOAD(U, t0 + U + PD)                                /* slot U is free */    \
         compute(U & 1);                                                                 \
-        sstore(std::integral_constant<int, (U + 1) % PD>{}, (U + 1) & 1);               \
+        /* tile t+1 -> LDS: from the queue while it is a full tile, the tail tile right after the last full one */ \
+        if (t0 + U + 1 == nfull) sstore_tail((U + 1) & 1);      /* wave-uniform; LDS stores only */ \
+        else if (t0 + U + 1 < nfull) GF_SSTORE_FULL(UN, (U + 1) & 1)   /* (nothing beyond the last tile) */ \
         __syncthreads();                                                                \
     }
     for (int t0 = 0; t0 < nt; t0 += PD) {
-        GF_STEP(0)
-        if constexpr (PD > 1) { GF_STEP(1) }
-        if constexpr (PD > 2) { GF_STEP(2) }
-        if constexpr (PD > 3) { GF_STEP(3) }
+        if constexpr (PD == 2) {
+            GF_STEP(0, 1)
+            GF_STEP(1, 0)
+        } else {
+            GF_STEP(0, 1)
+            GF_STEP(1, 2)
+            GF_STEP(2, 3)
+            GF_STEP(3, 0)
+        }
     }
 #undef GF_STEP
+#undef GF_GLOAD
+#undef GF_SSTORE_FULL
 
     // ---------------- epilogue ----------------
     if (MODE == MODE_TN) {
@@ -466,6 +618,170 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 template <int MODE, int BM, int BN, int BK, int EPI, int WGM = 2, int WGN = 2, int SHORTK = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmArgs g) {
     gemm_body<MODE, BM, BN, BK, EPI, WGM, WGN>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight-resident short-K GEMM (K = KC = 100: linear1 forward and linear2's dgrad of the d_model-100 feed-forward block,
+// the two [T x 100] -> [T x 2048] products with fused epilogues; /root/reference/model.py:1210 -> torch _ff_block).
+//
+// With the generic kernel this shape is 1504 one-tile workgroups for 1536 resident slots: every workgroup pays its own
+// load latency, pulls both operand tiles through L2 (86 MB per launch) and runs in lockstep with all the others.  Here a
+// workgroup is PERSISTENT over several 64-token tiles of one 64-column panel of the weight:
+//   * the wave's weight fragments (32 columns x K) are loaded from global memory ONCE, straight into the MFMA operand
+//     layout, and stay in 50 VGPRs — the weight never passes through LDS and is not re-read per tile;
+//   * the token tile (64 x K) is double-buffered in LDS through a register prefetch: tile i+1's global loads are issued
+//     before tile i's MFMAs and written to the other LDS buffer after them — one barrier per tile, the load latency is
+//     paid once per workgroup, and the epilogue's stores of tile i drain under tile i+1's MFMAs;
+//   * K = 100 is 12 groups of 8 + one group of 4: 50 MFMAs per wave and tile (the generic BK = 16 loop runs 56);
+//   * the grid is exactly the number of workgroups the device holds at once (occupancy query, cached).
+// Measured (tools/lab/ffn_gemm_lab.py, T = 3008 / 6016, train mode): 22.0 / 35.8 us against 22.1 / 39.3 us for the generic
+// kernel in the step.  What bounds it (ablation in the same lab): launch + operand loads 6.6 us, MFMA chain 7.7 us (= its
+// ideal), epilogue VALU + the 24.6 MB store 6.3 us, and these ADD — fp32 MFMAs execute on the SIMD's vector ALU
+// (tools/lab/mfma_valu.hip), so Philox / epilogue VALU work cannot hide behind MFMAs of the same or of another wave.
+// A software-pipelined variant (previous tile's epilogue and this tile's Philox rounds interleaved between the MFMAs,
+// 2 waves per SIMD at 200 VGPRs) was built and measured slower (22.3 / 37.0 us); this is the simple form.
+// Same MFMA (v_mfma_f32_32x32x2_f32, exact fp32) and the same epilogue formulas as gemm_body.
+template <int MODE, int EPI, int KC>
+__global__ __launch_bounds__(256) void gemm_wres_kernel(GemmArgs g, int mtiles, int wg_per_panel) {
+    static_assert(KC % 4 == 0 && KC <= 128, "short K only");
+    constexpr int BM = 64, BN = 64;
+    constexpr int G8 = KC / 8, HALF = (KC % 8) ? 1 : 0;          // full groups of 8, one trailing group of 4
+    constexpr int LD = 4 * ((KC / 4) | 1);                        // LDS row stride: 4 x odd floats (conflict-free b128 reads)
+    constexpr int KV = KC / 4, TOTALV = BM * KV, NV = (TOTALV + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    const int panel = blockIdx.x / wg_per_panel, j0 = blockIdx.x - panel * wg_per_panel;
+    const int n0 = panel * BN;
+
+    // weight fragments: MFMA j of group gq takes k = 8 gq + 4 h + j; the trailing half group takes k = 8 G8 + 2 h + j
+    float wf[G8][4], wh[2];
+    {
+        const int n = min(n0 + wn * 32 + r, g.N - 1);
+        if (MODE == MODE_NT) {
+            const float* wrow = g.B + (size_t)n * g.ldb;
+#pragma unroll
+            for (int gq = 0; gq < G8; ++gq) {
+                const float4 q = *reinterpret_cast<const float4*>(wrow + 8 * gq + 4 * h);
+                wf[gq][0] = q.x; wf[gq][1] = q.y; wf[gq][2] = q.z; wf[gq][3] = q.w;
+            }
+            if (HALF) {
+                const float2 q = *reinterpret_cast<const float2*>(wrow + 8 * G8 + 2 * h);
+                wh[0] = q.x; wh[1] = q.y;
+            }
+        } else {
+#pragma unroll
+            for (int gq = 0; gq < G8; ++gq)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wf[gq][j] = g.B[(size_t)(8 * gq + 4 * h + j) * g.ldb + n];
+            if (HALF) {
+                wh[0] = g.B[(size_t)(8 * G8 + 2 * h) * g.ldb + n];
+                wh[1] = g.B[(size_t)(8 * G8 + 2 * h + 1) * g.ldb + n];
+            }
+        }
+    }
+
+    // token-tile staging registers: NAMED vectors, not an array — hipcc left a float4[7] that lives across the tile
+    // loop in scratch memory (one scratch round trip per load)
+    static_assert(NV == 7, "staging code below is written out for 7 vectors per thread (64 x 100 floats, 256 threads)");
+    float4 ta0, ta1, ta2, ta3, ta4, ta5, ta6;
+#define GF_REP7(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6)
+#define GF_WRES_IDX(J)                                                                                   \
+    const int ti##J = min(tid + J * 256, TOTALV - 1); /* clamped duplicates rewrite the last vector */   \
+    const int trow##J = ti##J / KV, tcol##J = 4 * (ti##J - trow##J * KV), soff##J = trow##J * LD + tcol##J;
+    GF_REP7(GF_WRES_IDX)
+#define GF_WRES_GLOAD1(J) ta##J = *reinterpret_cast<const float4*>(g.A + (size_t)min(mrow0 + trow##J, g.M - 1) * g.lda + tcol##J);
+#define GF_WRES_GLOAD(MT) { const int mrow0 = (MT) * BM; GF_REP7(GF_WRES_GLOAD1) }
+#define GF_WRES_SSTORE1(J) *reinterpret_cast<float4*>(sdst + soff##J) = ta##J;
+#define GF_WRES_SSTORE(BUF) { float* const sdst = smem + (BUF) * (BM * LD); GF_REP7(GF_WRES_SSTORE1) }
+
+    DropCtx dc;
+    if (epi_has_dropout<EPI>()) dc = make_drop(g.ea.rng, g.ea.rng_add, g.ea.site, g.ea.p, g.ea.train);
+    else dc.on = 0;
+    const int nbase = n0 + wn * 32;
+    float bias = 0.f;                                           // the wave's columns never change: one load per workgroup
+    if (EPI == EPI_NONE || EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU)
+        if (g.ea.bias != nullptr) bias = g.ea.bias[min(nbase + r, g.N - 1)];
+
+    int mt = j0;
+    if (mt >= mtiles) return;                                   // (the host never launches such a workgroup)
+    GF_WRES_GLOAD(mt)
+    GF_WRES_SSTORE(0)
+    __syncthreads();
+    int buf = 0;
+
+    // One tile's 50 MFMAs with their LDS fragment reads.
+#define GF_WRES_MFMA(ACC, BUF)                                                                              \
+    {                                                                                                       \
+        const float* arow = smem + (BUF) * (BM * LD) + (wm * 32 + r) * LD;                                  \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = 0.f;                                        \
+        _Pragma("unroll") for (int gq = 0; gq < G8; ++gq) {                                                 \
+            const float4 q = *reinterpret_cast<const float4*>(arow + 8 * gq + 4 * h);                       \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.x, wf[gq][0], ACC, 0, 0, 0);                        \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.y, wf[gq][1], ACC, 0, 0, 0);                        \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.z, wf[gq][2], ACC, 0, 0, 0);                        \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.w, wf[gq][3], ACC, 0, 0, 0);                        \
+        }                                                                                                   \
+        if (HALF) {                                                                                         \
+            const float2 q = *reinterpret_cast<const float2*>(arow + 8 * G8 + 2 * h);                       \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.x, wh[0], ACC, 0, 0, 0);                            \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.y, wh[1], ACC, 0, 0, 0);                            \
+        }                                                                                                   \
+    }
+#pragma unroll 1
+    for (; mt < mtiles; mt += wg_per_panel, buf ^= 1) {
+        const int mbase = mt * BM + wm * 32;
+        const int mload = min(mt + wg_per_panel, mtiles - 1);   // unconditional (clamped): no load under a branch
+        GF_WRES_GLOAD(mload)
+        float aux[1][1][16];
+        gemm_load_aux<EPI, 1, 1>(g, aux, mbase, nbase, 0, r, h);
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t keep[1][1];
+        gemm_keep_bits<EPI, 1, 1>(g, dc, keep, mbase, nbase, r, h);
+        floatx16 acc[1][1];
+        GF_WRES_MFMA(acc[0][0], buf)
+        __builtin_amdgcn_sched_barrier(0);
+        GF_WRES_SSTORE(buf ^ 1)
+        if (mbase + 32 <= g.M && nbase + 32 <= g.N) {           // wave-uniform
+            gemm_apply_store_full<EPI>(g, acc[0][0], aux[0][0], bias, mbase, nbase, r, h, dc, keep[0][0]);
+        } else {
+            gemm_apply_store<EPI, 1, 1>(g, acc, aux, mbase, nbase, 0, r, h, dc, keep);
+        }
+        __syncthreads();
+    }
+#undef GF_WRES_MFMA
+#undef GF_WRES_GLOAD
+#undef GF_WRES_SSTORE
+#undef GF_WRES_GLOAD1
+#undef GF_WRES_SSTORE1
+#undef GF_WRES_IDX
+#undef GF_REP7
+}
+
+template <int MODE, int EPI>
+static int launch_wres(const GemmArgs& g, hipStream_t st) {
+    constexpr int KC = 100;
+    constexpr size_t lds = 2 * 64 * 4 * ((KC / 4) | 1) * sizeof(float);
+    const int panels = (g.N + 63) / 64, mtiles = (g.M + 63) / 64;
+    GF_TRY((lds_optin<gemm_wres_kernel<MODE, EPI, KC>>(lds, "gemm_wres")));
+    // persistent grid = exactly the workgroups the device holds at once (queried once per kernel and device)
+    static thread_local int resident[16] = {0};
+    int devid = 0;
+    GF_HIP(hipGetDevice(&devid));
+    int& res = resident[devid & 15];
+    if (res == 0) {
+        int per_cu = 0, cus = 0;
+        GF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_wres_kernel<MODE, EPI, KC>, 256, lds));
+        GF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid));
+        res = per_cu * cus > 0 ? per_cu * cus : 512;
+    }
+    int per = res / panels;
+    if (per < 1) per = 1;
+    if (per > mtiles) per = mtiles;
+    hipLaunchKernelGGL((gemm_wres_kernel<MODE, EPI, KC>), dim3(panels * per), dim3(256), lds, st, g, mtiles, per);
+    GF_LAUNCH_CHECK();
+    return 0;
 }
 
 // C[i] += sum_z part[z][i] (i < nC), colsum[i] += sum_z part[z][nC + i] (i < nS), slabs added in split order z = 0, 1, ...
@@ -558,6 +874,9 @@ static int launch_pick(const GemmArgs& g, int splits, hipStream_t st) {
     // measured on MI355X (tools/gemm_bench.py, M = 3008 / 6016, N = 100 .. 2048, K = 100 .. 2048): with the
     // straight-line K loop the 4-wave 64x64x16 block is the fastest or within 2 % of the fastest of every block /
     // wave-tile shape tried (64x64x32, 128x64, 64x128, 128x128 with 2, 4, 8 or 16 waves), so it is the only one used.
+    if constexpr (MODE != MODE_TN)
+        if (g.K == 100 && g.N >= 1024 && splits == 1 && (g.lda & 3) == 0 && ((MODE == MODE_NT) ? (g.ldb & 3) == 0 : true))
+            return launch_wres<MODE, EPI>(g, st);
     if (g.K <= 128) return launch_cfg<MODE, 64, 64, 16, EPI, 2, 2, 1>(g, splits, st);
     return launch_cfg<MODE, 64, 64, 16, EPI>(g, splits, st);
 }

@@ -38,7 +38,8 @@ def rel_err(a, b):
 
 
 GEMM_SHAPES = [(3008, 300, 100), (3008, 2048, 100), (3008, 100, 2048), (282, 1536, 512), (14, 300, 100),
-               (5, 4, 4), (65, 68, 20), (3008, 64, 100), (3008, 16, 64), (330, 100, 512), (6016, 2048, 512)]
+               (5, 4, 4), (65, 68, 20), (3008, 64, 100), (3008, 16, 64), (330, 100, 512), (6016, 2048, 512),
+               (3025, 1100, 100), (6016, 2048, 100), (40, 1024, 100)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
@@ -53,7 +54,8 @@ def test_gemm_nt(lib, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(3008, 100, 300), (3008, 2048, 100), (3008, 100, 2048), (282, 512, 1536),
-                                   (14, 100, 300), (5, 4, 4), (65, 68, 20), (3008, 64, 16), (3008, 512, 100)])
+                                   (14, 100, 300), (5, 4, 4), (65, 68, 20), (3008, 64, 16), (3008, 512, 100),
+                                   (3025, 1100, 100), (6016, 2048, 100), (40, 1024, 100)])
 def test_gemm_nn(lib, M, N, K):
     g = torch.Generator().manual_seed(M + N * 5 + K * 11)
     A, Bm = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)

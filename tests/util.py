@@ -94,10 +94,10 @@ def _assert_close(t, ref, rtol, atol, label, outlier_frac=0.02, outlier_mult=100
     return err.max() / scale
 
 
-def check_summary(g, prefix, t, rtol=1e-4, atol=1e-5, what="", strict=False, outlier_frac=0.02, l2_rtol=1e-3):
+def check_summary(g, prefix, t, rtol=1e-4, atol=1e-5, what="", strict=False, outlier_frac=0.02, l2_rtol=1e-3, outlier_mult=100.0):
     """compare tensor `t` with the fixture summary stored under prefix/..."""
     t = np.asarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t, dtype=np.float64)
-    kw = dict(outlier_frac=0.0, outlier_mult=1.0) if strict else dict(outlier_frac=outlier_frac)
+    kw = dict(outlier_frac=0.0, outlier_mult=1.0) if strict else dict(outlier_frac=outlier_frac, outlier_mult=outlier_mult)
     if prefix + "/full" in g.files:
         ref = g[prefix + "/full"].astype(np.float64)
         assert ref.shape == t.shape, (prefix, ref.shape, t.shape)
