@@ -145,8 +145,8 @@ def time_dominant_kernel(S, B, reps=3, config="iemocap"):
 
 def time_linear1_kernel(S, B, reps=3):
     """Live HIP-event timing (launch stream = torch's current stream) of the heavy kernel that sits lowest on its roofline:
-    the d_model-100 feed-forward linear1 GEMM with its fused bias + ReLU + dropout epilogue, `gemm_kernel<0,64,64,16,1,2,2,1>`
-    ([T x 100] x [2048 x 100]^T; K = 100 is seven 16-wide K tiles per workgroup).  One iteration launches it 112 times at
+    the d_model-100 feed-forward linear1 GEMM with its fused bias + ReLU + dropout epilogue, `gemm_wres_kernel<0,1,100>`
+    ([T x 100] x [2048 x 100]^T, K = 100).  One iteration launches it 112 times at
     T = S*B (4 generator + 6 frozen-discriminator + 4 no-save generator passes x 8 layers) and 48 times at T = 2*S*B (the
     six batched [real | fake] discriminator passes).  Returns (avg seconds per launch, avg algorithmic flops per launch, launches)."""
     from gan_ffn_amd import _lib, ops
@@ -521,17 +521,19 @@ def main():
         if cfgname == "iemocap":
             # the heavy kernel (>= 5 % of GPU time in profiles/r02_bench_streams1_*) that sits LOWEST on its roofline
             lt, lflop, ln = time_linear1_kernel(S, B)
-            ins = in_step_kernel_us("gemm_kernel<0, 64, 64, 16, 1, 2, 2, 1>", "(32,47,1)") if (S, B) == (94, 32) else None
+            ins = in_step_kernel_us("gemm_wres_kernel<0, 1, 100>", "(512,1,1)") if (S, B) == (94, 32) else None
             out["roofline_worst"] = {
-                "bound": "mfma", "kernel": "gemm_kernel<0,64,64,16,1,2,2,1> = linear1 of the d_model-100 feed-forward block with fused "
-                                           "bias + ReLU + dropout ([T x 100] x [2048 x 100]^T, K = 100); %d launches per iteration" % ln,
+                "bound": "mfma", "kernel": "gemm_wres_kernel<0,1,100> = linear1 of the d_model-100 feed-forward block with fused "
+                                           "bias + ReLU + dropout ([T x 100] x [2048 x 100]^T, K = 100; persistent, weight "
+                                           "fragments register-resident); %d launches per iteration (T = S*B and 2*S*B)" % ln,
                 "achieved": round(lflop / lt / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": round(lflop / lt / FP32_MFMA_PEAK, 4), "avg_kernel_us": round(lt * 1e6, 2),
                 "avg_gflop_per_launch": round(lflop / 1e9, 4), "traffic": None,
-                "in_step_avg_us_T%d" % (S * B): ins,
-                "in_step_frac_T%d" % (S * B): round(2.0 * S * B * 100 * 2048 / (ins * 1e-6) / FP32_MFMA_PEAK, 4) if ins else None,
+                "in_step_avg_us": ins,
+                "in_step_frac": round(lflop / (ins * 1e-6) / FP32_MFMA_PEAK, 4) if ins else None,
                 "how": "HIP events around one iteration's launch mix of this kernel replayed in isolation on the launch stream; "
-                       "in_step_* = the same kernel's average inside the step, from the committed rocprofv3 summary " + IN_STEP_FILE}
+                       "in_step_* = the same symbol's average over the same launch mix inside the single-stream step, from the "
+                       "committed rocprofv3 summary " + IN_STEP_FILE}
         if world == 1 and not args.no_cpu_baseline:
             threads = host_threads()
             cv, cdt, cutts = cpu_baseline(S, args.cpu_sample_batch, threads, config=cfgname)

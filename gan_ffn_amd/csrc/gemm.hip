@@ -632,7 +632,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmArgs g) {
 //   * the token tile (64 x K) is double-buffered in LDS through a register prefetch: tile i+1's global loads are issued
 //     before tile i's MFMAs and written to the other LDS buffer after them — one barrier per tile, the load latency is
 //     paid once per workgroup, and the epilogue's stores of tile i drain under tile i+1's MFMAs;
-//   * K = 100 is 12 groups of 8 + one group of 4: 50 MFMAs per wave and tile (the generic BK = 16 loop runs 56);
+//   * K = 100 is 13 groups of 8: 52 MFMAs per wave and tile (the generic BK = 16 loop runs 56), in gemm_body's k order,
+//     so both kernels give the same bits;
 //   * the grid is exactly the number of workgroups the device holds at once (occupancy query, cached).
 // Measured (tools/lab/ffn_gemm_lab.py, T = 3008 / 6016, train mode): 22.0 / 35.8 us against 22.1 / 39.3 us for the generic
 // kernel in the step.  What bounds it (ablation in the same lab): launch + operand loads 6.6 us, MFMA chain 7.7 us (= its
@@ -645,7 +646,7 @@ template <int MODE, int EPI, int KC>
 __global__ __launch_bounds__(256) void gemm_wres_kernel(GemmArgs g, int mtiles, int wg_per_panel) {
     static_assert(KC % 4 == 0 && KC <= 128, "short K only");
     constexpr int BM = 64, BN = 64;
-    constexpr int G8 = KC / 8, HALF = (KC % 8) ? 1 : 0;          // full groups of 8, one trailing group of 4
+    constexpr int G8 = (KC + 7) / 8;                              // groups of 8 along k; k >= KC carries zero weights
     constexpr int LD = 4 * ((KC / 4) | 1);                        // LDS row stride: 4 x odd floats (conflict-free b128 reads)
     constexpr int KV = KC / 4, TOTALV = BM * KV, NV = (TOTALV + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -655,29 +656,22 @@ __global__ __launch_bounds__(256) void gemm_wres_kernel(GemmArgs g, int mtiles, 
     const int panel = blockIdx.x / wg_per_panel, j0 = blockIdx.x - panel * wg_per_panel;
     const int n0 = panel * BN;
 
-    // weight fragments: MFMA j of group gq takes k = 8 gq + 4 h + j; the trailing half group takes k = 8 G8 + 2 h + j
-    float wf[G8][4], wh[2];
+    // weight fragments: MFMA j of group gq takes k = 8 gq + 4 h + j — the k order of gemm_body, so this kernel's results
+    // are bit-identical to the generic kernel's (a K tail is zero weights against clamped, finite token values)
+    float wf[G8][4];
     {
         const int n = min(n0 + wn * 32 + r, g.N - 1);
-        if (MODE == MODE_NT) {
-            const float* wrow = g.B + (size_t)n * g.ldb;
 #pragma unroll
-            for (int gq = 0; gq < G8; ++gq) {
-                const float4 q = *reinterpret_cast<const float4*>(wrow + 8 * gq + 4 * h);
-                wf[gq][0] = q.x; wf[gq][1] = q.y; wf[gq][2] = q.z; wf[gq][3] = q.w;
-            }
-            if (HALF) {
-                const float2 q = *reinterpret_cast<const float2*>(wrow + 8 * G8 + 2 * h);
-                wh[0] = q.x; wh[1] = q.y;
-            }
-        } else {
+        for (int gq = 0; gq < G8; ++gq) {
+            const int k = 8 * gq + 4 * h;                       // K % 4 == 0: a group half is inside K or outside it
+            const float keepw = k < KC ? 1.f : 0.f;
+            const int kc = min(k, KC - 4);
+            if (MODE == MODE_NT) {
+                const float4 q = *reinterpret_cast<const float4*>(g.B + (size_t)n * g.ldb + kc);
+                wf[gq][0] = q.x * keepw; wf[gq][1] = q.y * keepw; wf[gq][2] = q.z * keepw; wf[gq][3] = q.w * keepw;
+            } else {
 #pragma unroll
-            for (int gq = 0; gq < G8; ++gq)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wf[gq][j] = g.B[(size_t)(8 * gq + 4 * h + j) * g.ldb + n];
-            if (HALF) {
-                wh[0] = g.B[(size_t)(8 * G8 + 2 * h) * g.ldb + n];
-                wh[1] = g.B[(size_t)(8 * G8 + 2 * h + 1) * g.ldb + n];
+                for (int j = 0; j < 4; ++j) wf[gq][j] = g.B[(size_t)(kc + j) * g.ldb + n] * keepw;
             }
         }
     }
@@ -711,22 +705,17 @@ __global__ __launch_bounds__(256) void gemm_wres_kernel(GemmArgs g, int mtiles, 
     __syncthreads();
     int buf = 0;
 
-    // One tile's 50 MFMAs with their LDS fragment reads.
+    // One tile's 4 * G8 MFMAs with their LDS fragment reads.
 #define GF_WRES_MFMA(ACC, BUF)                                                                              \
     {                                                                                                       \
         const float* arow = smem + (BUF) * (BM * LD) + (wm * 32 + r) * LD;                                  \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = 0.f;                                        \
         _Pragma("unroll") for (int gq = 0; gq < G8; ++gq) {                                                 \
-            const float4 q = *reinterpret_cast<const float4*>(arow + 8 * gq + 4 * h);                       \
+            const float4 q = *reinterpret_cast<const float4*>(arow + min(8 * gq + 4 * h, KC - 4));          \
             ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.x, wf[gq][0], ACC, 0, 0, 0);                        \
             ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.y, wf[gq][1], ACC, 0, 0, 0);                        \
             ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.z, wf[gq][2], ACC, 0, 0, 0);                        \
             ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.w, wf[gq][3], ACC, 0, 0, 0);                        \
-        }                                                                                                   \
-        if (HALF) {                                                                                         \
-            const float2 q = *reinterpret_cast<const float2*>(arow + 8 * G8 + 2 * h);                       \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.x, wh[0], ACC, 0, 0, 0);                            \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.y, wh[1], ACC, 0, 0, 0);                            \
         }                                                                                                   \
     }
 #pragma unroll 1

@@ -66,6 +66,28 @@ def test_gemm_nn(lib, M, N, K):
     assert rel_err(Cd, ref) < 2e-6 * max(1, K ** 0.5)
 
 
+def test_weight_resident_short_k_kernel_gives_the_generic_kernels_bits(lib):
+    """K = 100, N >= 1024 runs on the persistent weight-resident kernel (gemm_wres_kernel); the same rows through the
+    generic kernel (N < 1024) must give identical bits — both use the same k order inside the MFMA chain"""
+    g = torch.Generator().manual_seed(5)
+    M, K = 3025, 100
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(2048, K, generator=g), torch.randn(2048, generator=g)
+    Ad, Wd, bd = dev(A), dev(W), dev(b)
+    big = torch.empty(M, 2048, device="cuda")
+    lib.call("ganffn_gemm_nt", ptr(Ad), ptr(Wd), ptr(bd), ptr(big), M, 2048, K, stream())
+    Ws, bs = Wd[:1000].contiguous(), bd[:1000].contiguous()
+    small = torch.empty(M, 1000, device="cuda")
+    lib.call("ganffn_gemm_nt", ptr(Ad), ptr(Ws), ptr(bs), ptr(small), M, 1000, K, stream())
+    assert torch.equal(big[:, :1000], small)
+    Bm = dev(torch.randn(K, 2048, generator=g))
+    big2 = torch.empty(M, 2048, device="cuda")
+    lib.call("ganffn_gemm_nn", ptr(Ad), ptr(Bm), ptr(big2), M, 2048, K, stream())
+    Bs = Bm[:, :1000].contiguous()
+    small2 = torch.empty(M, 1000, device="cuda")
+    lib.call("ganffn_gemm_nn", ptr(Ad), ptr(Bs), ptr(small2), M, 1000, K, stream())
+    assert torch.equal(big2[:, :1000], small2)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 100, 3008), (2048, 100, 3008), (100, 2048, 3008), (1536, 512, 282),
                                    (100, 100, 14), (4, 4, 5), (68, 20, 65), (16, 64, 3008), (2048, 512, 6016)])
 def test_gemm_tn_acc(lib, M, N, K):
