@@ -8,6 +8,7 @@
 Host-side reporting only: metrics come from the same scikit-learn calls the reference makes.  The numbers that feed
 them (losses, log-probabilities) come from the HIP path (engine.GanEngine / engine.Phase2Engine).
 """
+import json
 import os
 
 import numpy as np
@@ -78,6 +79,9 @@ def draw_GAN_loss(df, path="./output/GAN_loss.png"):
 # ------------------------------------------------------------------------------------------------
 # checkpoints: whole pickled modules, `save_path + name + ".pth"`
 # ------------------------------------------------------------------------------------------------
+RNG_STATE_FILE = "philox_state.json"
+
+
 def save_GAN_models(models, save_path):
     """models in the order of MODEL_NAMES (a dict {"gens": .., "discs": ..} pair is accepted too)"""
     if isinstance(models, dict):
@@ -85,6 +89,11 @@ def save_GAN_models(models, save_path):
         models = [g["acoustic"], d["acoustic"], g["visual"], d["visual"], g["text"], d["text"]]
     for name, m in zip(MODEL_NAMES, models):
         torch.save(m, save_path + name + ".pth")
+    dev = next(models[0].parameters()).device
+    if dev.type == "cuda":                           # beside the reference's six files: where the Philox stream stands
+        from . import ops
+        with open(save_path + RNG_STATE_FILE, "w") as f:
+            json.dump(ops.DeviceRng.get(dev).state_dict(), f)
 
 
 def load_GAN_models(save_path, device="cuda"):
@@ -106,6 +115,11 @@ def load_GAN_models(save_path, device="cuda"):
         out[name] = obj.to(device).eval()
     gens = {"acoustic": out["acoustic_gen"], "visual": out["visual_gen"], "text": out["text_gen"]}
     discs = {"acoustic": out["acoustic_disc"], "visual": out["visual_disc"], "text": out["text_disc"]}
+    if os.path.exists(save_path + RNG_STATE_FILE) and torch.device(device).type == "cuda":
+        # a resumed run continues the dropout stream of the run it resumes (absent for reference-made checkpoints)
+        from . import ops
+        with open(save_path + RNG_STATE_FILE) as f:
+            ops.DeviceRng.get(device).load_state_dict(json.load(f))
     return gens, discs
 
 

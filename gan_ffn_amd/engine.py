@@ -186,6 +186,7 @@ STREAM_MAP = {1: [0] * 12,
 
 # Bi-modal schedule of the MELD-dimension extension workload (BASELINE.json configs[2]; MELD has text and audio only,
 # dataloader.py:93-95): the text/acoustic sub-steps 5-8 of the reference's order (train_IEMOCAP.py:363-370).
+ADDS_PER_SUBSTEP = 4     # dropout-bearing launches of one sub-step (two encoder passes and two heads)
 SCHEDULE_BIMODAL = [s for s in SCHEDULE if "visual" not in s[1:]]
 STREAM_MAP_BIMODAL = {1: [0, 0, 0, 0], 2: [0, 0, 1, 1]}
 
@@ -197,6 +198,15 @@ class _Runner:
     _cur_stream = None
     _base_add = 0
     _adds = 0
+
+    def _check_slabs(self):
+        """the engine trains the slab it captured at construction; a module that re-packed into a NEW slab since then
+        (`.to(other device)`, `.double()`, load into fresh parameters) would silently stop following — refuse instead"""
+        for group in (getattr(self, "G", {}), getattr(self, "D", {})):
+            for k, st in group.items():
+                if st.m.slab.data_ptr() != st.slab.data_ptr():
+                    raise RuntimeError("network %r re-packed its parameters after the engine was built (module.slab moved): "
+                                       "build the engine after the last .to()/.cuda()/dtype change" % k)
 
     def _init_common(self, device, process_group, n_buckets):
         self.dev = device
@@ -490,6 +500,11 @@ class GanEngine(_Runner):
 
     def _iteration_body(self, batch, device_rng_advance):
         self._adds = 0
+        self._check_slabs()
+        if not device_rng_advance:
+            # eager: this iteration's block of dropout offsets comes from the device's one allocator (shared with the
+            # module path and every other engine); iterations may overlap, the offsets are host-side arguments
+            self._base_add = self.rng.next_add(ADDS_PER_SUBSTEP * len(self.schedule))
         if self.n_streams == 1:
             for i, (kind, who, partner) in enumerate(self.schedule):
                 (self.train_disc if kind == "D" else self.train_gen)(who, partner, batch, i)
@@ -533,7 +548,7 @@ class GanEngine(_Runner):
         if device_rng_advance:
             ops.rng_advance_raw(self.rng.state, self._adds)
         else:
-            self._base_add += self._adds        # eager: offsets advance on the host, iterations may overlap
+            assert self._adds <= ADDS_PER_SUBSTEP * len(self.schedule), self._adds
 
     def synchronize(self):
         """make the current stream wait for all side-stream work (call before reading results / timing)"""
@@ -699,7 +714,12 @@ class Phase2Engine(GanEngine):
         train=False: forward + loss only (model.eval())."""
         S, B = batch["text"].shape[:2]
         self._prepare2(S, B)
+        self._check_slabs()
+        if self.fc_w.data_ptr() != self.fc_slab.data_ptr():
+            raise RuntimeError("GAN_FFN.fc was re-allocated after the engine was built: build Phase2Engine after the last .to()")
         T, C_ = S * B, self.n_classes
+        self._adds = 0
+        self._base_add = self.rng.next_add(8)      # 3 generators x (encoder, head): one block from the device allocator
         adds = {}
         for k in ("acoustic", "visual", "text"):                    # model.py:1441-1443
             adds[k] = self._net_fwd(self.G[k], self.pass_G[k], batch[k], train=train, save=train)
@@ -724,8 +744,7 @@ class Phase2Engine(GanEngine):
                 red.finish()
             ops.adam_step_raw(self.fc_slab, self.fc_grad, self.fc_m, self.fc_v, self.fc_step, self.fc_total, self.lr,
                               0.9, 0.999, 1e-8, self.wd, 1.0 / self.world)
-        self._base_add += self._adds
-        self._adds = 0
+        assert self._adds <= 8, self._adds
         return self.loss, self.log_prob
 
     @staticmethod

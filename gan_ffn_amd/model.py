@@ -155,14 +155,20 @@ class _Net(nn.Module):
         return off, views, per * L
 
     def _pack(self):
+        """(re)build the slab.  When a slab of the right size already exists on the parameters' device it is re-filled IN
+        PLACE, so a no-op `.to(same device)` / `.float()` after an engine captured `module.slab` does not disconnect the
+        engine (which trains the slab) from the module (whose parameters, state_dict and checkpoints are views of it)."""
         ps = self._slab_params()
         total, views, _ = self.slab_layout()
         dev = ps[0].device
-        slab = torch.zeros(total, device=dev, dtype=torch.float32)
+        old = self._slab
+        slab = old if (old is not None and old.device == dev and old.numel() == total) else torch.zeros(total, device=dev, dtype=torch.float32)
         with torch.no_grad():
             for p, (off, shape) in zip(ps, views):
-                slab[off:off + p.numel()].copy_(p.detach().reshape(-1).float())
-                p.data = slab[off:off + p.numel()].view(shape)
+                dst = slab[off:off + p.numel()]
+                if p.data_ptr() != dst.data_ptr() or p.device != dev:
+                    dst.copy_(p.detach().reshape(-1).float())
+                p.data = dst.view(shape)
         self._slab = slab
         self._views = views
 

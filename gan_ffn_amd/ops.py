@@ -62,9 +62,22 @@ class DeviceRng:
         self.counter = 0
 
     def next_add(self, n=1):
+        """reserve n consecutive dropout offsets: THE allocator of this device — the autograd/module path takes one per
+        call, GanEngine / Phase2Engine take one block per iteration, so no two dropout-bearing launches of a process
+        ever share a (seed, offset) pair, whichever path issued them"""
         v = self.counter
         self.counter += n
         return v
+
+    def state_dict(self):
+        """{seed, offset, counter} — saved beside the checkpoints (artifacts.save_GAN_models) so that a resumed run
+        continues the Philox stream instead of replaying the masks of the run it resumes"""
+        seed, offset = [int(v) for v in self.state.cpu()]
+        return {"seed": seed, "offset": offset, "counter": int(self.counter)}
+
+    def load_state_dict(self, d):
+        self.state.copy_(torch.tensor([int(d["seed"]), int(d["offset"])], dtype=torch.int64))
+        self.counter = int(d["counter"])
 
 
 def manual_seed(seed, device=None):

@@ -49,3 +49,37 @@ def test_phase2_epoch_metrics_consistent_with_manual_count(tmp_path):
     assert labels.shape == preds.shape == masks.shape and masks.sum() > 0
     assert abs(acc - round(100.0 * ((labels == preds) * masks).sum() / masks.sum(), 2)) < 1e-9
     assert np.isfinite(avg_loss) and extra[3] == D.IEMOCAPDataset(pk, train=False).testVid
+
+
+def test_checkpoints_carry_the_philox_stream_and_engines_refuse_a_moved_slab(tmp_path):
+    """ the dropout-offset allocator is one per device and travels with the checkpoints; a module that
+    re-packs into a new slab after an engine captured it is refused instead of silently ignored; a no-op .to() keeps
+    the slab in place"""
+    from gan_ffn_amd import artifacts as A, engine as E, ops, data as D
+    gens, discs = E.build_networks(100, 0.2, "cuda", 5)
+    ops.manual_seed(11)
+    eng = E.GanEngine(gens, discs)
+    b = D.synthetic_batch(B=3, S_max=9, seed=2, device="cuda")
+    eng.iteration(b)
+    eng.synchronize()
+    rng = ops.DeviceRng.get("cuda")
+    assert rng.counter == 48
+    y = gens["text"].train()(b["text"])                      # the module path draws from the same allocator
+    assert rng.counter == 49 and torch.isfinite(y).all()
+    save = str(tmp_path) + "/GAN_save_"
+    A.save_GAN_models({"gens": gens, "discs": discs}, save)
+    ops.manual_seed(3)                                        # a new process would start from its own default
+    A.load_GAN_models(save, "cuda")
+    assert rng.state_dict() == {"seed": 11, "offset": 0, "counter": 49}
+    # no-op .to(): same slab, engine still attached
+    ptr = gens["text"].slab.data_ptr()
+    gens["text"].to("cuda")
+    assert gens["text"].slab.data_ptr() == ptr
+    eng.iteration(b)
+    eng.synchronize()
+    # a real re-pack (round trip through the host) moves the slab: the engine must notice
+    gens["acoustic"].cpu()
+    gens["acoustic"].cuda()
+    assert gens["acoustic"].slab.data_ptr() != eng.G["acoustic"].slab.data_ptr()
+    with pytest.raises(RuntimeError, match="re-packed"):
+        eng.iteration(b)
