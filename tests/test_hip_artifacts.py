@@ -65,12 +65,12 @@ def test_checkpoints_carry_the_philox_stream_and_engines_refuse_a_moved_slab(tmp
     rng = ops.DeviceRng.get("cuda")
     assert rng.counter == 48
     y = gens["text"].train()(b["text"])                      # the module path draws from the same allocator
-    assert rng.counter == 49 and torch.isfinite(y).all()
+    assert rng.counter == 50 and torch.isfinite(y).all()      # encoder + head: two dropout-bearing calls
     save = str(tmp_path) + "/GAN_save_"
     A.save_GAN_models({"gens": gens, "discs": discs}, save)
     ops.manual_seed(3)                                        # a new process would start from its own default
     A.load_GAN_models(save, "cuda")
-    assert rng.state_dict() == {"seed": 11, "offset": 0, "counter": 49}
+    assert rng.state_dict() == {"seed": 11, "offset": 0, "counter": 50}
     # no-op .to(): same slab, engine still attached
     ptr = gens["text"].slab.data_ptr()
     gens["text"].to("cuda")
