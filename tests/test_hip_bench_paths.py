@@ -41,3 +41,19 @@ def test_bench_rccl_path_on_one_rank():
     d = _last_json(r.stdout)
     assert d["config"]["launch"] == "eager" and d["config"]["parallelism"] == "dp1"
     assert all(0.1 < v < 5 for v in d["config"]["last_losses"].values())
+
+
+@pytest.mark.parametrize("config", ["meld", "drnn"])
+def test_bench_other_configs_on_the_rccl_path(config):
+    """configs[2] (MELD widths) and configs[4] (GAN-FFN + DialogueRNN) through the same launcher and the 1-rank nccl
+    group: the line keeps the contract's keys and a roofline object"""
+    env = dict(os.environ, GANFFN_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29519" if config == "meld" else "29521",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--config", config], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "config", "roofline"):
+        assert k in d, k
+    assert d["value"] > 0 and d["config"]["parallelism"] == "dp1" and 0 < d["roofline"]["frac"] < 1
