@@ -126,10 +126,13 @@ def time_dominant_kernel(S, B, reps=3, config="iemocap"):
         flops = sum(2.0 * m * n_ * k for (m, n_, k) in probs)
         calls.append((cnt, (n, PA, PB, PC, PS, Ms, Ns, Ks), flops))
 
+    nws = int(_lib.load().ganffn_gemm_tn_grouped_workspace_floats())
+    ws = torch.empty(nws, device="cuda")         # as inside the encoder backward: narrow groups split their token range
+
     def one_iteration():
         for cnt, a, _ in calls:
             for _i in range(cnt):
-                _lib.call("ganffn_gemm_tn_grouped", a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], st)
+                _lib.call("ganffn_gemm_tn_grouped", a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], ops._ptr(ws), nws, st)
     one_iteration()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -507,7 +510,9 @@ def main():
                        "step_frac_of_fp32_mfma_peak": round(step_tflops * 1e12 / (FP32_MFMA_PEAK * world), 4),
                        "last_losses": {k: round(v, 4) for k, v in losses.items()}},
             "roofline": {"bound": "mfma", "kernel": "gemm_tn_grouped_kernel (all 32 weight-gradient GEMMs of one encoder backward pass in one "
-                                                     "launch: one owner workgroup per output tile over the whole token range, no atomics); "
+                                                     "launch, no atomics: one owner workgroup per output tile, or — narrow d_model-100 groups "
+                                                     "— the token range split in two with partial slabs and an ordered reduce launch, whose "
+                                                     "time is included); "
                                                      "%d launches per iteration; the (kernel, launch shape) with the largest share of GPU "
                                                      "time in the single-stream profile" % klaunch,
                          "achieved": round(kflop / kt / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",

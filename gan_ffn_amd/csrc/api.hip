@@ -112,7 +112,9 @@ static int64_t enc_ws_floats(const ganffn_enc_cfg* c) {
     // L x (dh | dyA dyB d_qkv(3)) | dz2 dz1 d_attn | tmp slabs | L x 2 LayerNorm partial-sum blocks
     // + L packed FFN weight blocks (fused feed-forward kernel, d_model 100)
     const int64_t pack = ffn_fused_supported(c->E, c->F) ? (int64_t)c->L * ffn_pack_floats(c->F) : 0;
-    const int64_t bwd = (int64_t)c->L * (TF + 5 * TE) + (3 + MAX_SPLITS) * TE + (int64_t)c->L * 2 * ln_part_floats(c) + pack;
+    // + the partial-slab workspace of the grouped weight-gradient launch (narrow groups split the token range)
+    const int64_t bwd = (int64_t)c->L * (TF + 5 * TE) + (3 + MAX_SPLITS) * TE + (int64_t)c->L * 2 * ln_part_floats(c) + pack +
+                        gemm_tn_grouped_part_floats() + 8;
     const SavedOff s = saved_off(c);
     const int64_t fwd_nosave = 2 * TE + s.per_layer + MAX_SPLITS * TE + pack;   // X ping-pong + one layer's saved set + tmp slabs + packs
     return (bwd > fwd_nosave ? bwd : fwd_nosave) + 64;
@@ -261,6 +263,8 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
     float* pack = lnp0 + (int64_t)c->L * 2 * LNP;    // packed FFN weights of the layers of this range (backward orientation)
     const bool fused = ffn_fused_supported(E, F) && g_ffn_fused;
     const int64_t PK = fused ? ffn_pack_floats(F) : 0;
+    float* tnp = pack + (ffn_fused_supported(E, F) ? (int64_t)c->L * ffn_pack_floats(F) : 0);   // grouped-wgrad partial slabs
+    tnp = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(tnp) + 15) & ~(uintptr_t)15);
     if (fused)
         GF_TRY(launch_ffn_pack(params + (int64_t)layer_lo * lo.total, lo.total, lo.w1, lo.w2, pack, layer_hi - layer_lo, F, 1, st));
     const int lnblk = ln_bwd_blocks(T);
@@ -321,7 +325,7 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
         // in-proj wgrad + dgrad; dX[l] = d_qkv W_in + dz1
         if (G) tn[ntn++] = TnDesc{d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T};
         if (ntn == 40 || (l == layer_lo && ntn > 0)) {
-            GF_TRY(launch_gemm_tn_grouped(tn, ntn, st));
+            GF_TRY(launch_gemm_tn_grouped(tn, ntn, st, tnp, gemm_tn_grouped_part_floats()));
             ntn = 0;
         }
         EpiArgs eadd;
@@ -529,12 +533,14 @@ extern "C" int ganffn_ffn_fused_bwd(const float* dy, const float* w1, const floa
     return -1000 - splits;
 }
 extern "C" int64_t ganffn_ffn_pack_floats(int F) { return ffn_pack_floats(F); }
+extern "C" int64_t ganffn_gemm_tn_grouped_workspace_floats(void) { return gemm_tn_grouped_part_floats(); }
 extern "C" int ganffn_gemm_tn_grouped(int n, const float* const* At, const float* const* Bm, float* const* C, float* const* colsum,
-                                      const int* M, const int* N, const int* K, void* stream) {
+                                      const int* M, const int* N, const int* K, float* workspace, int64_t workspace_floats,
+                                      void* stream) {
     GF_CHECK_ARG(n >= 1 && n <= 40 && At && Bm && C && M && N && K, "gemm_tn_grouped: bad arguments");
     TnDesc d[40];
     for (int i = 0; i < n; ++i) d[i] = TnDesc{At[i], M[i], Bm[i], N[i], C[i], N[i], colsum ? colsum[i] : nullptr, M[i], N[i], K[i]};
-    return launch_gemm_tn_grouped(d, n, (hipStream_t)stream);
+    return launch_gemm_tn_grouped(d, n, (hipStream_t)stream, workspace, (long)workspace_floats);
 }
 extern "C" int ganffn_attention_fwd(const float* qkv, float* o, float* lse, int S, int B, int E, int H, float p, uint32_t site,
                                     const uint64_t* rng, uint64_t add, void* stream) {

@@ -232,7 +232,11 @@ struct TnDesc {
     float* colsum;
     int M, N, K;
 };
-int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st);
+// part_ws (optional, gemm_tn_grouped_part_floats() floats): when the group has too few output tiles to load every CU
+// evenly, the token range is split over 2..8 workgroups per tile; each writes its partial tile to the workspace and one
+// grouped reduce launch adds the partials in split order (deterministic).  Without a workspace: one owner per tile.
+int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws = nullptr, long part_floats = 0);
+long gemm_tn_grouped_part_floats();
 
 // lse [B*H x S]: log-sum-exp of every score row, written by the forward (may be NULL: not kept) and, together with the
 // forward's output o, read by the backward of the small-head kernels (attention16.hip); the head_dim 60/64 kernels

@@ -388,7 +388,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     const int wm = wave / WGN, wn = wave % WGN;
     const int r = lane & 31, h = lane >> 5;
     const int m0 = by * BM, n0 = bx * BN;
-    const int kbeg = bz * g.kchunk;
+    const int kbeg = min(bz * g.kchunk, g.K);   // (a split beyond a short problem's range computes and stores zeros)
     const int kend = min(g.K, kbeg + g.kchunk);
 
     floatx16 acc[TM][TN];
@@ -815,10 +815,14 @@ struct TnProblem {
     int lda, ldb, ldc, M, N, K, kchunk;
     int tiles_n, tiles_mn;   // tiles along N, tiles_m * tiles_n
     int block0;              // first workgroup of this problem
+    long part_off;           // this problem's [M x N | M] partial block inside a split's slab
 };
 struct TnGroup {
     TnProblem p[MAXP];
     int n;
+    float* part;             // partial-slab workspace (nullptr: one owner workgroup per tile adds in place)
+    long part_stride;        // floats per split slab
+    int splits;
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
@@ -838,6 +842,7 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
     GemmArgs g;
     g.A = q.A; g.lda = q.lda; g.B = q.B; g.ldb = q.ldb; g.C = q.C; g.ldc = q.ldc; g.colsum = q.colsum;
     g.M = q.M; g.N = q.N; g.K = q.K; g.kchunk = q.kchunk; g.slab_stride = 0;
+    if (grp.part != nullptr) { g.part = grp.part + q.part_off; g.part_stride = grp.part_stride; }
     // tiles in panels of 8 along N (n fastest inside a panel, then m, then the next panel): an XCD's contiguous
     // range of ~32 tiles is then a 4 x 8 patch — 12 operand panels instead of the 33 of a 1 x 32 strip
     constexpr int PW = 8;
@@ -983,30 +988,89 @@ int launch_gemm_tn_acc(const float* At, int lda, const float* Bm, int ldb, float
     return 0;
 }
 
-// dW_i[M_i x N_i] += At_i^T B_i for n problems in one launch (see gemm_tn_grouped_kernel).  No split-K: every output tile
-// has one owner workgroup that runs the whole token range and adds its result in place — deterministic, and the group
-// is wide enough without it (one encoder backward pass: 1136 tiles at d_model 100, 6144 at 512).
-int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st) {
+// C_i += sum_z part[z][i], colsum_i += sum_z part[z][M N + i] for every problem of a split grouped launch, slabs in split
+// order; blockIdx.y = problem, blockIdx.x strides over its elements
+__global__ __launch_bounds__(256) void tn_reduce_grouped_kernel(TnGroup grp) {
+    const TnProblem& q = grp.p[blockIdx.y];
+    const float* part = grp.part + q.part_off;
+    const long nC = (long)q.M * q.N;
+    for (long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i4 < nC; i4 += (long)gridDim.x * 1024) {
+        float4 s = *reinterpret_cast<const float4*>(part + i4);
+        for (int z = 1; z < grp.splits; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)z * grp.part_stride + i4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const long row = i4 / q.N, col = i4 - row * q.N;       // N % 4 == 0: a float4 stays inside one row
+        float* dst = q.C + row * q.ldc + col;
+        dst[0] += s.x; dst[1] += s.y; dst[2] += s.z; dst[3] += s.w;
+    }
+    if (q.colsum != nullptr)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < q.M; i += gridDim.x * 256) {
+            float s = part[nC + i];
+            for (int z = 1; z < grp.splits; ++z) s += part[(size_t)z * grp.part_stride + nC + i];
+            q.colsum[i] += s;
+        }
+}
+
+// A grouped launch is "wide enough" at TN_GROUP_TILES workgroups (10 per CU: the slowest CU is then within a few % of the
+// average); below that the token range of every tile is split so that about that many workgroups exist.
+constexpr int TN_GROUP_TILES = 2560;
+constexpr int TN_GROUP_MAXSPLIT = 8;
+long gemm_tn_grouped_part_floats() { return (long)(TN_GROUP_TILES + 256) * (64 * 64 + 64) + 4 * MAXP; }
+
+// dW_i[M_i x N_i] += At_i^T B_i for n problems in one launch (see gemm_tn_grouped_kernel).  Wide groups (one encoder
+// backward pass at d_model 512: 6144 tiles): every output tile has one owner workgroup that runs the whole token range and
+// adds its result in place.  Narrow groups (d_model 100: 1136 tiles for 1280 resident workgroup slots, the busiest CU 5
+// tiles against an average of 4.4; a 2-layer gradient bucket: 284 tiles) with a workspace: the token range is split, the
+// partial tiles go to per-split slabs and one reduce launch adds them in split order.  Deterministic either way.
+int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws, long part_floats) {
     GF_CHECK_ARG(d && n >= 1 && n <= MAXP, "gemm_tn_grouped: n=%d out of [1,%d]", n, MAXP);
     TnGroup grp;
     grp.n = n;
-    int total = 0;
+    long tiles = 0, per_split = 0;
+    int kmin = 1 << 30;
     for (int i = 0; i < n; ++i) {
         GF_TRY(check_common(d[i].At, d[i].lda, d[i].B, d[i].ldb, d[i].C, d[i].M, d[i].N, d[i].K));
         GF_CHECK_ARG((d[i].M & 3) == 0 && (d[i].N & 3) == 0, "gemm_tn_grouped: M, N must be multiples of 4");
+        tiles += (long)((d[i].M + 63) / 64) * ((d[i].N + 63) / 64);
+        per_split += (((long)d[i].M * d[i].N + d[i].M) + 3) & ~3L;
+        kmin = d[i].K < kmin ? d[i].K : kmin;
+    }
+    int splits = 1;
+    if (part_ws != nullptr && tiles < TN_GROUP_TILES) {
+        splits = (int)((TN_GROUP_TILES + tiles - 1) / tiles);
+        if (splits > TN_GROUP_MAXSPLIT) splits = TN_GROUP_MAXSPLIT;
+        if (splits > kmin / 256) splits = kmin / 256;             // at least 256 tokens per workgroup
+        if ((long)splits * per_split > part_floats) splits = (int)(part_floats / per_split);
+        if (splits < 2) splits = 1;
+    }
+    grp.splits = splits;
+    grp.part = splits > 1 ? part_ws : nullptr;
+    grp.part_stride = per_split;
+    GF_CHECK_ARG(splits == 1 || aligned16(part_ws), "gemm_tn_grouped: partial-slab workspace must be 16-byte aligned");
+    int total = 0;
+    long off = 0;
+    for (int i = 0; i < n; ++i) {
         TnProblem& q = grp.p[i];
         q.A = d[i].At; q.B = d[i].B; q.C = d[i].C; q.colsum = d[i].colsum;
         q.lda = d[i].lda; q.ldb = d[i].ldb; q.ldc = d[i].ldc; q.M = d[i].M; q.N = d[i].N; q.K = d[i].K;
-        q.kchunk = d[i].K;
+        // chunk: a multiple of 64 tokens; problems with different K in one group simply get fewer non-empty splits
+        q.kchunk = splits > 1 ? (int)((((long)d[i].K + splits - 1) / splits + 63) / 64 * 64) : d[i].K;
         const int tm = (d[i].M + 63) / 64;
         q.tiles_n = (d[i].N + 63) / 64;
         q.tiles_mn = tm * q.tiles_n;
         q.block0 = total;
-        total += q.tiles_mn;
+        q.part_off = off;
+        off += (((long)d[i].M * d[i].N + d[i].M) + 3) & ~3L;
+        total += q.tiles_mn * splits;
     }
     constexpr size_t lds = Smem<MODE_TN, 64, 64, 16>::TOTAL * sizeof(float);
     hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(256), lds, st, grp);
     GF_LAUNCH_CHECK();
+    if (splits > 1) {
+        hipLaunchKernelGGL(tn_reduce_grouped_kernel, dim3(16, n), dim3(256), 0, st, grp);
+        GF_LAUNCH_CHECK();
+    }
     return 0;
 }
 

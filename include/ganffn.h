@@ -266,9 +266,14 @@ int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const
 int ganffn_ffn_fused_bwd(const float* dy, const float* w1, const float* w2, const float* h, float* dh,
                          float* slabs, float* pack_ws, int T, int E, int F, float mscale, void* stream);
 /* n (<= 40) independent problems C_i[M_i x N_i] += At_i[K_i x M_i]^T B_i[K_i x N_i] (+ column sums) in ONE launch: the
- * deferred weight-gradient GEMMs of all encoder layers of a backward pass (dense leading dimensions) */
+ * deferred weight-gradient GEMMs of all encoder layers of a backward pass (dense leading dimensions).  workspace
+ * (ganffn_gemm_tn_grouped_workspace_floats() floats, or NULL): lets a group with few output tiles split the token range
+ * over several workgroups per tile (partial slabs + one ordered reduce launch; deterministic).  NULL: one owner
+ * workgroup per tile. */
+int64_t ganffn_gemm_tn_grouped_workspace_floats(void);
 int ganffn_gemm_tn_grouped(int n, const float* const* At, const float* const* Bm, float* const* C,
-                           float* const* colsum, const int* M, const int* N, const int* K, void* stream);
+                           float* const* colsum, const int* M, const int* N, const int* K, float* workspace,
+                           int64_t workspace_floats, void* stream);
 /* Attention core of nn.MultiheadAttention (call sites model.py:1210,1244,1276,1307,1340,1377):
  * qkv [T x 3E] -> o [T x E]; site = dropout site id; p = 0 disables dropout.  lse [B*H x S] receives the log-sum-exp of
  * every score row (may be NULL when no backward follows).  The backward takes the forward's o and lse back (head_dim

@@ -308,9 +308,11 @@ def test_ffn_fused_fwd_bwd(lib, T, p):
     assert rel_err(dx, dx_ref) < 3e-5
 
 
-def test_gemm_tn_grouped(lib):
-    """several weight-gradient GEMMs in one launch == each computed separately"""
-    probs = [(100, 2048, 330), (2048, 100, 330), (100, 100, 330), (300, 100, 330), (16, 64, 75), (512, 512, 128)]
+@pytest.mark.parametrize("use_ws", [False, True])
+def test_gemm_tn_grouped(lib, use_ws):
+    """several weight-gradient GEMMs in one launch == each computed separately; with a workspace the narrow group splits
+    its token ranges (problems of different K in one group: short ones get empty splits) and reduces in split order"""
+    probs = [(100, 2048, 3300), (2048, 100, 3300), (100, 100, 330), (300, 100, 3300), (16, 64, 75), (512, 512, 1280)]
     g = torch.Generator().manual_seed(5)
     At = [dev(torch.randn(k, m, generator=g)) for (m, n, k) in probs]
     Bm = [dev(torch.randn(k, n, generator=g)) for (m, n, k) in probs]
@@ -320,8 +322,16 @@ def test_gemm_tn_grouped(lib):
     n = len(probs)
     arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
     ints = lambda i: (C.c_int * n)(*[p[i] for p in probs])
-    lib.call("ganffn_gemm_tn_grouped", n, arr(At), arr(Bm), arr(Cd), arr(Sd), ints(0), ints(1), ints(2), stream())
+    nws = int(lib.load().ganffn_gemm_tn_grouped_workspace_floats())
+    ws = torch.full((nws,), float("nan"), device="cuda") if use_ws else None
+    lib.call("ganffn_gemm_tn_grouped", n, arr(At), arr(Bm), arr(Cd), arr(Sd), ints(0), ints(1), ints(2), ptr(ws), nws if use_ws else 0,
+             stream())
     for i, (m, nn, k) in enumerate(probs):
         ref = C0[i].double() + At[i].double().cpu().T @ Bm[i].double().cpu()
         assert rel_err(Cd[i], ref) < 3e-6 * max(1, k ** 0.5), probs[i]
         assert rel_err(Sd[i], At[i].double().cpu().sum(0)) < 3e-6 * max(1, k ** 0.5)
+    if use_ws:       # deterministic: a second run from the same inputs gives the same bits
+        Cd2 = [dev(c.clone()) for c in C0]
+        Sd2 = [torch.zeros(m, device="cuda") for (m, n, k) in probs]
+        lib.call("ganffn_gemm_tn_grouped", n, arr(At), arr(Bm), arr(Cd2), arr(Sd2), ints(0), ints(1), ints(2), ptr(ws), nws, stream())
+        assert all(torch.equal(a, b) for a, b in zip(Cd, Cd2)) and all(torch.equal(a, b) for a, b in zip(Sd, Sd2))
