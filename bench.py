@@ -510,9 +510,7 @@ def main():
                        "step_frac_of_fp32_mfma_peak": round(step_tflops * 1e12 / (FP32_MFMA_PEAK * world), 4),
                        "last_losses": {k: round(v, 4) for k, v in losses.items()}},
             "roofline": {"bound": "mfma", "kernel": "gemm_tn_grouped_kernel (all 32 weight-gradient GEMMs of one encoder backward pass in one "
-                                                     "launch, no atomics: one owner workgroup per output tile, or — narrow d_model-100 groups "
-                                                     "— the token range split in two with partial slabs and an ordered reduce launch, whose "
-                                                     "time is included); "
+                                                     "launch: one owner workgroup per output tile over the whole token range, no atomics); "
                                                      "%d launches per iteration; the (kernel, launch shape) with the largest share of GPU "
                                                      "time in the single-stream profile" % klaunch,
                          "achieved": round(kflop / kt / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",

@@ -53,9 +53,9 @@ struct HeadSrc16 {
 // Stage NM [S x HD] head slices into LDS images [16 NT rows][LD] (rows >= S and columns >= HD zero), in two phases so that
 // the caller can put data-independent work (the Philox calls) between issuing the global loads and waiting for them:
 // every global load of all matrices is issued (clamped addresses, masked by a select) before the first LDS write.
-template <int HD, int NT, int NM>
+template <int HD, int NT, int NM, int NW = NT>   // NW: waves of the workgroup doing the staging
 struct HeadStage {
-    static constexpr int LD = A16<HD>::LD, PR = LD / 2, ROWS = 16 * NT, PER = ROWS * PR, NTH = 64 * NT;
+    static constexpr int LD = A16<HD>::LD, PR = LD / 2, ROWS = 16 * NT, PER = ROWS * PR, NTH = 64 * NW;
     static constexpr int U = (PER + NTH - 1) / NTH;
     float2 v[NM][U];
     __device__ __forceinline__ void load(const HeadSrc16 (&m)[NM], int S, int B, int b, int tid) {
@@ -162,17 +162,22 @@ __device__ __forceinline__ void store4(float* __restrict__ row, int d0, const fl
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
-// forward: one workgroup per (dialogue, head); wave w owns queries 16w .. 16w+15
+// forward: one workgroup per (dialogue, head, block of WPB query tiles); a wave owns 16 queries.  WPB < NT cuts a
+// (dialogue, head) problem into NT / WPB workgroups that each stage the head's K and V again (a few KB out of L2) — the
+// 320 problems of a d_model-100 pass are 1.25 per CU as whole workgroups (64 CUs hold two), finer workgroups spread evenly
 // ------------------------------------------------------------------------------------------
-template <int HD, int NT>
-__global__ __launch_bounds__(64 * NT) void attn16_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+template <int HD, int NT, int WPB>
+__global__ __launch_bounds__(64 * WPB) void attn16_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                              float* __restrict__ lse, int S, int B, int E, int H, float p,
                                                              uint32_t site, const uint64_t* __restrict__ rng, uint64_t add,
                                                              int train) {
     constexpr int LD = A16<HD>::LD, NTD = A16<HD>::NTD, MAT = 16 * NT * LD + A16<HD>::TAIL;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
+    static_assert(NT % WPB == 0, "query tiles per workgroup must divide the tile count");
+    constexpr int NQB = NT / WPB;
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x / NQB, w = (blockIdx.x - bh * NQB) * WPB + (tid >> 6);     // w: query tile of this wave
+    const int b = bh / H, head = bh - b * H;
     float* Qs = smem;
     float* Ks = Qs + MAT;
     float* Vs = Ks + MAT;
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(64 * NT) void attn16_fwd_kernel(const float* __rest
     {
         const HeadSrc16 m3[3] = {{Qs, qkv + head * HD, ld3, rsqrtf((float)HD)}, {Ks, qkv + E + head * HD, ld3, 1.f},
                                  {Vs, qkv + 2 * E + head * HD, ld3, 1.f}};
-        HeadStage<HD, NT, 3> stg;
+        HeadStage<HD, NT, 3, WPB> stg;
         stg.load(m3, S, B, b, tid);
         if (dc.on) {
             // Dropout keep-bits, computed while the global loads are in flight (they depend on indices only).  One Philox
@@ -437,9 +442,18 @@ template <int HD, int NT>
 static int launch16_fwd(const float* qkv, float* o, float* lse, int S, int B, int E, int H, float p, uint32_t site,
                         const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
     const size_t lds = fwd_lds<HD>(NT);
-    GF_TRY((lds_optin<attn16_fwd_kernel<HD, NT>>(lds, "attention_fwd")));
-    hipLaunchKernelGGL((attn16_fwd_kernel<HD, NT>), dim3(B * H), dim3(64 * NT), lds, st, qkv, o, lse, S, B, E, H, p, site, rng,
-                       add, train);
+    // query tiles per workgroup: measured at hd = 10, S = 94 (tools/lab/attn_wpb.py, lab build): 320 problems 11.1 us as
+    // whole workgroups, 10.1 / 9.9 / 11.5 us cut in 2 / 3 / 6; 640 problems 15.0 us whole, 16.4 / 17.9 / 21.5 us cut —
+    // the cut pays while the problems do not fill the chip, then the repeated K / V staging costs more than the balance gains
+#define GF_A16_FWD(W)                                                                                               \
+    {                                                                                                               \
+        GF_TRY((lds_optin<attn16_fwd_kernel<HD, NT, W>>(lds, "attention_fwd")));                                    \
+        hipLaunchKernelGGL((attn16_fwd_kernel<HD, NT, W>), dim3(B * H * (NT / W)), dim3(64 * W), lds, st, qkv, o, lse, S, B, E, \
+                           H, p, site, rng, add, train);                                                            \
+    }
+    if ((long)B * H < 512 && NT % 2 == 0 && NT > 2) GF_A16_FWD((NT % 2 == 0 ? 2 : NT))
+    else GF_A16_FWD(NT)
+#undef GF_A16_FWD
     GF_LAUNCH_CHECK();
     return 0;
 }

@@ -988,6 +988,14 @@ int launch_gemm_tn_acc(const float* At, int lda, const float* Bm, int ldb, float
     return 0;
 }
 
+// A grouped launch with fewer than TN_GROUP_MIN_TILES output tiles (4 per CU) splits the token range of every tile so that
+// about TN_GROUP_TILES workgroups exist.  Measured at 1136 tiles (a whole d_model-100 backward pass, T = 6016): unsplit
+// 446 us; split in 3: 424 us + 20 us for the reduce launch — no gain, so such groups stay on the owner-only path; the
+// narrow groups this is for are the 1-4-layer gradient buckets of the data-parallel path (142-568 tiles).
+constexpr int TN_GROUP_MIN_TILES = 1024;
+constexpr int TN_GROUP_TILES = 2560;
+constexpr int TN_GROUP_MAXSPLIT = 8;
+
 // C_i += sum_z part[z][i], colsum_i += sum_z part[z][M N + i] for every problem of a split grouped launch, slabs in split
 // order; blockIdx.y = problem, blockIdx.x strides over its elements
 __global__ __launch_bounds__(256) void tn_reduce_grouped_kernel(TnGroup grp) {
@@ -995,14 +1003,18 @@ __global__ __launch_bounds__(256) void tn_reduce_grouped_kernel(TnGroup grp) {
     const float* part = grp.part + q.part_off;
     const long nC = (long)q.M * q.N;
     for (long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i4 < nC; i4 += (long)gridDim.x * 1024) {
-        float4 s = *reinterpret_cast<const float4*>(part + i4);
-        for (int z = 1; z < grp.splits; ++z) {
-            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)z * grp.part_stride + i4);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
+        float4 v[TN_GROUP_MAXSPLIT];                             // all slabs' loads in flight together
+#pragma unroll
+        for (int z = 0; z < TN_GROUP_MAXSPLIT; ++z)
+            v[z] = *reinterpret_cast<const float4*>(part + (size_t)min(z, grp.splits - 1) * grp.part_stride + i4);
         const long row = i4 / q.N, col = i4 - row * q.N;       // N % 4 == 0: a float4 stays inside one row
         float* dst = q.C + row * q.ldc + col;
-        dst[0] += s.x; dst[1] += s.y; dst[2] += s.z; dst[3] += s.w;
+        const float4 old = *reinterpret_cast<const float4*>(dst);
+        float4 s = v[0];
+#pragma unroll
+        for (int z = 1; z < TN_GROUP_MAXSPLIT; ++z)
+            if (z < grp.splits) { s.x += v[z].x; s.y += v[z].y; s.z += v[z].z; s.w += v[z].w; }
+        *reinterpret_cast<float4*>(dst) = make_float4(old.x + s.x, old.y + s.y, old.z + s.z, old.w + s.w);
     }
     if (q.colsum != nullptr)
         for (int i = blockIdx.x * 256 + threadIdx.x; i < q.M; i += gridDim.x * 256) {
@@ -1012,35 +1024,32 @@ __global__ __launch_bounds__(256) void tn_reduce_grouped_kernel(TnGroup grp) {
         }
 }
 
-// A grouped launch is "wide enough" at TN_GROUP_TILES workgroups (10 per CU: the slowest CU is then within a few % of the
-// average); below that the token range of every tile is split so that about that many workgroups exist.
-constexpr int TN_GROUP_TILES = 2560;
-constexpr int TN_GROUP_MAXSPLIT = 8;
 long gemm_tn_grouped_part_floats() { return (long)(TN_GROUP_TILES + 256) * (64 * 64 + 64) + 4 * MAXP; }
 
-// dW_i[M_i x N_i] += At_i^T B_i for n problems in one launch (see gemm_tn_grouped_kernel).  Wide groups (one encoder
-// backward pass at d_model 512: 6144 tiles): every output tile has one owner workgroup that runs the whole token range and
-// adds its result in place.  Narrow groups (d_model 100: 1136 tiles for 1280 resident workgroup slots, the busiest CU 5
-// tiles against an average of 4.4; a 2-layer gradient bucket: 284 tiles) with a workspace: the token range is split, the
-// partial tiles go to per-split slabs and one reduce launch adds them in split order.  Deterministic either way.
+// dW_i[M_i x N_i] += At_i^T B_i for n problems in one launch (see gemm_tn_grouped_kernel).  Groups of >= 1024 tiles (one
+// encoder backward pass: 6144 tiles at d_model 512, 1136 at 100): every output tile has one owner workgroup that runs the
+// whole token range and adds its result in place.  Narrower groups (a 2-layer gradient bucket: 284 tiles on 256 CUs) with
+// a workspace: the token range is split, the partial tiles go to per-split slabs and one reduce launch adds them in split
+// order.  Deterministic either way.
 int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws, long part_floats) {
     GF_CHECK_ARG(d && n >= 1 && n <= MAXP, "gemm_tn_grouped: n=%d out of [1,%d]", n, MAXP);
     TnGroup grp;
     grp.n = n;
     long tiles = 0, per_split = 0;
-    int kmin = 1 << 30;
+    int kmax = 0;
     for (int i = 0; i < n; ++i) {
         GF_TRY(check_common(d[i].At, d[i].lda, d[i].B, d[i].ldb, d[i].C, d[i].M, d[i].N, d[i].K));
         GF_CHECK_ARG((d[i].M & 3) == 0 && (d[i].N & 3) == 0, "gemm_tn_grouped: M, N must be multiples of 4");
         tiles += (long)((d[i].M + 63) / 64) * ((d[i].N + 63) / 64);
         per_split += (((long)d[i].M * d[i].N + d[i].M) + 3) & ~3L;
-        kmin = d[i].K < kmin ? d[i].K : kmin;
+        kmax = d[i].K > kmax ? d[i].K : kmax;
+        if (!aligned16(d[i].C) || (d[i].ldc & 3) != 0) part_ws = nullptr;     // the reduce adds 16-byte vectors in place
     }
     int splits = 1;
-    if (part_ws != nullptr && tiles < TN_GROUP_TILES) {
+    if (part_ws != nullptr && tiles < TN_GROUP_MIN_TILES) {
         splits = (int)((TN_GROUP_TILES + tiles - 1) / tiles);
         if (splits > TN_GROUP_MAXSPLIT) splits = TN_GROUP_MAXSPLIT;
-        if (splits > kmin / 256) splits = kmin / 256;             // at least 256 tokens per workgroup
+        if (splits > kmax / 256) splits = kmax / 256;             // >= 256 tokens per workgroup of the longest problem
         if ((long)splits * per_split > part_floats) splits = (int)(part_floats / per_split);
         if (splits < 2) splits = 1;
     }
@@ -1068,7 +1077,7 @@ int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st, float* part_w
     hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(256), lds, st, grp);
     GF_LAUNCH_CHECK();
     if (splits > 1) {
-        hipLaunchKernelGGL(tn_reduce_grouped_kernel, dim3(16, n), dim3(256), 0, st, grp);
+        hipLaunchKernelGGL(tn_reduce_grouped_kernel, dim3(64, n), dim3(256), 0, st, grp);
         GF_LAUNCH_CHECK();
     }
     return 0;

@@ -17,11 +17,8 @@ def timeit(fn, reps=50):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
 
-import ctypes
-raw = ctypes.CDLL(_lib.LIB_PATH) if hasattr(_lib,'LIB_PATH') else None
 rng = torch.tensor([3407, 0], dtype=torch.int64, device="cuda")
-for dbg in (0, 1, 2, 3):
-  lib.ganffn_lab_wres_dbg(dbg); print('dbg', dbg, '(1: no stores, 2: no MFMA)')
+for _once in (0,):
   for T in (3008, 6016):
       x, w1, b1 = torch.randn(T, 100, device="cuda"), torch.randn(2048, 100, device="cuda") * 0.1, torch.randn(2048, device="cuda") * 0.1
       h = torch.empty(T, 2048, device="cuda")
