@@ -458,6 +458,170 @@ __global__ __launch_bounds__(256) void drnn_party_grad_kernel(PartyAddArgs a) {
 // ------------------------------------------------------------------------------------------
 // layouts
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Emotion cell as ONE chain per dialogue (round 2).  e_t = drop(GRU_e(q_t[spk], e_{t-1})) takes q_t from the party cell
+// but feeds nothing back into the recurrence, so: (1) its input product GI_e = QN W_ih^T + b_ih for ALL steps is one
+// ordinary GEMM after the main loop; (2) what remains is a recurrence over e alone, independent per dialogue, with a
+// 300 x 100 recurrent weight — one 512-thread workgroup per (dialogue, direction) runs all S steps with that weight in
+// registers and no grid-level synchronisation.  The backward mirrors it (e chain first, then dQN for all steps as one
+// GEMM).  Replaces 4 launches per step (2 skinny products, 2 gate kernels) by 4 launches per call.  D_e <= 128.
+// ------------------------------------------------------------------------------------------
+constexpr int EC_MAXHE = 128;
+constexpr int EC_NT = 512;
+struct EchainDir {
+    const float* GI;          // [T x 3He] input pre-activations of all steps (b_ih included)
+    const float* whh;         // [3He x He]
+    const float* bhh;         // [3He]
+    float* E;                 // [(S+1) B x He], block 0 = zeros
+    float* R; float* Z; float* N; float* HN;      // [T x He] saved gates
+    uint32_t site;
+};
+struct EchainArgs {
+    EchainDir d[2];
+    int S, B, He;
+    float p; int train;
+    const uint64_t* rng; uint64_t add;
+};
+
+__global__ __launch_bounds__(EC_NT) void drnn_echain_fwd_kernel(EchainArgs a) {
+    const EchainDir& d = a.d[blockIdx.z];
+    const int b = blockIdx.x, tid = threadIdx.x, He = a.He, H3 = 3 * He;
+    __shared__ __attribute__((aligned(16))) float e_s[EC_MAXHE];
+    __shared__ float gh_s[3 * EC_MAXHE];
+    float w[EC_MAXHE];
+    float bj = 0.f;
+    if (tid < H3) {
+        bj = d.bhh[tid];
+#pragma unroll
+        for (int k = 0; k < EC_MAXHE; ++k) w[k] = k < He ? d.whh[(size_t)tid * He + k] : 0.f;
+    } else {
+#pragma unroll
+        for (int k = 0; k < EC_MAXHE; ++k) w[k] = 0.f;
+    }
+    if (tid < EC_MAXHE) e_s[tid] = 0.f;
+    const DropCtx dc = make_drop(a.rng, a.add, d.site, a.p, a.train);
+    // input pre-activations of the next 4 steps are always in flight (a step is ~1 us, an L2 / HBM round trip up to 2)
+    constexpr int PF = 4;
+    float gq[PF][3];
+    const int uu = min(tid, He - 1);
+    auto fetch = [&](int t, float (&g)[3]) __attribute__((always_inline)) {
+        const float* gi = d.GI + ((size_t)min(t, a.S - 1) * a.B + b) * H3;
+        g[0] = gi[uu]; g[1] = gi[He + uu]; g[2] = gi[2 * He + uu];
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) fetch(i, gq[i]);
+    for (int t = 0; t < a.S; ++t) {
+        const size_t row = (size_t)t * a.B + b;
+        const float gi0 = gq[0][0], gi1 = gq[0][1], gi2 = gq[0][2];
+#pragma unroll
+        for (int i = 0; i + 1 < PF; ++i) { gq[i][0] = gq[i + 1][0]; gq[i][1] = gq[i + 1][1]; gq[i][2] = gq[i + 1][2]; }
+        fetch(t + PF, gq[PF - 1]);
+        __syncthreads();                                   // e_s holds e_{t-1}
+        {
+            float acc = bj;
+#pragma unroll
+            for (int k4 = 0; k4 < EC_MAXHE / 4; ++k4) {
+                if (4 * k4 < He) {                         // uniform
+                    const float4 e4 = *reinterpret_cast<const float4*>(e_s + 4 * k4);
+                    acc += e4.x * w[4 * k4] + e4.y * w[4 * k4 + 1] + e4.z * w[4 * k4 + 2] + e4.w * w[4 * k4 + 3];
+                }
+            }
+            if (tid < H3) gh_s[tid] = acc;
+        }
+        __syncthreads();
+        if (tid < He) {
+            const float h = e_s[tid];
+            const float r = sigm(gi0 + gh_s[tid]);
+            const float z = sigm(gi1 + gh_s[He + tid]);
+            const float hn = gh_s[2 * He + tid];
+            const float n = tanhf(gi2 + r * hn);
+            float hnew = (1.0f - z) * n + z * h;
+            const size_t o = row * He + tid;
+            d.R[o] = r; d.Z[o] = z; d.N[o] = n; d.HN[o] = hn;
+            hnew *= drop_mult1(dc, (uint32_t)row, (uint32_t)He, (uint32_t)tid);
+            d.E[((size_t)(t + 1) * a.B + b) * He + tid] = hnew;
+            // (written after every thread has read e_s for this step's matvec: second barrier above)
+            e_s[tid] = hnew;
+        }
+    }
+}
+
+struct EchainBwdDir {
+    const float* d_e;         // [T x He] upstream gradient wrt every e_t
+    const float* whh;         // [3He x He]
+    const float* E;           // [(S+1) B x He]
+    const float* R; const float* Z; const float* N; const float* HN;
+    float* dGI; float* dGH;   // [T x 3He] gate gradients of all steps (kept for dQN and the weight gradients)
+    uint32_t site;
+};
+struct EchainBwdArgs {
+    EchainBwdDir d[2];
+    int S, B, He;
+    float p; int train;
+    const uint64_t* rng; uint64_t add;
+};
+
+__global__ __launch_bounds__(EC_NT) void drnn_echain_bwd_kernel(EchainBwdArgs a) {
+    const EchainBwdDir& d = a.d[blockIdx.z];
+    const int b = blockIdx.x, tid = threadIdx.x, He = a.He, H3 = 3 * He;
+    __shared__ float carry_s[EC_MAXHE];                   // gradient wrt e_t arriving from step t+1
+    __shared__ float dgh_s[3 * EC_MAXHE];
+    __shared__ float dir_s[EC_MAXHE];
+    __shared__ float part_s[4][EC_MAXHE];
+    // thread (k, part): column k of W_hh restricted to a quarter of its 3He rows
+    const int k = tid & (EC_MAXHE - 1), part = tid >> 7, jper = (H3 + 3) / 4, j0 = part * jper;
+    float wT[(3 * EC_MAXHE + 3) / 4];
+#pragma unroll
+    for (int i = 0; i < (3 * EC_MAXHE + 3) / 4; ++i) wT[i] = (k < He && i < jper && j0 + i < H3) ? d.whh[(size_t)(j0 + i) * He + k] : 0.f;
+    if (tid < EC_MAXHE) carry_s[tid] = 0.f;
+    const DropCtx dc = make_drop(a.rng, a.add, d.site, a.p, a.train);
+    // the saved gates / states / upstream gradients of the next 4 steps are always in flight
+    constexpr int PF = 4;
+    float sq[PF][6];
+    const int uu = min(tid, He - 1);
+    auto fetch = [&](int t, float (&v)[6]) __attribute__((always_inline)) {
+        const size_t o = ((size_t)max(t, 0) * a.B + b) * He + uu;
+        v[0] = d.R[o]; v[1] = d.Z[o]; v[2] = d.N[o]; v[3] = d.HN[o]; v[4] = d.E[o]; v[5] = d.d_e[o];
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) fetch(a.S - 1 - i, sq[i]);
+    for (int t = a.S - 1; t >= 0; --t) {
+        const size_t row = (size_t)t * a.B + b;
+        const float r = sq[0][0], z = sq[0][1], n = sq[0][2], hn = sq[0][3], h = sq[0][4], de = sq[0][5];
+#pragma unroll
+        for (int i = 0; i + 1 < PF; ++i)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) sq[i][q] = sq[i + 1][q];
+        fetch(t - PF, sq[PF - 1]);
+        __syncthreads();                                   // carry_s complete
+        if (tid < He) {
+            const float dout = carry_s[tid] + de;
+            const float dhn = dout * drop_mult1(dc, (uint32_t)row, (uint32_t)He, (uint32_t)tid);
+            const float dn = dhn * (1.0f - z);
+            const float dz = dhn * (h - n);
+            const float dnp = dn * (1.0f - n * n);
+            const float drp = dnp * hn * r * (1.0f - r);
+            const float dzp = dz * z * (1.0f - z);
+            float* gi = d.dGI + row * H3;
+            float* gh = d.dGH + row * H3;
+            gi[tid] = drp; gi[He + tid] = dzp; gi[2 * He + tid] = dnp;
+            gh[tid] = drp; gh[He + tid] = dzp; gh[2 * He + tid] = dnp * r;
+            dgh_s[tid] = drp; dgh_s[He + tid] = dzp; dgh_s[2 * He + tid] = dnp * r;
+            dir_s[tid] = dhn * z;
+        }
+        __syncthreads();
+        {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < (3 * EC_MAXHE + 3) / 4; ++i)
+                if (i < jper) acc += dgh_s[min(j0 + i, H3 - 1)] * wT[i];     // (rows beyond H3 carry zero weights)
+            part_s[part][k] = acc;
+        }
+        __syncthreads();
+        if (tid < He) carry_s[tid] = dir_s[tid] + ((part_s[0][tid] + part_s[1][tid]) + (part_s[2][tid] + part_s[3][tid]));
+    }
+}
+
 struct DrnnSaved {
     int64_t XG, XP, XA, G, Q, E, QS, CT, QN, Rg, Zg, Ng, HNg, Rp, Zp, Np, HNp, Re, Ze, Ne, HNe, total;
 };
@@ -476,7 +640,7 @@ static DrnnSaved drnn_saved(const ganffn_drnn_cfg* c) {
     return s;
 }
 struct DrnnWs {
-    int64_t GI, GH, dGIg, dGHg, dGIp, dGHp, dGIe, dGHe, dXA, dCT, dG, dQa, dQb, dEa, dEb, dQsel, dQSp, dQSg, dhdir, dQN, total;
+    int64_t GI, GH, dGIg, dGHg, dGIp, dGHp, dGIe, dGHe, dXA, dCT, dG, dQa, dQb, dEa, dEb, dQsel, dQSp, dQSg, dhdir, dQN, GIe, dQNall, total;
 };
 static DrnnWs drnn_ws(const ganffn_drnn_cfg* c) {
     DrnnWs w;
@@ -489,6 +653,7 @@ static DrnnWs drnn_ws(const ganffn_drnn_cfg* c) {
     w.dXA = take(T * H); w.dCT = take(B * H); w.dG = take(T1 * H);
     w.dQa = take(B * 2 * H); w.dQb = take(B * 2 * H); w.dEa = take(B * He); w.dEb = take(B * He);
     w.dQsel = take(B * H); w.dQSp = take(B * H); w.dQSg = take(B * H); w.dhdir = take(B * H); w.dQN = take(B * H);
+    w.GIe = take(T * 3 * He); w.dQNall = take(T * H);       // emotion chain: input pre-activations / dQN of all steps
     w.total = p;
     return w;
 }
@@ -562,6 +727,7 @@ extern "C" int ganffn_drnn_fwd(const ganffn_drnn_cfg* c, int ndir, const float* 
         GF_TRY(memset_f(alpha[z], (int64_t)B * S * S, st));
     }
     const dim3 gH((B * H + 255) / 256, 1, ndir), gHe((B * He + 255) / 256, 1, ndir);
+    const bool echain = He <= EC_MAXHE;          // emotion cell as one chain per dialogue after the main loop
     for (int t = 0; t < S; ++t) {
         const int64_t r0 = (int64_t)t * B, r1 = (int64_t)(t + 1) * B;
         SkinnyGroup sg;
@@ -607,6 +773,7 @@ extern "C" int ganffn_drnn_fwd(const ganffn_drnn_cfg* c, int ndir, const float* 
         }
         hipLaunchKernelGGL(gru_gate_fwd_kernel<1>, gH, dim3(256), 0, st, ga);
         GF_LAUNCH_CHECK();
+        if (echain) continue;
         // ---- emotion cell: GI = QN[t] Wih_e^T + bih_e ; GH = E[t] Whh_e^T + bhh_e
         for (int z = 0; z < ndir; ++z) {
             float* sv = saved[z]; float* ws = workspace[z];
@@ -622,6 +789,20 @@ extern "C" int ganffn_drnn_fwd(const ganffn_drnn_cfg* c, int ndir, const float* 
                               SITE_DRNN_E + 4u * z};
         }
         hipLaunchKernelGGL(gru_gate_fwd_kernel<0>, gHe, dim3(256), 0, st, ga);
+        GF_LAUNCH_CHECK();
+    }
+    if (echain) {
+        EchainArgs ea;
+        ea.S = S; ea.B = B; ea.He = He; ea.p = c->p; ea.train = c->train; ea.rng = rng; ea.add = add;
+        for (int z = 0; z < ndir; ++z) {
+            float* sv = saved[z]; float* ws = workspace[z];
+            EpiArgs e;
+            e.bias = prm[z].e_bih;                 // GI_e of every step: one GEMM over all T rows of q_t[spk]
+            GF_TRY(launch_gemm_nt(sv + so.QN, H, prm[z].e_wih, H, ws + wo.GIe, 3 * He, T, 3 * He, H, EPI_NONE, e, st));
+            ea.d[z] = EchainDir{ws + wo.GIe, prm[z].e_whh, prm[z].e_bhh, sv + so.E, sv + so.Re, sv + so.Ze, sv + so.Ne, sv + so.HNe,
+                                SITE_DRNN_E + 4u * z};
+        }
+        hipLaunchKernelGGL(drnn_echain_fwd_kernel, dim3(B, 1, ndir), dim3(EC_NT), 0, st, ea);
         GF_LAUNCH_CHECK();
     }
     for (int z = 0; z < ndir; ++z) {
@@ -655,6 +836,24 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
         GF_TRY(memset_f(ws + wo.dXA, (int64_t)B * H, st));          // step 0 has no attention: dXA[0] = 0
     }
     const dim3 gH((B * H + 255) / 256, 1, ndir), gHe((B * He + 255) / 256, 1, ndir);
+    const bool echain = He <= EC_MAXHE;
+    if (echain) {
+        // emotion chain first (it depends on nothing else): gate gradients of all steps, then dQN of all steps in one GEMM
+        EchainBwdArgs eb;
+        eb.S = S; eb.B = B; eb.He = He; eb.p = c->p; eb.train = c->train; eb.rng = rng; eb.add = add;
+        for (int z = 0; z < ndir; ++z) {
+            const float* sv = saved[z]; float* ws = workspace[z];
+            eb.d[z] = EchainBwdDir{d_e[z], prm[z].e_whh, sv + so.E, sv + so.Re, sv + so.Ze, sv + so.Ne, sv + so.HNe, ws + wo.dGIe,
+                                   ws + wo.dGHe, SITE_DRNN_E + 4u * z};
+        }
+        hipLaunchKernelGGL(drnn_echain_bwd_kernel, dim3(B, 1, ndir), dim3(EC_NT), 0, st, eb);
+        GF_LAUNCH_CHECK();
+        for (int z = 0; z < ndir; ++z) {
+            float* ws = workspace[z];
+            EpiArgs e0;
+            GF_TRY(launch_gemm_nn(ws + wo.dGIe, 3 * He, prm[z].e_wih, H, ws + wo.dQNall, H, T, H, 3 * He, EPI_NONE, e0, st));
+        }
+    }
     for (int t = S - 1; t >= 0; --t) {
         const int64_t r0 = (int64_t)t * B, r1 = (int64_t)(t + 1) * B;
         const bool even = ((S - 1 - t) & 1) == 0;            // ping-pong of the recurrent gradients
@@ -663,8 +862,9 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
         SkinnyGroup sg;
         GateBwdArgs gb;
         gb.B = B; gb.row0 = (int)r0; gb.p = c->p; gb.train = c->train; gb.rng = rng; gb.add = add;
-        // ---- emotion cell
+        // ---- emotion cell (per step only when the chain kernels do not apply)
         gb.H = He;
+        if (!echain) {
         for (int z = 0; z < ndir; ++z) {
             const float* sv = saved[z]; float* ws = workspace[z];
             gb.d[z] = GateBwdDir{ws + dEin, d_e[z] + r0 * He, sv + so.Re + r0 * He, sv + so.Ze + r0 * He, sv + so.Ne + r0 * He,
@@ -680,11 +880,12 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
             sg.p[2 * z + 1] = SkinnyProb{ws + wo.dGHe + r0 * 3 * He, 3 * He, prm[z].e_whh, He, ws + wo.dhdir, He, nullptr, nullptr, ws + dEout, He, B, He, 3 * He};
         }
         GF_TRY(launch_skinny(sg, 2 * ndir, true, st));
+        }
         // ---- party cell: gradient wrt Q[t+1][spk] = dQ[t+1][spk] + dQN (selected inside the gate kernel)
         gb.H = H;
         for (int z = 0; z < ndir; ++z) {
             const float* sv = saved[z]; float* ws = workspace[z];
-            gb.d[z] = GateBwdDir{ws + dQin, ws + wo.dQN, sv + so.Rp + r0 * H, sv + so.Zp + r0 * H, sv + so.Np + r0 * H, sv + so.HNp + r0 * H,
+            gb.d[z] = GateBwdDir{ws + dQin, echain ? ws + wo.dQNall + r0 * H : ws + wo.dQN, sv + so.Rp + r0 * H, sv + so.Zp + r0 * H, sv + so.Np + r0 * H, sv + so.HNp + r0 * H,
                                  sv + so.QS + r0 * H, ws + wo.dGIp + r0 * 3 * H, ws + wo.dGHp + r0 * 3 * H, ws + wo.dhdir, mval[z] + r0,
                                  spk[z] + r0, SITE_DRNN_P + 4u * z};
         }
