@@ -319,7 +319,7 @@ def run_drnn(args, dev, pg, rank, world):
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 10)):      # latency-sized kernels: the clocks need ~10 steps to settle (28.6 -> 20.2 ms)
         step()
     sync()
     t0 = time.perf_counter()
@@ -346,7 +346,7 @@ def run_drnn(args, dev, pg, rank, world):
                                    "6-class head, forward + MaskedNLLLoss + backward + Adam, batch=%d per GPU fp32 on "
                                    "%dxMI355X" % (B, world),
                        "dialogues_per_gpu": B, "seq_len": S, "parallelism": "dp%d" % world, "launch": "eager",
-                       "last_loss": round(float(loss), 4)},
+                       "last_loss": round(float(loss.detach()), 4)},
             "roofline": {"bound": "hbm", "kernel": "skinny_nn_kernel (backward of one recurrence step's gate products, both directions: "
                                                    "4 x ([B x 500] x [500 x 1500]); the kernel with the largest share of GPU time in "
                                                    "profiles/r02_drnn_by_launch_shape.txt)",
