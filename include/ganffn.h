@@ -15,9 +15,12 @@
  *    (train_IEMOCAP.py:142-147).
  *  - The caller owns EVERY buffer (inputs, outputs, saved-for-backward, workspace,
  *    parameter/gradient/optimizer-state slabs).  The library allocates nothing, creates no
- *    streams or events, and keeps no mutable state between calls except two caches that
- *    do not affect results: the thread-local last-error string and, per (kernel, device,
- *    host thread), the fact that hipFuncSetAttribute has opted a kernel in to > 48 KiB of LDS.
+ *    streams or events, and keeps no mutable state between calls except caches that do not
+ *    affect results — the thread-local last-error string and, per (kernel, device, host thread),
+ *    the facts that hipFuncSetAttribute has opted a kernel in to > 48 KiB of LDS and how many
+ *    workgroups of the persistent short-K GEMM the device holds at once — and ONE debug switch,
+ *    ganffn_debug_set_ffn_mode (default 0 = two GEMMs; 1 = the fused feed-forward kernel, which
+ *    gives the same results to rounding and measured slower).
  *  - Results are bit-reproducible: no kernel accumulates with floating-point atomics (weight
  *    gradients, bias gradients, LayerNorm gradients and loss sums are owner-computed or reduced
  *    in a fixed order), so two runs from the same state and RNG offset give identical bits.
