@@ -426,9 +426,14 @@ __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-bool attn16_supported(int E, int H) {
+// head_dim 10 / 30: always.  head_dim 60 / 64: short sequences only — measured against attention.hip (tools/lab/attn_big.py,
+// B = 32): S = 33, hd 60: forward 17.1 -> 9.6 us, backward 30.4 -> 19.4 us; S = 94, hd 64: forward 17.2 -> 36.9 us
+// (16 k-steps per score tile on 16-wide tiles), backward 34.1 -> 32.2 us.
+bool attn16_supported(int E, int H, int S) {
     const int hd = H > 0 ? E / H : 0;
-    return H > 0 && E % H == 0 && (hd == 10 || hd == 30);
+    if (!(H > 0 && E % H == 0)) return false;
+    if (hd == 10 || hd == 30) return true;
+    return (hd == 60 || hd == 64) && S <= 48;
 }
 
 template <int HD>
@@ -468,6 +473,12 @@ static int launch16_bwd(const float* qkv, const float* o, const float* lse, cons
     return 0;
 }
 
+#define NT16_SWITCH3(FN, HD, ...)                           \
+    switch ((S + 15) / 16) {                                \
+        case 1: return FN<HD, 1>(__VA_ARGS__);              \
+        case 2: return FN<HD, 2>(__VA_ARGS__);              \
+        default: return FN<HD, 3>(__VA_ARGS__);             \
+    }
 #define NT16_SWITCH(FN, HD, ...)                            \
     switch ((S + 15) / 16) {                                \
         case 1: return FN<HD, 1>(__VA_ARGS__);              \
@@ -481,17 +492,21 @@ static int launch16_bwd(const float* qkv, const float* o, const float* lse, cons
 
 int launch_attn16_fwd(const float* qkv, float* o, float* lse, int S, int B, int E, int H, float p, uint32_t site,
                       const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
-    GF_CHECK_ARG(attn16_supported(E, H) && S >= 1 && S <= GANFFN_MAX_SEQ, "attn16_fwd: unsupported E=%d H=%d S=%d", E, H, S);
+    GF_CHECK_ARG(attn16_supported(E, H, S) && S >= 1 && S <= GANFFN_MAX_SEQ, "attn16_fwd: unsupported E=%d H=%d S=%d", E, H, S);
     GF_CHECK_ARG((long)B * H * 28 * 128 < (1l << 32), "attention: B*H too large for the Philox counter");
+    if (E / H == 64) { NT16_SWITCH3(launch16_fwd, 64, qkv, o, lse, S, B, E, H, p, site, rng, add, train, st) }
+    if (E / H == 60) { NT16_SWITCH3(launch16_fwd, 60, qkv, o, lse, S, B, E, H, p, site, rng, add, train, st) }
     if (E / H == 10) { NT16_SWITCH(launch16_fwd, 10, qkv, o, lse, S, B, E, H, p, site, rng, add, train, st) }
     NT16_SWITCH(launch16_fwd, 30, qkv, o, lse, S, B, E, H, p, site, rng, add, train, st)
 }
 
 int launch_attn16_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv, int S, int B, int E,
                       int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
-    GF_CHECK_ARG(attn16_supported(E, H) && S >= 1 && S <= GANFFN_MAX_SEQ, "attn16_bwd: unsupported E=%d H=%d S=%d", E, H, S);
+    GF_CHECK_ARG(attn16_supported(E, H, S) && S >= 1 && S <= GANFFN_MAX_SEQ, "attn16_bwd: unsupported E=%d H=%d S=%d", E, H, S);
     GF_CHECK_ARG(o && lse, "attention_bwd: head_dim %d needs the forward's output and log-sum-exp", E / H);
     GF_CHECK_ARG((long)B * H * 28 * 128 < (1l << 32), "attention: B*H too large for the Philox counter");
+    if (E / H == 64) { NT16_SWITCH3(launch16_bwd, 64, qkv, o, lse, d_o, d_qkv, S, B, E, H, p, site, rng, add, train, st) }
+    if (E / H == 60) { NT16_SWITCH3(launch16_bwd, 60, qkv, o, lse, d_o, d_qkv, S, B, E, H, p, site, rng, add, train, st) }
     if (E / H == 10) { NT16_SWITCH(launch16_bwd, 10, qkv, o, lse, d_o, d_qkv, S, B, E, H, p, site, rng, add, train, st) }
     NT16_SWITCH(launch16_bwd, 30, qkv, o, lse, d_o, d_qkv, S, B, E, H, p, site, rng, add, train, st)
 }

@@ -245,7 +245,7 @@ int launch_attention_fwd(const float* qkv, float* o, float* lse, int S, int B, i
                          const uint64_t* rng, uint64_t add, int train, hipStream_t st);
 int launch_attention_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv, int S, int B,
                          int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st);
-bool attn16_supported(int E, int H);
+bool attn16_supported(int E, int H, int S);
 int launch_attn16_fwd(const float* qkv, float* o, float* lse, int S, int B, int E, int H, float p, uint32_t site,
                       const uint64_t* rng, uint64_t add, int train, hipStream_t st);
 int launch_attn16_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv, int S, int B, int E,

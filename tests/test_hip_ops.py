@@ -120,7 +120,9 @@ ATTN_CASES = [(7, 2, 100, 10), (110, 3, 100, 10), (94, 4, 512, 8), (33, 2, 100, 
               (32, 1, 100, 10), (96, 2, 100, 10), (97, 1, 512, 8), (16, 3, 100, 10), (17, 1, 100, 10), (94, 32, 100, 10),
               (80, 2, 100, 10), (49, 5, 100, 10),
               # MELD-dimension stacks (BASELINE.json configs[2]): text E = 600 (head_dim 60), audio E = 300 (head_dim 30)
-              (94, 2, 600, 10), (33, 3, 600, 10), (110, 2, 600, 10), (94, 3, 300, 10), (7, 2, 300, 10), (110, 2, 300, 10)]
+              (94, 2, 600, 10), (33, 3, 600, 10), (110, 2, 600, 10), (94, 3, 300, 10), (7, 2, 300, 10), (110, 2, 300, 10),
+              # head_dim 60 / 64 at S <= 48 run on the 16x16x4 kernels, longer sequences on attention.hip
+              (48, 2, 600, 10), (49, 2, 600, 10), (40, 3, 512, 8), (16, 2, 512, 8), (5, 1, 600, 10)]
 
 
 @pytest.mark.parametrize("S,B,E,H", ATTN_CASES)
