@@ -825,6 +825,9 @@ struct TnGroup {
     int splits;
 };
 
+// SPLIT = false: no partial-slab code in the kernel at all (with it the kernel needs 100 instead of 96 VGPRs = 4 instead
+// of 5 workgroups per CU, and the 1136-tile d_model-100 group no longer fits the chip in one round: 446 -> 470 us)
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
     // XCD-aware workgroup order: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (private
     // 4 MiB L2 each), so tiles that share an operand panel would all miss in different L2s (measured, rocprofv3
@@ -842,7 +845,7 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
     GemmArgs g;
     g.A = q.A; g.lda = q.lda; g.B = q.B; g.ldb = q.ldb; g.C = q.C; g.ldc = q.ldc; g.colsum = q.colsum;
     g.M = q.M; g.N = q.N; g.K = q.K; g.kchunk = q.kchunk; g.slab_stride = 0;
-    if (grp.part != nullptr) { g.part = grp.part + q.part_off; g.part_stride = grp.part_stride; }
+    if constexpr (SPLIT) { g.part = grp.part + q.part_off; g.part_stride = grp.part_stride; }
     // tiles in panels of 8 along N (n fastest inside a panel, then m, then the next panel): an XCD's contiguous
     // range of ~32 tiles is then a 4 x 8 patch — 12 operand panels instead of the 33 of a 1 x 32 strip
     constexpr int PW = 8;
@@ -1074,7 +1077,8 @@ int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st, float* part_w
         total += q.tiles_mn * splits;
     }
     constexpr size_t lds = Smem<MODE_TN, 64, 64, 16>::TOTAL * sizeof(float);
-    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(256), lds, st, grp);
+    if (splits > 1) hipLaunchKernelGGL(gemm_tn_grouped_kernel<true>, dim3(total), dim3(256), lds, st, grp);
+    else hipLaunchKernelGGL(gemm_tn_grouped_kernel<false>, dim3(total), dim3(256), lds, st, grp);
     GF_LAUNCH_CHECK();
     if (splits > 1) {
         hipLaunchKernelGGL(tn_reduce_grouped_kernel, dim3(64, n), dim3(256), 0, st, grp);
