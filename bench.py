@@ -292,7 +292,7 @@ def run_drnn(args, dev, pg, rank, world):
     w = torch.tensor([1.2, 0.60072, 0.38066, 0.94019, 0.67924, 0.34332], device=dev)      # train_IEMOCAP_DialogueRNN.py:738
     loss_fn = M.MaskedNLLLoss(w)
     params = [p for p in net.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-5)
+    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-5, fused=True)     # train_IEMOCAP_DialogueRNN.py:746
     if pg is not None:
         import torch.distributed as dist
         for p in params:
