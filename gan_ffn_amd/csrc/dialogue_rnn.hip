@@ -211,9 +211,7 @@ struct GateArgs {
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 template <int PARTY>
-__global__ __launch_bounds__(256) void gru_gate_fwd_kernel(GateArgs a) {
-    const GateDir& d = a.d[blockIdx.z];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void gru_gate_fwd_body(const GateArgs& a, const GateDir& d, const int idx) {
     if (idx >= a.B * a.H) return;
     const int b = idx / a.H, u = idx - b * a.H, H3 = 3 * a.H;
     const float* gi = d.GI + (size_t)b * H3;
@@ -241,6 +239,10 @@ __global__ __launch_bounds__(256) void gru_gate_fwd_kernel(GateArgs a) {
         if (d.spk_next) d.QSnext[idx] = d.spk_next[b] == s ? qs : other;
     }
 }
+template <int PARTY>
+__global__ __launch_bounds__(256) void gru_gate_fwd_kernel(GateArgs a) {
+    gru_gate_fwd_body<PARTY>(a, a.d[blockIdx.z], blockIdx.x * 256 + threadIdx.x);
+}
 
 struct GateBwdDir {
     const float* dh;        // [B x H] gradient wrt the cell output AFTER dropout (g / e cells) or wrt Q[t+1][spk] (party cell)
@@ -261,9 +263,7 @@ struct GateBwdArgs {
 };
 
 template <int PARTY>
-__global__ __launch_bounds__(256) void gru_gate_bwd_kernel(GateBwdArgs a) {
-    const GateBwdDir& d = a.d[blockIdx.z];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void gru_gate_bwd_body(const GateBwdArgs& a, const GateBwdDir& d, const int idx) {
     if (idx >= a.B * a.H) return;
     const int b = idx / a.H, u = idx - b * a.H, H3 = 3 * a.H;
     float dout = PARTY ? d.dh[((size_t)b * 2 + d.spk[b]) * a.H + u] : d.dh[idx];
@@ -287,6 +287,10 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(GateBwdArgs a) {
     gi[u] = drp; gi[a.H + u] = dzp; gi[2 * a.H + u] = dnp;
     gh[u] = drp; gh[a.H + u] = dzp; gh[2 * a.H + u] = dnp * r;
     d.dhdir[idx] = dhn * z + pass;
+}
+template <int PARTY>
+__global__ __launch_bounds__(256) void gru_gate_bwd_kernel(GateBwdArgs a) {
+    gru_gate_bwd_body<PARTY>(a, a.d[blockIdx.z], blockIdx.x * 256 + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -334,12 +338,11 @@ __device__ __forceinline__ void drnn_scores(const float* __restrict__ q, const f
     }
 }
 
-__global__ __launch_bounds__(DR_AT) void drnn_attn_fwd_kernel(AttnArgs a) {
+__device__ __forceinline__ void drnn_attn_fwd_body(const AttnArgs& a, const AttnDir& d, const int b) {
     __shared__ float sc[DR_MAXS + 16];
     __shared__ float red[2];
     __shared__ float part[512];
-    const AttnDir& d = a.d[blockIdx.z];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, t = a.t;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, t = a.t;
     drnn_scores(d.XA + (size_t)b * a.H, d.G, a.B, a.H, b, t, sc, lane, w);     // H <= 512 (checked on the host)
     __syncthreads();
     // softmax over t <= 112 scores: the first two waves
@@ -379,6 +382,16 @@ __global__ __launch_bounds__(DR_AT) void drnn_attn_fwd_kernel(AttnArgs a) {
     __syncthreads();
     if (!half && k < a.H) d.CT[(size_t)b * a.H + k] = c + part[k];
 }
+__global__ __launch_bounds__(DR_AT) void drnn_attn_fwd_kernel(AttnArgs a) { drnn_attn_fwd_body(a, a.d[blockIdx.z], blockIdx.x); }
+
+// One launch for two INDEPENDENT pieces of a step: the global cell's gate math (needs this step's skinny products) and
+// the context attention of the same step (needs only g_0 .. g_{t-1}).  Blocks [0, gate_blocks) run the gate body with
+// 1024 threads each, the rest one dialogue's attention each.
+struct GateAttnArgs { GateArgs g; AttnArgs at; int gate_blocks; };
+__global__ __launch_bounds__(DR_AT) void drnn_gate_attn_fwd_kernel(GateAttnArgs a) {
+    if ((int)blockIdx.x < a.gate_blocks) gru_gate_fwd_body<0>(a.g, a.g.d[blockIdx.z], blockIdx.x * DR_AT + threadIdx.x);
+    else drnn_attn_fwd_body(a.at, a.at.d[blockIdx.z], blockIdx.x - a.gate_blocks);
+}
 
 struct AttnBwdDir {
     const float* dCT;    // [B x H]
@@ -390,13 +403,12 @@ struct AttnBwdDir {
 };
 struct AttnBwdArgs { AttnBwdDir d[2]; int B, H, S, t; };
 
-__global__ __launch_bounds__(DR_AT) void drnn_attn_bwd_kernel(AttnBwdArgs a) {
+__device__ __forceinline__ void drnn_attn_bwd_body(const AttnBwdArgs& a, const AttnBwdDir& d, const int b) {
     __shared__ float da[DR_MAXS + 16];
     __shared__ float al[DR_MAXS + 16];
     __shared__ float red[2];
     __shared__ float part[512];
-    const AttnBwdDir& d = a.d[blockIdx.z];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, t = a.t;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, t = a.t;
     const float* dc = d.dCT + (size_t)b * a.H;
     drnn_scores(dc, d.G, a.B, a.H, b, t, da, lane, w);                 // d alpha_j = <dc, g_j>
     if (tid < t) al[tid] = d.alpha[((size_t)b * a.S + t) * a.S + tid];
@@ -437,6 +449,15 @@ __global__ __launch_bounds__(DR_AT) void drnn_attn_bwd_kernel(AttnBwdArgs a) {
     if (half) part[k] = dx;
     __syncthreads();
     if (!half && k < a.H) d.dXA[(size_t)b * a.H + k] = dx + part[k];
+}
+__global__ __launch_bounds__(DR_AT) void drnn_attn_bwd_kernel(AttnBwdArgs a) { drnn_attn_bwd_body(a, a.d[blockIdx.z], blockIdx.x); }
+
+// backward counterpart of drnn_gate_attn_fwd_kernel: the attention backward of step t (adds into dG rows <= t, writes
+// dXA[t]) and the global cell's gate backward of the same step (reads dG row t+1 and the saved gates) touch disjoint data
+struct GateAttnBwdArgs { GateBwdArgs g; AttnBwdArgs at; int gate_blocks; };
+__global__ __launch_bounds__(DR_AT) void drnn_gate_attn_bwd_kernel(GateAttnBwdArgs a) {
+    if ((int)blockIdx.x < a.gate_blocks) gru_gate_bwd_body<0>(a.g, a.g.d[blockIdx.z], blockIdx.x * DR_AT + threadIdx.x);
+    else drnn_attn_bwd_body(a.at, a.at.d[blockIdx.z], blockIdx.x - a.gate_blocks);
 }
 
 // out[b][s][:] (+)= in[b][:] into party s = spk[b] of a [B x 2 x H] tensor; the other party is copied from `other`
@@ -746,15 +767,18 @@ extern "C" int ganffn_drnn_fwd(const ganffn_drnn_cfg* c, int ndir, const float* 
                               sv + so.HNg + r0 * H, sv + so.G + r1 * H, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                               SITE_DRNN_G + 4u * z};
         }
-        hipLaunchKernelGGL(gru_gate_fwd_kernel<0>, gH, dim3(256), 0, st, ga);
-        GF_LAUNCH_CHECK();
-        // ---- context attention over g_0 .. g_{t-1}
+        // ---- ... together with the context attention over g_0 .. g_{t-1} (independent of this step's global cell)
         if (t > 0) {
-            AttnArgs aa;
-            aa.B = B; aa.H = H; aa.S = S; aa.t = t;
+            GateAttnArgs gaa;
+            gaa.g = ga;
+            gaa.at.B = B; gaa.at.H = H; gaa.at.S = S; gaa.at.t = t;
             for (int z = 0; z < ndir; ++z)
-                aa.d[z] = AttnDir{saved[z] + so.XA + r0 * H, saved[z] + so.G, saved[z] + so.CT + r0 * H, alpha[z]};
-            hipLaunchKernelGGL(drnn_attn_fwd_kernel, dim3(B, 1, ndir), dim3(DR_AT), 0, st, aa);
+                gaa.at.d[z] = AttnDir{saved[z] + so.XA + r0 * H, saved[z] + so.G, saved[z] + so.CT + r0 * H, alpha[z]};
+            gaa.gate_blocks = (B * H + DR_AT - 1) / DR_AT;
+            hipLaunchKernelGGL(drnn_gate_attn_fwd_kernel, dim3(gaa.gate_blocks + B, 1, ndir), dim3(DR_AT), 0, st, gaa);
+            GF_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL(gru_gate_fwd_kernel<0>, gH, dim3(256), 0, st, ga);
             GF_LAUNCH_CHECK();
         }
         // ---- party cell (speaker): GI = XP[t] + CT[t] Wih_p[:, Dm:]^T ; GH = QS[t] Whh_p^T + bhh_p
@@ -898,25 +922,28 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
             sg.p[2 * z + 1] = SkinnyProb{ws + wo.dGHp + r0 * 3 * H, 3 * H, prm[z].p_whh, H, ws + wo.dhdir, H, nullptr, nullptr, ws + wo.dQSp, H, B, H, 3 * H};
         }
         GF_TRY(launch_skinny(sg, 2 * ndir, true, st));
-        // ---- attention
-        if (t > 0) {
-            AttnBwdArgs ab;
-            ab.B = B; ab.H = H; ab.S = S; ab.t = t;
-            for (int z = 0; z < ndir; ++z)
-                ab.d[z] = AttnBwdDir{workspace[z] + wo.dCT, saved[z] + so.XA + r0 * H, saved[z] + so.G, alpha[z], workspace[z] + wo.dG,
-                                     workspace[z] + wo.dXA + r0 * H};
-            hipLaunchKernelGGL(drnn_attn_bwd_kernel, dim3(B, 1, ndir), dim3(DR_AT), 0, st, ab);
-            GF_LAUNCH_CHECK();
-        }
-        // ---- global cell: dg_t = dG[t+1] (attention uses at later steps + the recurrent path, both already added)
+        // ---- attention backward + global cell gate backward: dg_t = dG[t+1] (attention uses at later steps + the recurrent
+        // path, both already added); one launch, the two touch disjoint data
         for (int z = 0; z < ndir; ++z) {
             const float* sv = saved[z]; float* ws = workspace[z];
             gb.d[z] = GateBwdDir{ws + wo.dG + r1 * H, nullptr, sv + so.Rg + r0 * H, sv + so.Zg + r0 * H, sv + so.Ng + r0 * H, sv + so.HNg + r0 * H,
                                  sv + so.G + r0 * H, ws + wo.dGIg + r0 * 3 * H, ws + wo.dGHg + r0 * 3 * H, ws + wo.dhdir, nullptr,
                                  nullptr, SITE_DRNN_G + 4u * z};
         }
-        hipLaunchKernelGGL(gru_gate_bwd_kernel<0>, gH, dim3(256), 0, st, gb);
-        GF_LAUNCH_CHECK();
+        if (t > 0) {
+            GateAttnBwdArgs gab;
+            gab.g = gb;
+            gab.at.B = B; gab.at.H = H; gab.at.S = S; gab.at.t = t;
+            for (int z = 0; z < ndir; ++z)
+                gab.at.d[z] = AttnBwdDir{workspace[z] + wo.dCT, saved[z] + so.XA + r0 * H, saved[z] + so.G, alpha[z], workspace[z] + wo.dG,
+                                         workspace[z] + wo.dXA + r0 * H};
+            gab.gate_blocks = (B * H + DR_AT - 1) / DR_AT;
+            hipLaunchKernelGGL(drnn_gate_attn_bwd_kernel, dim3(gab.gate_blocks + B, 1, ndir), dim3(DR_AT), 0, st, gab);
+            GF_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL(gru_gate_bwd_kernel<0>, gH, dim3(256), 0, st, gb);
+            GF_LAUNCH_CHECK();
+        }
         for (int z = 0; z < ndir; ++z) {
             float* ws = workspace[z];
             // dQS_g = dGI_g Wih_g[:, Dm:] ; dG[t] += dGH_g Whh_g + dhdir (in place: second addend = the output block itself)
