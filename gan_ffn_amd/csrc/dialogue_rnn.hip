@@ -254,6 +254,10 @@ struct GateBwdDir {
     const float* mval;      // party cell: [B]
     const int* spk;         // party cell: [B]; dh is then the [B x 2 x H] gradient wrt Q[t+1], read at party spk[b]
     uint32_t site;
+    // party cell, optional: the previous (later-in-time) step's party-gradient assembly done here instead of in its own
+    // launch — dQ[t+1][b][p] = p == spk_{t+1}[b] ? dQSp + dQSg : dQ[t+2][b][p]; written to pg_out (= dh) and used directly
+    const float* pg_dQ = nullptr; const float* pg_dQSp = nullptr; const float* pg_dQSg = nullptr; const int* pg_spk = nullptr;
+    float* pg_out = nullptr;
 };
 struct GateBwdArgs {
     GateBwdDir d[2];
@@ -266,7 +270,19 @@ template <int PARTY>
 __device__ __forceinline__ void gru_gate_bwd_body(const GateBwdArgs& a, const GateBwdDir& d, const int idx) {
     if (idx >= a.B * a.H) return;
     const int b = idx / a.H, u = idx - b * a.H, H3 = 3 * a.H;
-    float dout = PARTY ? d.dh[((size_t)b * 2 + d.spk[b]) * a.H + u] : d.dh[idx];
+    float dout;
+    if (PARTY && d.pg_out != nullptr) {
+        const int sn = d.pg_spk[b];
+        const size_t o0 = ((size_t)b * 2) * a.H + u, o1 = o0 + a.H;
+        const float own = d.pg_dQSp[idx] + d.pg_dQSg[idx];
+        const float v0 = sn == 0 ? own : d.pg_dQ[o0];
+        const float v1 = sn == 1 ? own : d.pg_dQ[o1];
+        d.pg_out[o0] = v0;
+        d.pg_out[o1] = v1;
+        dout = d.spk[b] ? v1 : v0;
+    } else {
+        dout = PARTY ? d.dh[((size_t)b * 2 + d.spk[b]) * a.H + u] : d.dh[idx];
+    }
     if (d.dh2) dout += d.dh2[idx];
     float pass = 0.f;
     if (PARTY) {
@@ -912,6 +928,12 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
             gb.d[z] = GateBwdDir{ws + dQin, echain ? ws + wo.dQNall + r0 * H : ws + wo.dQN, sv + so.Rp + r0 * H, sv + so.Zp + r0 * H, sv + so.Np + r0 * H, sv + so.HNp + r0 * H,
                                  sv + so.QS + r0 * H, ws + wo.dGIp + r0 * 3 * H, ws + wo.dGHp + r0 * 3 * H, ws + wo.dhdir, mval[z] + r0,
                                  spk[z] + r0, SITE_DRNN_P + 4u * z};
+            if (t < S - 1) {      // assemble dQ[t+1] here (the previous iteration's party-gradient launch is gone)
+                const bool even1 = ((S - 2 - t) & 1) == 0;
+                gb.d[z].pg_dQ = ws + (even1 ? wo.dQa : wo.dQb);
+                gb.d[z].pg_out = ws + dQin;
+                gb.d[z].pg_dQSp = ws + wo.dQSp; gb.d[z].pg_dQSg = ws + wo.dQSg; gb.d[z].pg_spk = spk[z] + r1;
+            }
         }
         hipLaunchKernelGGL(gru_gate_bwd_kernel<1>, gH, dim3(256), 0, st, gb);
         GF_LAUNCH_CHECK();
@@ -952,15 +974,6 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
                                          ws + wo.dG + r0 * H, H, B, H, 3 * H};
         }
         GF_TRY(launch_skinny(sg, 2 * ndir, true, st));
-        // ---- gradient wrt Q[t]
-        PartyAddArgs pa;
-        pa.B = B; pa.H = H;
-        for (int z = 0; z < ndir; ++z) {
-            float* ws = workspace[z];
-            pa.dQ[z] = ws + dQin; pa.dQSp[z] = ws + wo.dQSp; pa.dQSg[z] = ws + wo.dQSg; pa.dQout[z] = ws + dQout; pa.spk[z] = spk[z] + r0;
-        }
-        hipLaunchKernelGGL(drnn_party_grad_kernel, gH, dim3(256), 0, st, pa);
-        GF_LAUNCH_CHECK();
     }
     // ---- dU and the deferred weight gradients (all steps at once)
     for (int z = 0; z < ndir; ++z) {
