@@ -13,21 +13,21 @@ pytestmark = pytest.mark.gpu
 DIMS = dict(D_m=100, D_g=500, D_p=500, D_e=100)
 
 
-def make_inputs(S, B, seed):
+def make_inputs(S, B, seed, Dm=100):
     g = torch.Generator().manual_seed(seed)
     lens = torch.randint(max(1, S // 3), S + 1, (B,), generator=g)
     lens[0] = S
     valid = (torch.arange(S).unsqueeze(1) < lens.unsqueeze(0)).float()            # (S, B)
-    U = (torch.rand(S, B, 100, generator=g) - 0.3) * valid.unsqueeze(2)
+    U = (torch.rand(S, B, Dm, generator=g) - 0.3) * valid.unsqueeze(2)
     spk = torch.randint(0, 2, (S, B), generator=g)
     qmask = torch.nn.functional.one_hot(spk, 2).float() * valid.unsqueeze(2)
     return U, qmask
 
 
-def build(seed=7, dropout=0.1):
+def build(seed=7, dropout=0.1, dims=None):
     from gan_ffn_amd import dialogue_rnn as DR
     torch.manual_seed(seed)
-    m = DR.DialogueRNN(context_attention="general", listener_state=False, dropout=dropout, **DIMS)
+    m = DR.DialogueRNN(context_attention="general", listener_state=False, dropout=dropout, **(dims or DIMS))
     with torch.no_grad():                       # livelier recurrent weights than the default init
         for p in m.parameters():
             p.mul_(1.5)
@@ -215,3 +215,18 @@ def test_composite_train_mode_step_matches_cpu_bimodel_on_the_same_fusion_and_ma
     pc = dict(cpu.named_parameters())
     for k, p in net.bi_model.named_parameters():
         assert rel(p.grad, pc[k].grad) < 1e-3, k
+
+
+@pytest.mark.parametrize("dims", [dict(D_m=52, D_g=128, D_p=128, D_e=128), dict(D_m=100, D_g=256, D_p=256, D_e=36),
+                                  dict(D_m=20, D_g=64, D_p=64, D_e=4)])
+def test_other_widths_match_torch_restatement(dims):
+    """the kernels are not specialised to the (100, 500, 500, 100) widths of configuration 5: emotion chain at its largest
+    (D_e = 128) and smallest width, short K ranges in the skinny products"""
+    import copy
+    S, B = 11, 5
+    U, qmask = make_inputs(S, B, seed=dims["D_e"], Dm=dims["D_m"])
+    m_cpu = build(dims=dims).double().eval()
+    m_gpu = copy.deepcopy(m_cpu).float().cuda().eval()
+    from gan_ffn_amd import ops
+    assert ops.dialogue_rnn_supported(m_gpu.dialogue_cell, U.cuda(), qmask.cuda())
+    compare(m_gpu, m_cpu, U, qmask)
