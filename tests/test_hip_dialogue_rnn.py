@@ -64,7 +64,7 @@ def test_one_training_step_updates_generators_and_head():
     assert moved["fc1.weight"] == 0           # present on the object, unused by forward (as in the reference)
 
 
-@pytest.mark.parametrize("S,B,D", [(7, 3, 200), (94, 30, 200), (128, 2, 256), (1, 1, 4)])
+@pytest.mark.parametrize("S,B,D", [(7, 3, 200), (94, 30, 200), (128, 2, 256), (1, 1, 4), (5, 2, 50), (112, 2, 600), (33, 3, 600)])
 def test_general2_attention_kernel_vs_fp64_torch(S, B, D):
     """HIP kernel (fwd + bwd) against the torch restatement of model.py:169-182,193 in fp64"""
     from gan_ffn_amd import dialogue_rnn as DR, ops
