@@ -12,15 +12,20 @@
 // Why not one kernel per dialogue: a step needs every cell's full weight matrix (12.7 MB per direction); one workgroup
 // per dialogue would stream that through ONE CU 94 times.  Instead the dialogues are the N axis (<= 32 per tile) of
 // skinny matrix products that spread a cell's weight rows over ~100-200 workgroups, and the S steps are a chain of small
-// launches (7 per step, both directions of BiModel in the same launches):
+// launches (4 per step forward, 4 backward, both directions of BiModel in the same launches; independent pieces of a step
+// share a launch: the global cell's gate math with the step's context attention, the party-gradient assembly with the
+// next step's party gate kernel):
 //   * everything that depends on U alone is hoisted out of the recurrence into three ordinary GEMMs over all steps
 //     (x-parts of the g / p cells incl. b_ih, and the attention query W_a U_t);
 //   * skinny_nt / skinny_nn: C[B x N] = A[B x K] W^T resp. A W on v_mfma_f32_16x16x4_f32 (exact fp32): a workgroup owns
 //     16 weight rows (columns) and all dialogues, its waves split K and are summed through LDS in a fixed order;
 //   * gate kernels (elementwise GRU math + Philox dropout + party select/update), attention kernels (one workgroup
 //     per dialogue, history in L2);
+//   * the emotion cell feeds nothing back into the recurrence: its input product for all steps is one GEMM after the
+//     main loop and its own recurrence (independent per dialogue, 300 x 100 weight) runs as one persistent workgroup per
+//     (dialogue, direction) — drnn_echain_fwd / bwd_kernel;
 //   * backward mirrors it step by step in reverse; all weight gradients are deferred: the per-step gate gradients are
-//     kept and ONE grouped TN GEMM launch (gemm.hip, owner-accumulated, no atomics) computes the 12 products at the end.
+//     kept and ONE grouped TN GEMM launch (gemm.hip, owner-accumulated, no atomics) computes the 9 products at the end.
 // Everything is deterministic (no atomics).  Dropout follows the Philox contract of common.h with rows t*B + b.
 #include "common.h"
 

@@ -20,6 +20,12 @@
 // k = kk + 4h + j on lane half h), which is all an MFMA needs.
 // Global->LDS staging goes through a register prefetch queue (2-4 tiles deep) into two LDS stages: the loads of tile
 // t+PD are issued before the MFMAs of tile t, tile t+1 is written to the other stage after them; one barrier per K tile.
+// Full tiles are loaded without any per-tile masking or address arithmetic (loop-invariant per-thread offsets from a
+// uniform base pointer); the K tail is one zero-filled tile loaded up front — fp32 MFMAs share the SIMD's vector ALU, so
+// every VALU instruction in the K loop costs MFMA time (tools/lab/mfma_valu.hip).
+// Besides the generic kernel: gemm_wres_kernel (K = 100 -> N >= 1024: persistent workgroups, weight fragments resident in
+// registers, same k order and bits as the generic kernel) and gemm_tn_grouped_kernel (all weight-gradient problems of a
+// backward pass in one XCD-aware launch).
 #include "common.h"
 
 #include <type_traits>
