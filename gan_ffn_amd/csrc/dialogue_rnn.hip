@@ -481,25 +481,6 @@ __global__ __launch_bounds__(DR_AT) void drnn_gate_attn_bwd_kernel(GateAttnBwdAr
     else drnn_attn_bwd_body(a.at, a.at.d[blockIdx.z], blockIdx.x - a.gate_blocks);
 }
 
-// out[b][s][:] (+)= in[b][:] into party s = spk[b] of a [B x 2 x H] tensor; the other party is copied from `other`
-struct PartyAddArgs {
-    const float* dQ[2];       // [B x 2 x H] gradient wrt Q[t+1]
-    const float* dQSp[2];     // [B x H] gradient wrt Q[t][spk] from the party cell (h path + direct)
-    const float* dQSg[2];     // [B x H] gradient wrt Q[t][spk] from the global cell's x path
-    float* dQout[2];          // [B x 2 x H] gradient wrt Q[t]
-    const int* spk[2];
-    int B, H;
-};
-__global__ __launch_bounds__(256) void drnn_party_grad_kernel(PartyAddArgs a) {
-    const int z = blockIdx.z, idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.B * a.H) return;
-    const int b = idx / a.H, u = idx - b * a.H, s = a.spk[z][b];
-    a.dQout[z][((size_t)b * 2 + s) * a.H + u] = a.dQSp[z][idx] + a.dQSg[z][idx];
-    a.dQout[z][((size_t)b * 2 + (1 - s)) * a.H + u] = a.dQ[z][((size_t)b * 2 + (1 - s)) * a.H + u];
-}
-// ------------------------------------------------------------------------------------------
-// layouts
-// ------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------
 // Emotion cell as ONE chain per dialogue (round 2).  e_t = drop(GRU_e(q_t[spk], e_{t-1})) takes q_t from the party cell
 // but feeds nothing back into the recurrence, so: (1) its input product GI_e = QN W_ih^T + b_ih for ALL steps is one
@@ -664,6 +645,9 @@ __global__ __launch_bounds__(EC_NT) void drnn_echain_bwd_kernel(EchainBwdArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// layouts of the saved-for-backward block and of the workspace (floats; every region 16-byte aligned)
+// ------------------------------------------------------------------------------------------
 struct DrnnSaved {
     int64_t XG, XP, XA, G, Q, E, QS, CT, QN, Rg, Zg, Ng, HNg, Rp, Zp, Np, HNp, Re, Ze, Ne, HNe, total;
 };
@@ -902,7 +886,7 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
     for (int t = S - 1; t >= 0; --t) {
         const int64_t r0 = (int64_t)t * B, r1 = (int64_t)(t + 1) * B;
         const bool even = ((S - 1 - t) & 1) == 0;            // ping-pong of the recurrent gradients
-        const int64_t dQin = even ? wo.dQa : wo.dQb, dQout = even ? wo.dQb : wo.dQa;
+        const int64_t dQin = even ? wo.dQa : wo.dQb;      // gradient wrt Q[t+1] (assembled by the party gate kernel below)
         const int64_t dEin = even ? wo.dEa : wo.dEb, dEout = even ? wo.dEb : wo.dEa;
         SkinnyGroup sg;
         GateBwdArgs gb;
