@@ -107,6 +107,19 @@ static int64_t a4(int64_t n) { return (n + 3) & ~int64_t(3); }
 // per LayerNorm backward launch: per-block partial sums of the weight / bias gradient
 static int64_t ln_part_floats(const ganffn_enc_cfg* c) { return (int64_t)ln_bwd_blocks(c->S * c->B) * 2 * c->E; }
 
+// K splits of the in-proj dgrad [T x 3E] x [3E x E]: its T/64 x E/64 output tiles are far fewer than the chip's workgroup
+// slots (94 at d_model 100, T = 3008), so K is cut into ~128-wide chunks (at most 8) whose partial outputs the consuming
+// LayerNorm backward adds in order
+static int inproj_dgrad_splits(int T, int E) {
+    const long tiles = (long)((T + 63) / 64) * ((E + 63) / 64);
+    if (tiles >= 768) return 1;
+    long s = (768 + tiles - 1) / tiles;
+    const long maxs = (3L * E) / 128;
+    if (s > maxs) s = maxs;
+    if (s > 8) s = 8;
+    return s < 1 ? 1 : (int)s;
+}
+
 static int64_t enc_ws_floats(const ganffn_enc_cfg* c) {
     const int64_t T = (int64_t)c->S * c->B, TE = T * c->E, TF = T * c->F;
     // L x (dh | dyA dyB d_qkv(3)) | dz2 dz1 d_attn | tmp slabs | L x 2 LayerNorm partial-sum blocks
@@ -273,6 +286,8 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
     float* r_gw[2 * 64]; float* r_gb[2 * 64]; const float* r_part[2 * 64]; int r_nb[2 * 64];
     int nred = 0;
 
+    const float* dxin = dx;       // gradient wrt the current layer's output: the caller's dx, then in-proj dgrad slabs
+    int dxin_slabs = 1;
     for (int l = layer_hi - 1; l >= layer_lo; --l) {
         const float* P = params + (int64_t)l * lo.total;
         float* G = grads ? grads + (int64_t)l * lo.total : nullptr;
@@ -287,10 +302,11 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
         float* lnp2 = lnp0 + (int64_t)(2 * (l - layer_lo)) * LNP;
         float* lnp1 = lnp2 + LNP;
         EpiArgs none;
-        // LN2 backward: dx = dL/dX[l+1] -> dz2 (to x1), dyA (to FFN output)
-        GF_TRY(launch_add_drop_ln_bwd(dx, sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dyA, G ? G + lo.n2w : nullptr,
-                                      G ? G + lo.n2b : nullptr, T, E, c->p_enc, site + 3, rng, add, train, st, 1, 0, nullptr,
-                                      G ? lnp2 : nullptr));
+        // LN2 backward: dL/dX[l+1] -> dz2 (to x1), dyA (to FFN output).  dL/dX[l+1] is the caller's dx for the top layer
+        // of the range and otherwise the in-proj dgrad of the layer above: split-K partial slabs in `tmp`, summed here
+        GF_TRY(launch_add_drop_ln_bwd(dxin, sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dyA, G ? G + lo.n2w : nullptr,
+                                      G ? G + lo.n2b : nullptr, T, E, c->p_enc, site + 3, rng, add, train, st, dxin_slabs, TE,
+                                      nullptr, G ? lnp2 : nullptr));
         if (G) { r_gw[nred] = G + lo.n2w; r_gb[nred] = G + lo.n2b; r_part[nred] = lnp2; r_nb[nred] = lnblk; ++nred; }
         // linear2 wgrad: gW2[E,F] += dyA^T h ; gb2 += colsum(dyA)
         if (G) tn[ntn++] = TnDesc{dyA, E, sv + so.h, F, G + lo.w2, F, G + lo.b2, E, F, T};
@@ -329,8 +345,17 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
             ntn = 0;
         }
         EpiArgs eadd;
-        eadd.aux_in = dz1;            // dX[l] = d_qkv W_in + dz1 (residual) in the GEMM epilogue
-        GF_TRY(launch_gemm_nn(d_qkv, 3 * E, P + lo.in_w, E, dx, E, T, E, 3 * E, EPI_NONE, eadd, st));
+        eadd.aux_in = dz1;            // dX[l] = d_qkv W_in + dz1 (residual, added by split 0) in the GEMM epilogue
+        if (l > layer_lo) {
+            // few output tiles (T/64 x E/64): split K into slabs that the next layer's LN2 backward sums on the fly
+            // (`tmp` is free here: its previous content, this layer's dh W1 slabs, went into the LN1 backward above)
+            int sp = inproj_dgrad_splits(T, E);
+            GF_TRY(launch_gemm_nn(d_qkv, 3 * E, P + lo.in_w, E, tmp, E, T, E, 3 * E, EPI_NONE, eadd, st, &sp, TE));
+            dxin = tmp;
+            dxin_slabs = sp;
+        } else {
+            GF_TRY(launch_gemm_nn(d_qkv, 3 * E, P + lo.in_w, E, dx, E, T, E, 3 * E, EPI_NONE, eadd, st));
+        }
     }
     if (nred > 0) GF_TRY(launch_ln_param_reduce(nred, r_gw, r_gb, r_part, r_nb, E, st));
     if (layer_lo == 0) GF_TRY(launch_dropout_bwd_inplace(dx, T, E, c->p_pe, SITE_PE, rng, add, train, st));
