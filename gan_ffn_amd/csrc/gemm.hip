@@ -916,16 +916,9 @@ __global__ __launch_bounds__(256, 5) void gemm_tn_grouped_kernel(TnGroup grp) { 
         if (b >= grp.p[i].block0) pi = i;
     const TnProblem& q = grp.p[pi];
     const int local = b - q.block0;
-    const int bz = local / q.tiles_mn;
-    int t2 = local - bz * q.tiles_mn;
-    // A CU receives every 32nd workgroup of its XCD's range, so with the plain order it would see only one kind of tile
-    // (e.g. only the n0 = 64 tiles of a [2048 x 100] gradient, whose last quadrant column is a cheap strip — see
-    // gemm_body): rotate the order inside every complete block of 32 tiles by 9 x its block index (a bijection), which
-    // alternates both the n tile of two-column problems and the m tile of two-row problems from block to block, and
-    // alternate the wave roles every second block so that the strip waves visit all four SIMDs of a CU.
-    const int blk = t2 >> 5;
-    if ((blk + 1) * 32 <= q.tiles_mn) t2 = (blk << 5) + ((t2 + 9 * blk) & 31);
-    const int swz = (blk >> 1) & 1;
+    const int bz = local / q.tiles_mn, t2 = local - bz * q.tiles_mn;
+    const int swz = 0;   // (rotating the tile order so that every CU sees the same mix of full and strip tiles was measured:
+                         //  -1 % time, +25 % L2-miss traffic — the pairs of tiles sharing an operand panel drift apart; not kept)
     GemmArgs g;
     g.A = q.A; g.lda = q.lda; g.B = q.B; g.ldb = q.ldb; g.C = q.C; g.ldc = q.ldc; g.colsum = q.colsum;
     g.M = q.M; g.N = q.N; g.K = q.K; g.kchunk = q.kchunk; g.slab_stride = 0;
