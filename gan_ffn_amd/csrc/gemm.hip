@@ -382,7 +382,7 @@ __device__ __forceinline__ void gemm_store_epilogue(const GemmArgs& g, floatx16 
 }
 
 template <int MODE, int BM, int BN, int BK, int EPI, int WGM, int WGN>
-__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz, const int swz = 0) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz) {
     constexpr int NTH = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN;  // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -391,10 +391,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    // TN: which wave of a workgroup takes which quadrant alternates with the tile position, so that the light "strip"
-    // waves (below) of neighbouring tiles land on different SIMDs
-    const int wm = (MODE == MODE_TN) ? ((wave / WGN) ^ ((bx ^ swz) & (WGM - 1) & 1)) : wave / WGN;
-    const int wn = (MODE == MODE_TN) ? ((wave % WGN) ^ ((by ^ swz) & (WGN - 1) & 1)) : wave % WGN;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int r = lane & 31, h = lane >> 5;
     const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = min(bz * g.kchunk, g.K);   // (a split beyond a short problem's range computes and stores zeros)
@@ -524,44 +521,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
                     }
     };
 
-    // TN only — "strip" quadrants.  A weight-gradient dimension of 100 (every d_model-100 problem has one) ends in a 32-wide
-    // quadrant with 4 valid columns (or rows): 28 of its 32 MFMA columns would be padding.  Such a wave runs
-    // v_mfma_f32_4x4x1_16B_f32 instead (16 independent 4 x 4 outer products per instruction = a 64 x 4 strip at the full fp32
-    // rate, 8 cycles instead of 64; layout and rate: tools/lab/mfma_4x4.hip): blocks 0-7 (lanes 0-31) take the k's of lane
-    // half 0, blocks 8-15 those of half 1, exactly the k split of the 32x32x2 fragments, so the A (strip of columns) or B
-    // (strip of rows) fragment is the ordinary one and the two halves are added once in the epilogue.
-    //   mode 1, 0 < N - nbase <= 4: C[mbase + 4 (b & 7) + i][nbase + j] in lane 4 b + j, register i
-    //   mode 2, 0 < M - mbase <= 4: C[mbase + i][nbase + (lane & 31)]   in register i
-    typedef float floatx4s __attribute__((ext_vector_type(4)));
-    floatx4s accs = {0.f, 0.f, 0.f, 0.f};
-    int strip = 0;
-    if constexpr (MODE == MODE_TN && TM == 1 && TN == 1) {
-        const int left_n = g.N - (n0 + wn * WN), left_m = g.M - (m0 + wm * WM);
-        strip = (left_n > 0 && left_n <= 4) ? 1 : ((left_m > 0 && left_m <= 4) ? 2 : 0);
-    }
-    auto compute_strip_n = [&](int buf) __attribute__((always_inline)) {
-        const float* sa = smem + buf * SM::STAGE;
-        const float* sb = sa + SM::A_FLOATS;
-#pragma unroll
-        for (int gk = 0; gk < BK / 8; ++gk)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = 8 * gk + 4 * h + j;
-                accs = __builtin_amdgcn_mfma_f32_4x4x1f32(sa[k * (BM + 4) + wm * WM + r], sb[k * (BN + 4) + wn * WN + (lane & 3)], accs, 0, 0, 0);
-            }
-    };
-    auto compute_strip_m = [&](int buf) __attribute__((always_inline)) {
-        const float* sa = smem + buf * SM::STAGE;
-        const float* sb = sa + SM::A_FLOATS;
-#pragma unroll
-        for (int gk = 0; gk < BK / 8; ++gk)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = 8 * gk + 4 * h + j;
-                accs = __builtin_amdgcn_mfma_f32_4x4x1f32(sa[k * (BM + 4) + wm * WM + (lane & 3)], sb[k * (BN + 4) + wn * WN + r], accs, 0, 0, 0);
-            }
-    };
-
     // prologue: the tail tile and PD full tiles in flight, tile 0 to LDS
     {
         const int k0 = kbeg + nfull * BK;      // >= kend when there is no tail: the masked loaders then produce zeros
@@ -587,37 +546,26 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     // Steady state, iteration t: issue the global loads of tile t+PD, run tile t from LDS stage t&1, write tile t+1
     // (loaded PD-1 iterations ago) to the other stage, barrier.  The step body is straight-line code; the only branches
     // are the wave-uniform "is there a tile t" around a whole step and "is tile t+1 the tail" around its LDS stores.
-#define GF_STEP(U, UN, COMPUTE)                                                         \
+#define GF_STEP(U, UN)                                                                  \
     if (t0 + U < nt) {                                                                  \
         GF_GLOAD(U, t0 + U + PD)                                /* slot U is free */    \
-        COMPUTE(U & 1);                                                                 \
+        compute(U & 1);                                                                 \
         /* tile t+1 -> LDS: from the queue while it is a full tile, the tail tile right after the last full one */ \
         if (t0 + U + 1 == nfull) sstore_tail((U + 1) & 1);      /* wave-uniform; LDS stores only */ \
         else if (t0 + U + 1 < nfull) GF_SSTORE_FULL(UN, (U + 1) & 1)   /* (nothing beyond the last tile) */ \
         __syncthreads();                                                                \
     }
-#define GF_KLOOP(COMPUTE)                                                               \
-    for (int t0 = 0; t0 < nt; t0 += PD) {                                               \
-        if constexpr (PD == 2) {                                                        \
-            GF_STEP(0, 1, COMPUTE)                                                      \
-            GF_STEP(1, 0, COMPUTE)                                                      \
-        } else {                                                                        \
-            GF_STEP(0, 1, COMPUTE)                                                      \
-            GF_STEP(1, 2, COMPUTE)                                                      \
-            GF_STEP(2, 3, COMPUTE)                                                      \
-            GF_STEP(3, 0, COMPUTE)                                                      \
-        }                                                                               \
+    for (int t0 = 0; t0 < nt; t0 += PD) {
+        if constexpr (PD == 2) {
+            GF_STEP(0, 1)
+            GF_STEP(1, 0)
+        } else {
+            GF_STEP(0, 1)
+            GF_STEP(1, 2)
+            GF_STEP(2, 3)
+            GF_STEP(3, 0)
+        }
     }
-    // (the three loops run the same number of barriers: every wave of a workgroup walks the same K tiles; the MFMA kind
-    // is chosen per WAVE outside the loop so that no accumulator crosses a control-flow merge inside it)
-    if constexpr (MODE == MODE_TN && TM == 1 && TN == 1) {
-        if (strip == 1) { GF_KLOOP(compute_strip_n) }
-        else if (strip == 2) { GF_KLOOP(compute_strip_m) }
-        else { GF_KLOOP(compute) }
-    } else {
-        GF_KLOOP(compute)
-    }
-#undef GF_KLOOP
 #undef GF_STEP
 #undef GF_GLOAD
 #undef GF_SSTORE_FULL
@@ -628,23 +576,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
         // (the gradient slab is accumulated into, +=); split, it stores a partial slab that tn_reduce_kernel sums
         // in split order.  Either way the result does not depend on the order workgroups run in.
         float* const slab = g.part ? g.part + (size_t)bz * g.part_stride : nullptr;
-        if (strip != 0) {
-            // strip quadrant: the two lane halves hold the two k halves of the same 32 x 4 (or 4 x 32) outputs
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = accs[i] + __shfl_xor(accs[i], 32, 64);
-            if (h == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = m0 + wm * WM + (strip == 1 ? 4 * (r >> 2) + i : i);
-                    const int col = n0 + wn * WN + (strip == 1 ? (r & 3) : r);
-                    if (row < g.M && col < g.N) {
-                        if (slab) slab[(size_t)row * g.N + col] = v[i];
-                        else g.C[(size_t)row * g.ldc + col] += v[i];
-                    }
-                }
-            }
-        } else
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -903,7 +834,7 @@ struct TnGroup {
 // SPLIT = false: no partial-slab code in the kernel at all (with it the kernel needs 100 instead of 96 VGPRs = 4 instead
 // of 5 workgroups per CU, and the 1136-tile d_model-100 group no longer fits the chip in one round: 446 -> 470 us)
 template <bool SPLIT>
-__global__ __launch_bounds__(256, 5) void gemm_tn_grouped_kernel(TnGroup grp) {   // 5 workgroups per CU: <= 96 VGPRs
+__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
     // XCD-aware workgroup order: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (private
     // 4 MiB L2 each), so tiles that share an operand panel would all miss in different L2s (measured, rocprofv3
     // FETCH_SIZE: 3x the compulsory bytes on the d=512 launches).  Bijective remap (also when gridDim % 8 != 0): the
@@ -917,8 +848,6 @@ __global__ __launch_bounds__(256, 5) void gemm_tn_grouped_kernel(TnGroup grp) { 
     const TnProblem& q = grp.p[pi];
     const int local = b - q.block0;
     const int bz = local / q.tiles_mn, t2 = local - bz * q.tiles_mn;
-    const int swz = 0;   // (rotating the tile order so that every CU sees the same mix of full and strip tiles was measured:
-                         //  -1 % time, +25 % L2-miss traffic — the pairs of tiles sharing an operand panel drift apart; not kept)
     GemmArgs g;
     g.A = q.A; g.lda = q.lda; g.B = q.B; g.ldb = q.ldb; g.C = q.C; g.ldc = q.ldc; g.colsum = q.colsum;
     g.M = q.M; g.N = q.N; g.K = q.K; g.kchunk = q.kchunk; g.slab_stride = 0;
@@ -930,7 +859,7 @@ __global__ __launch_bounds__(256, 5) void gemm_tn_grouped_kernel(TnGroup grp) { 
     const int panel = t2 / (PW * tiles_m), rem = t2 - panel * PW * tiles_m;
     const int pw = min(PW, q.tiles_n - panel * PW);
     const int mt = rem / pw, nt = panel * PW + rem - mt * pw;
-    gemm_body<MODE_TN, 64, 64, 16, EPI_NONE, 2, 2>(g, nt, mt, bz, swz);
+    gemm_body<MODE_TN, 64, 64, 16, EPI_NONE, 2, 2>(g, nt, mt, bz);
 }
 
 template <int MODE, int BM, int BN, int BK, int EPI, int WGM = 2, int WGN = 2, int SHORTK = 0>
