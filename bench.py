@@ -319,7 +319,7 @@ def run_drnn(args, dev, pg, rank, world):
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 25)):      # latency-sized kernels: the clocks need a few hundred ms of load to settle (a cold run reads 23-35 ms)
+    for _ in range(max(args.warmup, 60)):      # latency-sized kernels: the clocks need about a second of load to settle (a cold run reads 23-35 ms)
         step()
     sync()
     t0 = time.perf_counter()
