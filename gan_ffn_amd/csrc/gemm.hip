@@ -416,11 +416,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     const int nt = nfull + (((kend - kbeg) % BK) ? 1 : 0);
     // One float4 of each operand per thread and tile (64 x 16 floats / 256 threads); the queue slots are plain named
     // vectors (arrays / structs of slots indexed by the unrolled step were left in scratch memory by hipcc).
-    static_assert(BM * BK / 4 == NTH && BN * BK / 4 == NTH, "queue code assumes one vector per thread, operand and tile");
-    float4 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
+    static_assert(BM * BK / 4 == NTH && (BN * BK / 4 == NTH || BN * BK / 4 == 2 * NTH),
+                  "queue code: one A vector and one or two B vectors per thread and tile");
+    constexpr bool B2 = BN * BK / 4 == 2 * NTH;          // BN = 128: a second B vector per thread (qc*)
+    float4 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3, qc0, qc1, qc2, qc3;
     // per-thread element offset inside a tile's rows (clamped at the matrix edge) and LDS slot, loop-invariant
-    uint32_t offa, offb;
-    int ldsa, ldsb;
+    uint32_t offa, offb, offc = 0;
+    int ldsa, ldsb, ldsc = 0;
     if constexpr (MODE == MODE_TN) {          // K-major: tile row = k, thread covers columns 4 * (tid % (BM/4)) ..
         const int kr = tid / (BM / 4), c4 = (tid % (BM / 4)) << 2;
         offa = (uint32_t)kr * (uint32_t)g.lda + (uint32_t)max(min(m0 + c4, g.M - 4), 0);
@@ -434,12 +436,22 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
         const int row = tid / (BK / 4), sl = tid % (BK / 4);
         offb = (uint32_t)min(n0 + row, g.N - 1) * (uint32_t)g.ldb + (uint32_t)(sl << 2);
         ldsb = kc_off<BK>(row, sl);
+        if constexpr (B2) {                   // second vector: tile rows NTH / (BK/4) further down
+            constexpr int R2 = NTH / (BK / 4);
+            offc = (uint32_t)min(n0 + row + R2, g.N - 1) * (uint32_t)g.ldb + (uint32_t)(sl << 2);
+            ldsc = kc_off<BK>(row + R2, sl);
+        }
     } else {
         const int kr = tid / (BN / 4), c4 = (tid % (BN / 4)) << 2;
         offb = (uint32_t)kr * (uint32_t)g.ldb + (uint32_t)max(min(n0 + c4, g.N - 4), 0);
         ldsb = kr * (BN + 4) + c4;
+        if constexpr (B2) {                   // second vector: k rows NTH / (BN/4) further down, same columns
+            constexpr int K2 = NTH / (BN / 4);
+            offc = offb + (uint32_t)K2 * (uint32_t)g.ldb;
+            ldsc = ldsb + K2 * (BN + 4);
+        }
     }
-    if (nfull == 0) offa = offb = 0;          // K range shorter than one tile: the (never consumed) queue loads read element 0
+    if (nfull == 0) offa = offb = offc = 0;   // K range shorter than one tile: the (never consumed) queue loads read element 0
     KcTile<BM, BK, NTH> tail_a_kc; KmTile<BM, BK, NTH> tail_a_km;      // the K-tail tile (all zeros when there is none)
     KcTile<BN, BK, NTH> tail_b_kc; KmTile<BN, BK, NTH> tail_b_km;
 
@@ -454,12 +466,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
         const int k0 = kbeg + max(min((T), nfull - 1), 0) * BK;        /* uniform: scalar ALU */         \
         qa##U = *reinterpret_cast<const float4*>(g.A + (size_t)k0 * kstride_a + offa);                   \
         qb##U = *reinterpret_cast<const float4*>(g.B + (size_t)k0 * kstride_b + offb);                   \
+        if constexpr (B2) qc##U = *reinterpret_cast<const float4*>(g.B + (size_t)k0 * kstride_b + offc); \
     }
 #define GF_SSTORE_FULL(U, BUF)                                                                           \
     {                                                                                                    \
         float* const sa = smem + (BUF) * SM::STAGE;                                                      \
         *reinterpret_cast<float4*>(sa + ldsa) = qa##U;                                                   \
         *reinterpret_cast<float4*>(sa + SM::A_FLOATS + ldsb) = qb##U;                                    \
+        if constexpr (B2) *reinterpret_cast<float4*>(sa + SM::A_FLOATS + ldsc) = qc##U;                  \
         if (want_colsum) { colsum4.x += qa##U.x; colsum4.y += qa##U.y; colsum4.z += qa##U.z; colsum4.w += qa##U.w; } \
     }
     auto sstore_tail = [&](int buf) __attribute__((always_inline)) {
@@ -833,7 +847,7 @@ struct TnGroup {
 
 // SPLIT = false: no partial-slab code in the kernel at all (with it the kernel needs 100 instead of 96 VGPRs = 4 instead
 // of 5 workgroups per CU, and the 1136-tile d_model-100 group no longer fits the chip in one round: 446 -> 470 us)
-template <bool SPLIT>
+template <bool SPLIT, int BN = 64>
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
     // XCD-aware workgroup order: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (private
     // 4 MiB L2 each), so tiles that share an operand panel would all miss in different L2s (measured, rocprofv3
@@ -859,7 +873,7 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup grp) {
     const int panel = t2 / (PW * tiles_m), rem = t2 - panel * PW * tiles_m;
     const int pw = min(PW, q.tiles_n - panel * PW);
     const int mt = rem / pw, nt = panel * PW + rem - mt * pw;
-    gemm_body<MODE_TN, 64, 64, 16, EPI_NONE, 2, 2>(g, nt, mt, bz);
+    gemm_body<MODE_TN, 64, BN, 16, EPI_NONE, 2, 2>(g, nt, mt, bz);
 }
 
 template <int MODE, int BM, int BN, int BK, int EPI, int WGM = 2, int WGN = 2, int SHORTK = 0>
@@ -1044,12 +1058,24 @@ int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st, float* part_w
     GF_CHECK_ARG(d && n >= 1 && n <= MAXP, "gemm_tn_grouped: n=%d out of [1,%d]", n, MAXP);
     TnGroup grp;
     grp.n = n;
+    // 64 x 128 tiles (two accumulators per wave sharing the A fragment: the single-accumulator MFMA chain of the 64 x 64
+    // tile is issue-limited) when every problem's N is a multiple of 128 and the group keeps >= 4 such tiles per CU.
+    // Measured (tools/lab/tn_wide.py, same bits): the d_model-512 group 1270 -> 1212 us; the d_model-100 group would drop
+    // to 568 tiles (N = 100 -> one 128-wide tile) and gets slower (543 -> 639 us), so it stays on 64 x 64.
+    bool wide = true;
+    long wtiles = 0;
+    for (int i = 0; i < n; ++i) {
+        wide = wide && (d[i].N % 128 == 0);
+        wtiles += (long)((d[i].M + 63) / 64) * ((d[i].N + 127) / 128);
+    }
+    wide = wide && wtiles >= TN_GROUP_MIN_TILES;
+    const int BNs = wide ? 128 : 64;
     long tiles = 0, per_split = 0;
     int kmax = 0;
     for (int i = 0; i < n; ++i) {
         GF_TRY(check_common(d[i].At, d[i].lda, d[i].B, d[i].ldb, d[i].C, d[i].M, d[i].N, d[i].K));
         GF_CHECK_ARG((d[i].M & 3) == 0 && (d[i].N & 3) == 0, "gemm_tn_grouped: M, N must be multiples of 4");
-        tiles += (long)((d[i].M + 63) / 64) * ((d[i].N + 63) / 64);
+        tiles += (long)((d[i].M + 63) / 64) * ((d[i].N + BNs - 1) / BNs);
         per_split += (((long)d[i].M * d[i].N + d[i].M) + 3) & ~3L;
         kmax = d[i].K > kmax ? d[i].K : kmax;
         if (!aligned16(d[i].C) || (d[i].ldc & 3) != 0) part_ws = nullptr;     // the reduce adds 16-byte vectors in place
@@ -1075,12 +1101,18 @@ int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st, float* part_w
         // chunk: a multiple of 64 tokens; problems with different K in one group simply get fewer non-empty splits
         q.kchunk = splits > 1 ? (int)((((long)d[i].K + splits - 1) / splits + 63) / 64 * 64) : d[i].K;
         const int tm = (d[i].M + 63) / 64;
-        q.tiles_n = (d[i].N + 63) / 64;
+        q.tiles_n = (d[i].N + BNs - 1) / BNs;
         q.tiles_mn = tm * q.tiles_n;
         q.block0 = total;
         q.part_off = off;
         off += (((long)d[i].M * d[i].N + d[i].M) + 3) & ~3L;
         total += q.tiles_mn * splits;
+    }
+    if (wide && splits == 1) {
+        constexpr size_t ldsw = Smem<MODE_TN, 64, 128, 16>::TOTAL * sizeof(float);
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<false, 128>), dim3(total), dim3(256), ldsw, st, grp);
+        GF_LAUNCH_CHECK();
+        return 0;
     }
     constexpr size_t lds = Smem<MODE_TN, 64, 64, 16>::TOTAL * sizeof(float);
     if (splits > 1) hipLaunchKernelGGL(gemm_tn_grouped_kernel<true>, dim3(total), dim3(256), lds, st, grp);
