@@ -55,8 +55,8 @@ def flops_per_token(S, config="iemocap"):
 
 def wgrad_groups(S, B, config="iemocap"):
     """The dominant kernel `gemm_tn_grouped_kernel` = the deferred weight-gradient GEMMs of one encoder backward pass
-    (8 layers x {linear2, linear1, out_proj, in_proj}: dW[M x N] += dY^T[M x K] X[K x N], K = tokens, split-K + fp32
-    atomics, bias gradients folded in) in one launch.  One iteration issues 6 launches for the discriminators' batched
+    (8 layers x {linear2, linear1, out_proj, in_proj}: dW[M x N] += dY^T[M x K] X[K x N], K = tokens; one owner workgroup
+    per output tile over the whole token range adds in place — no atomics —, bias gradients folded in) in one launch.  One iteration issues 6 launches for the discriminators' batched
     [real | fake] pass (2B dialogues, d=100), 4 for the 100-d generators and 2 for the 512-d generator.
     Returns [(launches per iteration, [(M, N, K)] x 32)]."""
     T1, T2 = S * B, S * 2 * B
@@ -319,7 +319,8 @@ def run_drnn(args, dev, pg, rank, world):
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 60)):      # latency-sized kernels: the clocks need about a second of load to settle (a cold run reads 23-35 ms)
+    n_warm = max(args.warmup, 60)
+    for _ in range(n_warm):      # latency-sized kernels: the clocks need about a second of load to settle (a cold run reads 23-35 ms)
         step()
     sync()
     t0 = time.perf_counter()
@@ -338,7 +339,7 @@ def run_drnn(args, dev, pg, rank, world):
         kt, kbytes = time_skinny_kernel(B)
         print(json.dumps({
             "metric": "utterances/sec per phase-2 train step, IEMOCAP GAN-FFN + DialogueRNN", "value": round(utts * args.steps / dt, 2),
-            "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": n_warm,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "IEMOCAP GAN-FFN + DialogueRNN (BASELINE.json configs[4]): 3 generators -> bidirectional "
@@ -359,8 +360,8 @@ def run_drnn(args, dev, pg, rank, world):
 
 
 def host_threads():
-    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota (a 1-GPU box
-    exposes many cores but grants a 16-core share)."""
+    """CPU threads this process may really use: the affinity mask, capped by the cgroup CPU quota (a 1-GPU box exposes
+    many cores but grants a share of them).  GANFFN_CPU_THREADS overrides (no built-in cap)."""
     n = os.cpu_count() or 1
     try:
         n = len(os.sched_getaffinity(0))
@@ -372,7 +373,9 @@ def host_threads():
             n = min(n, max(1, int(float(q) / float(per) + 0.5)))
     except Exception:
         pass
-    return max(1, min(n, int(os.environ.get("GANFFN_CPU_THREADS", "16"))))
+    if os.environ.get("GANFFN_CPU_THREADS"):
+        n = int(os.environ["GANFFN_CPU_THREADS"])
+    return max(1, n)
 
 
 def main():
@@ -539,6 +542,7 @@ def main():
                        "committed rocprofv3 summary " + IN_STEP_FILE}
         if world == 1 and not args.no_cpu_baseline:
             threads = host_threads()
+            print("[bench] cpu_baseline on %d host threads (affinity / cgroup share)" % threads, file=sys.stderr, flush=True)
             cv, cdt, cutts = cpu_baseline(S, args.cpu_sample_batch, threads, config=cfgname)
             out["cpu_baseline"] = {"value": round(cv, 2), "unit": "utterances/s", "cores": threads, "kind": "port",
                                    "sample": "1 full %d-sub-step iteration, stock PyTorch CPU nn.TransformerEncoder "
@@ -552,7 +556,7 @@ def main():
             out["cpu_baseline"]["dropout_free_seconds"] = round(cdt0, 1)
             out["config"]["gpu_over_cpu_dropout_free"] = round(value / cv0, 1)
             if threads > 8:       # an 8-thread figure, comparable with the survey's 8-core measurement
-                cv8, cdt8, _ = cpu_baseline(S, max(4, args.cpu_sample_batch // 2), 8, config=cfgname)
+                cv8, cdt8, _ = cpu_baseline(S, args.cpu_sample_batch, 8, config=cfgname)      # the same sample as `value`
                 out["cpu_baseline"]["value_8_threads"] = round(cv8, 2)
                 out["cpu_baseline"]["seconds_8_threads"] = round(cdt8, 1)
         print(json.dumps(out), flush=True)

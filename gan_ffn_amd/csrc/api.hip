@@ -542,8 +542,7 @@ extern "C" int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float
                                     const uint64_t* rng, uint64_t add, int train, void* stream) {
     GF_CHECK_ARG(w1 && w2 && pack_ws && ffn_fused_supported(E, F), "ffn_fused_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    // w1 / w2 are separate tensors here: pack them as a one-layer "slab" addressed relative to w1
-    GF_TRY(launch_ffn_pack(w1, 0, 0, (long)(w2 - w1), pack_ws, 1, F, 0, st));
+    GF_TRY(launch_ffn_pack_ptrs(w1, w2, 0, pack_ws, 1, F, 0, st));       // w1 / w2 are separate tensors here
     int splits = 0;
     GF_TRY(launch_ffn_fused_fwd(x, pack_ws, b1, b2, h, slabs, (long)T * E, T, E, F, p, site, rng, add, train, &splits, st));
     return -1000 - splits;   // negative "code" carries the slab count back to the test harness (see ganffn.h)
@@ -552,7 +551,7 @@ extern "C" int ganffn_ffn_fused_bwd(const float* dy, const float* w1, const floa
                                     float* pack_ws, int T, int E, int F, float mscale, void* stream) {
     GF_CHECK_ARG(w1 && w2 && pack_ws && ffn_fused_supported(E, F), "ffn_fused_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    GF_TRY(launch_ffn_pack(w1, 0, 0, (long)(w2 - w1), pack_ws, 1, F, 1, st));
+    GF_TRY(launch_ffn_pack_ptrs(w1, w2, 0, pack_ws, 1, F, 1, st));
     int splits = 0;
     GF_TRY(launch_ffn_fused_bwd(dy, pack_ws, h, dh, slabs, (long)T * E, T, E, F, mscale, &splits, st));
     return -1000 - splits;

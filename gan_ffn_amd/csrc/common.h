@@ -218,6 +218,8 @@ int ffn_fused_splits(int T, int F);
 long ffn_pack_floats(int F);
 int launch_ffn_pack(const float* params, long layer_stride, long off_w1, long off_w2, float* packed, int L, int F, int bwd,
                     hipStream_t st);
+int launch_ffn_pack_ptrs(const float* w1, const float* w2, long layer_stride, float* packed, int L, int F, int bwd,
+                         hipStream_t st);
 int launch_ffn_fused_fwd(const float* x, const float* packed, const float* b1, const float* b2, float* h, float* slabs,
                          long slab_stride, int T, int E, int F, float p, uint32_t site, const uint64_t* rng, uint64_t add,
                          int train, int* splits_out, hipStream_t st);

@@ -52,13 +52,14 @@ __device__ __forceinline__ int krow(int s, int h) { return (s & 3) + 8 * (s >> 2
 //   backward:  G1 = W2[8g + 4h + j][32ft + r]              G2 = W1[32ft + 8gq + 4h + j][32et + r]
 // (lane = 32h + r; j = component; entries with an e index >= 100 are zero)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__ params, long layer_stride, long off_w1, long off_w2,
-                                                       float4* __restrict__ packed, int F, int bwd, int nvec_layer) {
+__global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__ w1_base, const float* __restrict__ w2_base,
+                                                       long layer_stride, float4* __restrict__ packed, int F, int bwd,
+                                                       int nvec_layer) {
     const int layer = blockIdx.y;
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= nvec_layer) return;
-    const float* w1 = params + (size_t)layer * layer_stride + off_w1;   // [F x 100]
-    const float* w2 = params + (size_t)layer * layer_stride + off_w2;   // [100 x F]
+    const float* w1 = w1_base + (size_t)layer * layer_stride;   // [F x 100]
+    const float* w2 = w2_base + (size_t)layer * layer_stride;   // [100 x F]
     const int ft = v / UNIT_VEC, u = v - ft * UNIT_VEC;
     const int lane = u & 63, r = lane & 31, h = lane >> 5;
     float o[4];
@@ -332,9 +333,16 @@ long ffn_pack_floats(int F) { return (long)(F / 32) * UNIT_VEC * 4; }
 // pack linear1 / linear2 of L consecutive layers (fwd or bwd orientation) into packed[L][ffn_pack_floats(F)]
 int launch_ffn_pack(const float* params, long layer_stride, long off_w1, long off_w2, float* packed, int L, int F, int bwd,
                     hipStream_t st) {
-    GF_CHECK_ARG(params && packed && aligned16(packed) && L >= 1, "ffn_pack: bad arguments");
+    GF_CHECK_ARG(params, "ffn_pack: bad arguments");
+    return launch_ffn_pack_ptrs(params + off_w1, params + off_w2, layer_stride, packed, L, F, bwd, st);
+}
+
+// the same with the two weight matrices given by their own base pointers (separate allocations: one layer, stride 0)
+int launch_ffn_pack_ptrs(const float* w1, const float* w2, long layer_stride, float* packed, int L, int F, int bwd,
+                         hipStream_t st) {
+    GF_CHECK_ARG(w1 && w2 && packed && aligned16(packed) && L >= 1, "ffn_pack: bad arguments");
     const int nvec = (F / 32) * UNIT_VEC;
-    hipLaunchKernelGGL(ffn_pack_kernel, dim3((nvec + 255) / 256, L), dim3(256), 0, st, params, layer_stride, off_w1, off_w2,
+    hipLaunchKernelGGL(ffn_pack_kernel, dim3((nvec + 255) / 256, L), dim3(256), 0, st, w1, w2, layer_stride,
                        reinterpret_cast<float4*>(packed), F, bwd, nvec);
     GF_LAUNCH_CHECK();
     return 0;

@@ -320,7 +320,9 @@ class GanEngine(_Runner):
             self._resize_passes(S, B)
         self._view_scratch(S, B)
         if self.n_streams > 1 and self.streams is None:
-            self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
+            prio = [int(x) for x in os.environ.get("GANFFN_STREAM_PRIO", "").split(",") if x.strip()]
+            prio = (prio + [0] * self.n_streams)[:self.n_streams]
+            self.streams = [torch.cuda.Stream(device=dev, priority=prio[i]) for i in range(self.n_streams)]
         self._res = {}
         self.static_batch = None
 

@@ -62,9 +62,13 @@ class DeviceRng:
         self.counter = 0
 
     def next_add(self, n=1):
-        """reserve n consecutive dropout offsets: THE allocator of this device — the autograd/module path takes one per
-        call, GanEngine / Phase2Engine take one block per iteration, so no two dropout-bearing launches of a process
-        ever share a (seed, offset) pair, whichever path issued them"""
+        """reserve n consecutive dropout offsets: the allocator of this device's EAGER paths — the autograd/module path
+        takes one per call, eager GanEngine / Phase2Engine iterations take one block each, so no two dropout-bearing
+        eager launches of a process share a (seed, offset) pair.  A hipGraph-replayed engine (`use_graph=True`) cannot
+        take host-side blocks (its launch arguments are frozen at capture): it advances the DEVICE-side offset instead,
+        which every eager launch adds its host offset to — so masks of a graph-replayed engine and of eager calls issued
+        on the same device in between may coincide (correlated masks, never wrong arithmetic).  Do not mix the two modes
+        on one device where independent masks matter."""
         v = self.counter
         self.counter += n
         return v
@@ -506,11 +510,21 @@ class DialogueRNNFn(torch.autograd.Function):
         return tuple(out)
 
 
+_CHECK_QMASK = __import__("os").environ.get("GANFFN_CHECK_QMASK", "0") == "1"
+
+
 def dialogue_rnn_supported(cell, U, qmask):
-    """the configuration the HIP recurrence implements: general attention, no listener, two parties, dims % 4, on a GPU"""
-    return (U.is_cuda and not cell.listener_state and getattr(cell.attention, "att_type", None) == "general"
-            and qmask.size(2) == 2 and cell.D_g == cell.D_p and cell.D_m % 4 == 0 and cell.D_g % 4 == 0 and cell.D_e % 4 == 0
-            and U.size(0) <= 112)
+    """the configuration the HIP recurrence implements: general attention, no listener, two parties, dims % 4,
+    D_g = D_p <= 512 (the attention kernels keep one state column per thread), on a GPU.
+    PRECONDITION (not tested here: the test would be a device->host sync in front of ~760 latency-sized launches): every
+    qmask row is one-hot or all zero, as the reference's loaders produce (dataloader.py:41-50) — the gate kernels use
+    (argmax, value at argmax) only.  GANFFN_CHECK_QMASK=1 verifies it on every call."""
+    ok = (U.is_cuda and not cell.listener_state and getattr(cell.attention, "att_type", None) == "general"
+          and qmask.size(2) == 2 and cell.D_g == cell.D_p and cell.D_g <= 512 and cell.D_m % 4 == 0 and cell.D_g % 4 == 0
+          and cell.D_e % 4 == 0 and U.size(0) <= 112)
+    if ok and _CHECK_QMASK:
+        ok = bool((((qmask == 0) | (qmask == 1)).all() & (qmask.sum(2) <= 1).all()).item())
+    return ok
 
 
 def dialogue_rnn_run(cells, Us, qmasks, training):

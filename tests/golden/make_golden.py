@@ -319,9 +319,54 @@ def dialogue_rnn():
     return out
 
 
+BIG_S, BIG_B = 94, 30        # configuration 5's real size: train_IEMOCAP_DialogueRNN.py:580 (batch 30), model.py:1437 (S = 94)
+
+
+def drnn_big_inputs():
+    """ragged (94, 30) batch, closed form: dialogue 0 is full length, the others 12 .. 93 utterances"""
+    S, B = BIG_S, BIG_B
+    lens = [S] + [12 + (b * 37) % 82 for b in range(1, B)]
+    U = F_.formula_input("drnn.bigU", S, B, 100)
+    umask = np.zeros((B, S), np.float32)
+    for b, L in enumerate(lens):
+        umask[b, :L] = 1
+        U[L:, b] = 0
+    spk = (np.arange(S)[:, None] * 3 + np.arange(B)[None, :] * 2 + (np.arange(S)[:, None] // 3)) % 2
+    qmask = np.stack([1 - spk, spk], -1).astype(np.float32) * umask.T[:, :, None]
+    return U, qmask, umask
+
+
+def dialogue_rnn_big():
+    """the reference's BiModel (general attention, no listener: the trained configuration,
+    train_IEMOCAP_DialogueRNN.py:586,595) at configuration 5's real size, eval mode, formula weights: summaries of the
+    log-probabilities, the matching-attention map, the input gradient and sampled parameter gradients"""
+    out = {}
+    U, qmask, umask = drnn_big_inputs()
+    torch.manual_seed(0)
+    m = ref.BiModel(**DRNN_DIMS, **DRNN_CASES["general"]).eval()
+    sd = F_.formula_state_dict({k: v for k, v in m.state_dict().items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    Ut = torch.from_numpy(U).requires_grad_(True)
+    lp, alpha, alpha_f, alpha_b = m(Ut, torch.from_numpy(qmask), torch.from_numpy(umask))
+    gy = torch.from_numpy(F_.formula_input("drnn.biggrad", lp.shape[0], lp.shape[1], lp.shape[2])) - 0.5
+    (lp * gy).sum().backward()
+    put(out, "big/log_prob", lp)
+    put(out, "big/alpha", torch.stack(alpha, 0))
+    put(out, "big/alpha_f_last", alpha_f[-1])
+    put(out, "big/alpha_b_last", alpha_b[-1])
+    put(out, "big/dU", Ut.grad)
+    for k, p_ in m.named_parameters():
+        if p_.grad is not None:
+            put(out, "big/grad/" + k, p_.grad)
+    return out
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dialogue_rnn":
         np.savez_compressed(os.path.join(HERE, "dialogue_rnn.npz"), **dialogue_rnn())
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dialogue_rnn_big":
+        np.savez_compressed(os.path.join(HERE, "dialogue_rnn_big.npz"), **dialogue_rnn_big())
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "artifacts":
         np.savez_compressed(os.path.join(HERE, "artifacts.npz"), **artifacts())
@@ -332,4 +377,5 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "gan_steps.npz"), **gan_steps())
     np.savez_compressed(os.path.join(HERE, "artifacts.npz"), **artifacts())
     np.savez_compressed(os.path.join(HERE, "dialogue_rnn.npz"), **dialogue_rnn())
+    np.savez_compressed(os.path.join(HERE, "dialogue_rnn_big.npz"), **dialogue_rnn_big())
     print("golden fixtures written to", HERE)

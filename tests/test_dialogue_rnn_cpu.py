@@ -65,6 +65,58 @@ def test_bimodel_matches_reference_fixture(tag):
     assert n >= 20
 
 
+BIG_S, BIG_B = 94, 30
+
+
+def big_inputs():
+    """the ragged (94, 30) batch of tests/golden/make_golden.py drnn_big_inputs (configuration 5's real size)"""
+    S, B = BIG_S, BIG_B
+    lens = [S] + [12 + (b * 37) % 82 for b in range(1, B)]
+    U = F_.formula_input("drnn.bigU", S, B, 100)
+    umask = np.zeros((B, S), np.float32)
+    for b, L in enumerate(lens):
+        umask[b, :L] = 1
+        U[L:, b] = 0
+    spk = (np.arange(S)[:, None] * 3 + np.arange(B)[None, :] * 2 + (np.arange(S)[:, None] // 3)) % 2
+    qmask = np.stack([1 - spk, spk], -1).astype(np.float32) * umask.T[:, :, None]
+    return U, qmask, umask
+
+
+def check_big(m, dev, rtol=5e-5, grtol=5e-4):
+    """BiModel `m` (formula weights, eval) at (94, 30) against the reference-generated summaries of
+    tests/golden/dialogue_rnn_big.npz: log-probabilities, attention maps, input gradient, every parameter gradient"""
+    from util import check_summary
+    g = golden("dialogue_rnn_big")
+    U, qmask, umask = big_inputs()
+    Ut = torch.from_numpy(U).to(dev).requires_grad_(True)
+    lp, alpha, alpha_f, alpha_b = m(Ut, torch.from_numpy(qmask).to(dev), torch.from_numpy(umask).to(dev))
+    check_summary(g, "big/log_prob", lp, rtol=rtol, atol=1e-6, what="log_prob", strict=True)
+    check_summary(g, "big/alpha", torch.stack(alpha, 0), rtol=rtol, atol=1e-7, what="alpha", strict=True)
+    check_summary(g, "big/alpha_f_last", alpha_f[-1], rtol=rtol, atol=1e-7, what="alpha_f", strict=True)
+    check_summary(g, "big/alpha_b_last", alpha_b[-1], rtol=rtol, atol=1e-7, what="alpha_b", strict=True)
+    gy = torch.from_numpy(F_.formula_input("drnn.biggrad", lp.shape[0], lp.shape[1], lp.shape[2])) - 0.5
+    (lp * gy.to(dev)).sum().backward()
+    check_summary(g, "big/dU", Ut.grad, rtol=grtol, atol=1e-7, what="dU", strict=True)
+    n = 0
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            assert not any(f.startswith("big/grad/%s/" % k) for f in g.files), k
+            continue
+        check_summary(g, "big/grad/" + k, p.grad, rtol=grtol, atol=1e-7, what="grad " + k, strict=True, l2_rtol=2e-3)
+        n += 1
+    assert n >= 20
+
+
+def test_bimodel_at_configuration_5_size_matches_reference_fixture():
+    """(94, 30), ragged, general attention / no listener — the trained configuration at its real size"""
+    from gan_ffn_amd import dialogue_rnn as DR
+    torch.manual_seed(1)
+    m = DR.BiModel(**DIMS, **CASES["general"]).eval()
+    sd = F_.formula_state_dict(m.state_dict())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    check_big(m, "cpu")
+
+
 def test_general2_attention_single_query_and_batched_agree_with_reference():
     from gan_ffn_amd import dialogue_rnn as DR
     g = golden("dialogue_rnn")

@@ -116,6 +116,22 @@ def test_bimodel_on_gpu_matches_reference_fixture(tag):
         T.close(got, g["%s/grad/%s" % (tag, k)], 5e-4, "grad " + k)
 
 
+def test_hip_recurrence_at_configuration_5_size_matches_reference_fixture():
+    """the HIP recurrence (csrc/dialogue_rnn.hip) + HIP general2 at (94, 30) against summaries the REFERENCE's BiModel
+    produced at that size (tests/golden/dialogue_rnn_big.npz, make_golden.py dialogue_rnn_big)"""
+    import test_dialogue_rnn_cpu as T
+    import formula as F_
+    from gan_ffn_amd import dialogue_rnn as DR, ops
+    m = DR.BiModel(**T.DIMS, **T.CASES["general"]).eval()
+    sd = F_.formula_state_dict(m.state_dict())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.cuda()
+    U, qmask, _ = T.big_inputs()
+    cell = m.dialog_rnn_f.dialogue_cell
+    assert ops.dialogue_rnn_supported(cell, torch.from_numpy(U).cuda(), torch.from_numpy(qmask).cuda()), "HIP recurrence must be the path under test"
+    T.check_big(m, "cuda", rtol=1e-4, grtol=1e-3)
+
+
 def test_meld_lstm_model_on_gpu_matches_reference_fixture():
     """N4 on the device: MIOpen LSTM + the HIP general2 kernel (D = 600) against the reference's fixture"""
     import test_dialogue_rnn_cpu as T

@@ -55,23 +55,33 @@ def test_engine_reproduces_reference_gan_trajectory():
 
 
 def test_graph_replay_matches_eager():
+    """hipGraph replay against eager launches, EXACTLY (train mode, dropout on).  The first graph-mode call runs the
+    iteration once eagerly as warm-up (dropout offsets 0 .. 47, then the device-side offset is bumped by 48), captures
+    (capture executes nothing) and replays once, so replay k is the (k + 1)-th execution of the iteration: same
+    parameter versions, same effective Philox offsets (device offset 48 (k + 1) + v against the eager engine's host
+    block 48 (k + 1) + v) and the same deterministic kernels -> the same bits as eager iteration k + 1."""
     from gan_ffn_amd import engine, ops
     batch = gan_batch(S=9, B=2)
     res = []
-    for use_graph in (False, True):
+    for use_graph, n in ((False, 4), (True, 3)):
         gens, discs = build_all(zero_dropout=False)
         ops.manual_seed(1234)
         eng = engine.GanEngine(gens, discs, use_graph=use_graph)
+        assert eng.use_graph == use_graph
         out = []
-        for _ in range(3):
+        for _ in range(n):
             out.append(eng.iteration(batch).clone())
         torch.cuda.synchronize()
         res.append(torch.stack(out).cpu().numpy())
-    # graph capture runs a warm-up + capture pass first, so its parameter trajectory is 2 iterations ahead;
-    # what must agree is that losses are finite, in range and that replay advances the dropout stream
-    assert np.isfinite(res[0]).all() and np.isfinite(res[1]).all()
-    assert (res[1] > 0.2).all() and (res[1] < 3.0).all()
-    assert not np.allclose(res[1][0], res[1][1])
+        final = {k: m.slab.detach().cpu().clone() for k, m in list(gens.items()) + [("D" + k, v) for k, v in discs.items()]}
+        res.append(final)
+    eager, eager_final, replay, replay_final = res
+    assert np.isfinite(eager).all() and np.isfinite(replay).all()
+    for k in range(3):
+        assert np.array_equal(replay[k], eager[k + 1]), (k, replay[k], eager[k + 1])
+    assert not np.allclose(replay[0], replay[1])               # the replay advances the dropout stream
+    for k in eager_final:                                       # 4 executions each: identical parameters, bit for bit
+        assert torch.equal(eager_final[k], replay_final[k]), k
 
 
 def test_train_mode_losses_are_plausible_and_masks_advance():

@@ -151,12 +151,30 @@ def test_bimodal_engine_matches_oracle_iteration(S, B):
 
 
 def test_bimodal_engine_train_mode_full_batch_two_streams():
-    """configs[2] shape (B = 32, S = 33) in train mode on 2 streams: finite, plausible losses; masks advance"""
+    """configs[2] shape (B = 32, S = 33) in TRAIN mode on 2 streams, against the oracle with the SAME Philox masks.
+
+    Sub-step 0 = train_disc(D_text | G_acoustic): G in eval mode (no dropout), then ONE discriminator pass over the
+    [real | fake] batch of 2B = 64 dialogues with the dropout offsets the engine allocates (base + 2 encoder, base + 3
+    head; base + 0 / + 1 go to the eval-mode generator pass and draw nothing).  The oracle draws the masks of that
+    64-dialogue layout, so the train-mode loss is checked at north_star's 1e-4, then repeats D's Adam step and checks
+    sub-step 1 = train_gen(G_acoustic | D_text) (generator offsets base + 4 / + 5, the frozen D in eval mode) the same way.
+
+    History: this test used to assert 0.2 < loss < 3.0 on every sub-step and failed on its first
+    MELD run; the bound was then widened without a recorded cause.  Cause, measured on the GPU and reproduced by the
+    oracle below: with the FORMULA weights of the parity fixtures (sin-patterned, not a trained or Xavier-initialised
+    state) the MELD-width discriminators saturate — D_text answers ~1 on the real half AND on the fake half, so
+    BCE(fake, 0) alone is far above 3 and text_D_loss leaves (0.2, 3.0) while acoustic_G_loss = BCE(D(G(x)), 1) drops
+    under 0.2.  Nothing was wrong in the kernels; a range is simply not a property of these weights.  The range check is
+    therefore gone and the losses are compared with the oracle instead."""
+    import test_hip_modules as M
     from gan_ffn_amd import engine, ops
+    S, B, seed = 33, 32, 11
     gens, discs = _build_all(zero_dropout=False)
-    ops.manual_seed(11)
+    ops.manual_seed(seed)
     eng = engine.GanEngine(gens, discs, n_streams=2)
-    batch = _batch(33, 32)
+    assert eng.schedule[:2] == [("D", "text", "acoustic"), ("G", "acoustic", "text")]
+    batch = _batch(S, B)
+    base = eng.rng.counter                      # the block of offsets this iteration will get
     la = eng.iteration(batch)
     eng.synchronize()                 # side streams -> current stream before reading the loss slots
     torch.cuda.synchronize()
@@ -165,5 +183,29 @@ def test_bimodal_engine_train_mode_full_batch_two_streams():
     eng.synchronize()
     torch.cuda.synchronize()
     assert set(eng.loss_dict()) == {"text_D_loss", "acoustic_G_loss", "acoustic_D_loss", "text_G_loss"}
-    assert torch.isfinite(a).all() and torch.isfinite(b).all() and (a > 1e-3).all() and (a < 10.0).all(), (a, b)
-    assert not torch.allclose(a, b)
+    assert torch.isfinite(a).all() and torch.isfinite(b).all(), (a, b)
+    assert not torch.allclose(a, b)             # offsets advanced: new masks (and one Adam step further)
+    print("train-mode losses at (33, 32), formula weights:", [round(float(v), 4) for v in a])
+
+    # ---- oracle, sub-step 0: train_disc(D_text | G_acoustic) with the engine's offsets and the 2B layout
+    Ga = O.OracleNet("gen", formula_sd(MELD_GEN["acoustic"]), 10, 0.2, torch.float64)
+    Dt = O.OracleNet("disc", formula_sd(MELD_DISC["text"]), 10, 0.2, torch.float64)
+    xa, xt = batch["acoustic"].cpu().double(), batch["text"].cpu().double()
+    with torch.no_grad():
+        fusion = O.generator_forward(xa, Ga.P, 10, 0.2, None)                       # gen.eval(), detached
+    real_in = xt @ Dt.P["object.weight"].T + Dt.P["object.bias"]                   # model.py:1355-1356 at MELD's text width
+    xcat = torch.cat((real_in, fusion), dim=1)
+    h = O.encoder_stack(xcat, Dt.P, 10, O.Rng(seed, base + 2, True))
+    prob = M.oracle_head(Dt, "disc", h, O.Rng(seed, base + 3, True))
+    want0 = (O.bce_mean(prob[:, :B], torch.ones(S, B, 1, dtype=torch.float64)) +
+             O.bce_mean(prob[:, B:], torch.zeros(S, B, 1, dtype=torch.float64))) / 2.0
+    assert abs(float(a[0]) - float(want0)) < 1e-4 * max(1.0, abs(float(want0))), (float(a[0]), float(want0))
+    # D_text's Adam step (lr / 2, betas (0.5, 0.6): train_IEMOCAP.py:292-297,603-606), then sub-step 1
+    opt = O.Adam(Dt.parameters(), 1e-4 / 2, (0.5, 0.6))
+    want0.backward()
+    opt.step()
+    hg = O.encoder_stack(xa, Ga.P, 10, O.Rng(seed, base + 4, True))
+    fus = M.oracle_head(Ga, "gen", hg, O.Rng(seed, base + 5, True))
+    p1 = O.discriminator_forward(fus, Dt.P, 10, 0.2, None)                          # disc.eval()
+    want1 = O.bce_mean(p1, torch.ones(S, B, 1, dtype=torch.float64))
+    assert abs(float(a[1]) - float(want1)) < 1e-4 * max(1.0, abs(float(want1))), (float(a[1]), float(want1))
