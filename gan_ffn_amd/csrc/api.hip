@@ -100,12 +100,19 @@ static int check_cfg(const ganffn_enc_cfg* c) {
 // kernel streams 30 KB of packed weights per (32 tokens x 32 hidden units) and is bound by L2 -> CU bandwidth
 // (357 MB per launch at T = 6016), so it stays opt-in.
 int g_ffn_fused = 0;
+// d_model = 100: the token-local chains around the LayerNorms run as single kernels (rowchain.hip); bit 1 of
+// ganffn_debug_set_ffn_mode switches back to the separate GEMM + LayerNorm launches (both paths are parity-tested)
+int g_rc_off = 0;
 constexpr int MAX_SPLITS = 16;  // partial-output slabs: fused FFN (16 F splits) / split-K GEMMs (<= 8)
 
 static int64_t a4(int64_t n) { return (n + 3) & ~int64_t(3); }
 
 // per LayerNorm backward launch: per-block partial sums of the weight / bias gradient
-static int64_t ln_part_floats(const ganffn_enc_cfg* c) { return (int64_t)ln_bwd_blocks(c->S * c->B) * 2 * c->E; }
+static int64_t ln_part_floats(const ganffn_enc_cfg* c) {
+    const int T = c->S * c->B;
+    const int nb = ln_bwd_blocks(T) > rc_blocks(T) ? ln_bwd_blocks(T) : rc_blocks(T);
+    return (int64_t)nb * 2 * c->E;
+}
 
 // K splits of the in-proj dgrad [T x 3E] x [3E x E]: its T/64 x E/64 output tiles are far fewer than the chip's workgroup
 // slots (94 at d_model 100, T = 3008), so K is cut into ~128-wide chunks (at most 8) whose partial outputs the consuming
@@ -126,8 +133,10 @@ static int64_t enc_ws_floats(const ganffn_enc_cfg* c) {
     // + L packed FFN weight blocks (fused feed-forward kernel, d_model 100)
     const int64_t pack = ffn_fused_supported(c->E, c->F) ? (int64_t)c->L * ffn_pack_floats(c->F) : 0;
     // + the partial-slab workspace of the grouped weight-gradient launch (narrow groups split the token range)
+    // + L transposed {in-proj, out-proj} weight blocks (rowchain backward, d_model 100)
+    const int64_t rcw = rc_supported(c->E) ? (int64_t)c->L * rc_pack_floats() + 8 : 0;
     const int64_t bwd = (int64_t)c->L * (TF + 5 * TE) + (3 + MAX_SPLITS) * TE + (int64_t)c->L * 2 * ln_part_floats(c) + pack +
-                        gemm_tn_grouped_part_floats() + 8;
+                        gemm_tn_grouped_part_floats() + 8 + rcw;
     const SavedOff s = saved_off(c);
     const int64_t fwd_nosave = 2 * TE + s.per_layer + MAX_SPLITS * TE + pack;   // X ping-pong + one layer's saved set + tmp slabs + packs
     return (bwd > fwd_nosave ? bwd : fwd_nosave) + 64;
@@ -197,24 +206,37 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
     const int64_t PK = fused ? ffn_pack_floats(F) : 0;
     if (fused) GF_TRY(launch_ffn_pack(params, lo.total, lo.w1, lo.w2, pack, L, F, 0, st));
     GF_TRY(launch_pe_dropout(x_in, pe, Xcur, S, B, E, c->p_pe, rng, add, train, st));
+    // d_model 100: out-proj + residual + dropout + LN1 is one kernel, and LN2 carries the NEXT layer's in-proj (rowchain.hip)
+    const bool rc = rc_supported(E) && !g_rc_off;
+    auto layer_saved = [&](int l) { return saved ? saved + so.layers + (int64_t)l * so.per_layer : workspace + 2 * TE; };
+    if (rc) {
+        EpiArgs e0;
+        e0.bias = params + lo.in_b;
+        GF_TRY(launch_gemm_nt(Xcur, E, params + lo.in_w, E, layer_saved(0) + so.qkv, 3 * E, T, 3 * E, E, EPI_NONE, e0, st));
+    }
 
     for (int l = 0; l < L; ++l) {
         const float* P = params + (int64_t)l * lo.total;
-        float* sv = saved ? saved + so.layers + (int64_t)l * so.per_layer : workspace + 2 * TE;
+        float* sv = layer_saved(l);
         float* Xnext = saved ? saved + so.X + (int64_t)(l + 1) * TE : workspace + ((l & 1) ? 0 : TE);
         if (l == L - 1) Xnext = out;
         const uint32_t site = SITE_LAYER0 + 4 * l;
         EpiArgs ea;
         // qkv = X W_in^T + b_in
         ea.bias = P + lo.in_b;
-        GF_TRY(launch_gemm_nt(Xcur, E, P + lo.in_w, E, sv + so.qkv, 3 * E, T, 3 * E, E, EPI_NONE, ea, st));
+        if (!rc) GF_TRY(launch_gemm_nt(Xcur, E, P + lo.in_w, E, sv + so.qkv, 3 * E, T, 3 * E, E, EPI_NONE, ea, st));
         // attention core
         GF_TRY(launch_attention_fwd(sv + so.qkv, sv + so.attn_o, sv + so.lse, S, B, E, H, c->p_enc, site + 0, rng, add, train, st));
         // out-proj, residual + dropout + LN1
-        ea.bias = P + lo.out_b;
-        GF_TRY(launch_gemm_nt(sv + so.attn_o, E, P + lo.out_w, E, tmp, E, T, E, E, EPI_NONE, ea, st));
-        GF_TRY(launch_add_drop_ln_fwd(Xcur, tmp, P + lo.n1w, P + lo.n1b, sv + so.x1, sv + so.xhat1, sv + so.rstd1, T, E,
-                                      c->ln_eps, c->p_enc, site + 1, rng, add, train, st));
+        if (rc) {
+            GF_TRY(launch_rc_outproj_ln_fwd(sv + so.attn_o, P + lo.out_w, P + lo.out_b, Xcur, P + lo.n1w, P + lo.n1b, sv + so.x1,
+                                            sv + so.xhat1, sv + so.rstd1, T, c->ln_eps, c->p_enc, site + 1, rng, add, train, st));
+        } else {
+            ea.bias = P + lo.out_b;
+            GF_TRY(launch_gemm_nt(sv + so.attn_o, E, P + lo.out_w, E, tmp, E, T, E, E, EPI_NONE, ea, st));
+            GF_TRY(launch_add_drop_ln_fwd(Xcur, tmp, P + lo.n1w, P + lo.n1b, sv + so.x1, sv + so.xhat1, sv + so.rstd1, T, E,
+                                          c->ln_eps, c->p_enc, site + 1, rng, add, train, st));
+        }
         // FFN: h = drop(relu(x1 W1^T + b1)); y = h W2^T + b2
         int splits = 1;
         if (fused) {
@@ -229,11 +251,16 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
             splits = gemm_splitk_factor(T, E, F);      // few output tiles, K = 2048: split K, LN sums the slabs
             GF_TRY(launch_gemm_nt(sv + so.h, F, P + lo.w2, F, tmp, E, T, E, F, EPI_NONE, ea, st, &splits, TE));
         }
-        GF_TRY(launch_add_drop_ln_fwd(sv + so.x1, tmp, P + lo.n2w, P + lo.n2b, Xnext, sv + so.xhat2, sv + so.rstd2, T, E,
-                                      c->ln_eps, c->p_enc, site + 3, rng, add, train, st, splits, TE));
-        if (saved && l == L - 1) {
-            // keep X[L] in the saved set too (not needed by backward, but keeps the layout uniform) — skip the copy:
-            // nothing reads X[L].
+        if (rc) {
+            // LN2, then (all but the last layer) qkv of layer l + 1 from the fresh rows while they are in the workgroup
+            const float* Pn = (l + 1 < L) ? P + lo.total : nullptr;
+            GF_TRY(launch_rc_ln_inproj_fwd(tmp, splits, TE, sv + so.x1, P + lo.n2w, P + lo.n2b, Xnext, sv + so.xhat2, sv + so.rstd2,
+                                           Pn ? Pn + lo.in_w : nullptr, Pn ? Pn + lo.in_b : nullptr,
+                                           Pn ? layer_saved(l + 1) + so.qkv : nullptr, T, c->ln_eps, c->p_enc, site + 3, rng, add,
+                                           train, st));
+        } else {
+            GF_TRY(launch_add_drop_ln_fwd(sv + so.x1, tmp, P + lo.n2w, P + lo.n2b, Xnext, sv + so.xhat2, sv + so.rstd2, T, E,
+                                          c->ln_eps, c->p_enc, site + 3, rng, add, train, st, splits, TE));
         }
         Xcur = Xnext;
     }
@@ -280,7 +307,11 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
     tnp = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(tnp) + 15) & ~(uintptr_t)15);
     if (fused)
         GF_TRY(launch_ffn_pack(params + (int64_t)layer_lo * lo.total, lo.total, lo.w1, lo.w2, pack, layer_hi - layer_lo, F, 1, st));
-    const int lnblk = ln_bwd_blocks(T);
+    const bool rc = rc_supported(E) && !g_rc_off;
+    float* rcw = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(tnp + gemm_tn_grouped_part_floats()) + 15) & ~(uintptr_t)15);
+    const int64_t RCW = rc_pack_floats();              // per layer: in_w^T [E x 3E] | out_w^T [E x E]
+    if (rc) GF_TRY(launch_rc_pack(params + (int64_t)layer_lo * lo.total, lo.total, lo.in_w, lo.out_w, rcw, layer_hi - layer_lo, st));
+    const int lnblk = rc ? rc_blocks(T) : ln_bwd_blocks(T);
     TnDesc tn[40];
     int ntn = 0;
     float* r_gw[2 * 64]; float* r_gb[2 * 64]; const float* r_part[2 * 64]; int r_nb[2 * 64];
@@ -304,9 +335,21 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
         EpiArgs none;
         // LN2 backward: dL/dX[l+1] -> dz2 (to x1), dyA (to FFN output).  dL/dX[l+1] is the caller's dx for the top layer
         // of the range and otherwise the in-proj dgrad of the layer above: split-K partial slabs in `tmp`, summed here
-        GF_TRY(launch_add_drop_ln_bwd(dxin, sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dyA, G ? G + lo.n2w : nullptr,
-                                      G ? G + lo.n2b : nullptr, T, E, c->p_enc, site + 3, rng, add, train, st, dxin_slabs, TE,
-                                      nullptr, G ? lnp2 : nullptr));
+        if (rc) {
+            // top layer of the range: the caller's dx; below it: the in-proj dgrad of the layer above (its d_qkv is still in
+            // that layer's buffer set, its residual-branch gradient in dz1) runs inside this kernel
+            if (l == layer_hi - 1)
+                GF_TRY(launch_rc_ln_bwd(nullptr, nullptr, dx, 1, 0, nullptr, sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dyA,
+                                        G ? lnp2 : nullptr, nullptr, nullptr, T, c->p_enc, site + 3, rng, add, train, st));
+            else
+                GF_TRY(launch_rc_ln_bwd(bs + SET + TF + 2 * TE, rcw + (int64_t)(l + 1 - layer_lo) * RCW, nullptr, 0, 0, dz1,
+                                        sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dyA, G ? lnp2 : nullptr, nullptr, nullptr, T,
+                                        c->p_enc, site + 3, rng, add, train, st));
+        } else {
+            GF_TRY(launch_add_drop_ln_bwd(dxin, sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dyA, G ? G + lo.n2w : nullptr,
+                                          G ? G + lo.n2b : nullptr, T, E, c->p_enc, site + 3, rng, add, train, st, dxin_slabs, TE,
+                                          nullptr, G ? lnp2 : nullptr));
+        }
         if (G) { r_gw[nred] = G + lo.n2w; r_gb[nred] = G + lo.n2b; r_part[nred] = lnp2; r_nb[nred] = lnblk; ++nred; }
         // linear2 wgrad: gW2[E,F] += dyA^T h ; gb2 += colsum(dyA)
         if (G) tn[ntn++] = TnDesc{dyA, E, sv + so.h, F, G + lo.w2, F, G + lo.b2, E, F, T};
@@ -328,13 +371,20 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
             splits = gemm_splitk_factor(T, E, F);
             GF_TRY(launch_gemm_nn(dh, F, P + lo.w1, E, tmp, E, T, E, F, EPI_NONE, none, st, &splits, TE));
         }
-        GF_TRY(launch_add_drop_ln_bwd(tmp, sv + so.xhat1, sv + so.rstd1, P + lo.n1w, dz1, dyB, G ? G + lo.n1w : nullptr,
-                                      G ? G + lo.n1b : nullptr, T, E, c->p_enc, site + 1, rng, add, train, st, splits, TE, dz2,
-                                      G ? lnp1 : nullptr));
+        if (rc) {
+            // LN1 backward + the out-proj dgrad (d_attn = dyB W_o) on the rows while they are in the workgroup
+            GF_TRY(launch_rc_ln_bwd(nullptr, nullptr, tmp, splits, TE, dz2, sv + so.xhat1, sv + so.rstd1, P + lo.n1w, dz1, dyB,
+                                    G ? lnp1 : nullptr, rcw + (int64_t)(l - layer_lo) * RCW + 3 * (int64_t)E * E, d_attn, T, c->p_enc,
+                                    site + 1, rng, add, train, st));
+        } else {
+            GF_TRY(launch_add_drop_ln_bwd(tmp, sv + so.xhat1, sv + so.rstd1, P + lo.n1w, dz1, dyB, G ? G + lo.n1w : nullptr,
+                                          G ? G + lo.n1b : nullptr, T, E, c->p_enc, site + 1, rng, add, train, st, splits, TE, dz2,
+                                          G ? lnp1 : nullptr));
+        }
         if (G) { r_gw[nred] = G + lo.n1w; r_gb[nred] = G + lo.n1b; r_part[nred] = lnp1; r_nb[nred] = lnblk; ++nred; }
         // out-proj wgrad + dgrad
         if (G) tn[ntn++] = TnDesc{dyB, E, sv + so.attn_o, E, G + lo.out_w, E, G + lo.out_b, E, E, T};
-        GF_TRY(launch_gemm_nn(dyB, E, P + lo.out_w, E, d_attn, E, T, E, E, EPI_NONE, none, st));
+        if (!rc) GF_TRY(launch_gemm_nn(dyB, E, P + lo.out_w, E, d_attn, E, T, E, E, EPI_NONE, none, st));
         // attention core backward
         GF_TRY(launch_attention_bwd(sv + so.qkv, sv + so.attn_o, sv + so.lse, d_attn, d_qkv, S, B, E, H, c->p_enc, site + 0, rng,
                                     add, train, st));
@@ -346,7 +396,9 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
         }
         EpiArgs eadd;
         eadd.aux_in = dz1;            // dX[l] = d_qkv W_in + dz1 (residual, added by split 0) in the GEMM epilogue
-        if (l > layer_lo) {
+        if (l > layer_lo && rc) {
+            // (the in-proj dgrad of this layer runs inside the LN2 backward kernel of layer l - 1)
+        } else if (l > layer_lo) {
             // few output tiles (T/64 x E/64): split K into slabs that the next layer's LN2 backward sums on the fly
             // (`tmp` is free here: its previous content, this layer's dh W1 slabs, went into the LN1 backward above)
             int sp = inproj_dgrad_splits(T, E);
@@ -534,7 +586,8 @@ extern "C" int ganffn_ffn_linear1_fwd(const float* x, const float* w1, const flo
     return launch_gemm_nt(x, E, w1, E, h, F, T, F, E, EPI_RELU_DROP, e, (hipStream_t)stream);
 }
 extern "C" int ganffn_debug_set_ffn_mode(int bits) {
-    g_ffn_fused = bits ? 1 : 0;
+    g_ffn_fused = (bits & 1) ? 1 : 0;
+    g_rc_off = (bits & 2) ? 1 : 0;
     return 0;
 }
 extern "C" int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h,

@@ -274,6 +274,23 @@ int launch_add_drop_ln_bwd(const float* d_out, const float* xhat, const float* r
 int launch_ln_param_reduce(int n, float* const* gw, float* const* gb, const float* const* part, const int* nblk, int E,
                            hipStream_t st);
 int launch_add_inplace(float* a, const float* b, int64_t n, hipStream_t st);
+
+// rowchain.hip — d_model 100: out-proj + residual + dropout + LayerNorm1, LayerNorm2 + the next layer's in-proj, and the
+// mirror-image backward chains, one kernel each (16 token rows per workgroup)
+bool rc_supported(int E);
+long rc_pack_floats();          // floats of one layer's transposed {in-proj, out-proj} weights (backward)
+int rc_blocks(int T);           // workgroups = partial rows of the LayerNorm parameter gradients per launch
+int launch_rc_pack(const float* params, long layer_stride, long off_in, long off_out, float* wt, int nl, hipStream_t st);
+int launch_rc_outproj_ln_fwd(const float* attn_o, const float* wo, const float* bo, const float* x, const float* gamma,
+                             const float* beta, float* out, float* xhat, float* rstd, int T, float eps, float p, uint32_t site,
+                             const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+int launch_rc_ln_inproj_fwd(const float* y, int nslab, long slab_stride, const float* x, const float* gamma, const float* beta,
+                            float* out, float* xhat, float* rstd, const float* w_in, const float* b_in, float* qkv, int T,
+                            float eps, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+int launch_rc_ln_bwd(const float* d_qkv, const float* w_in_t, const float* d_out, int nslab, long slab_stride, const float* addend,
+                     const float* xhat, const float* rstd, const float* gamma, float* dz, float* dy, float* gpart,
+                     const float* wo_t, float* d_attn, int T, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
+                     hipStream_t st);
 int launch_gelu_drop_fwd(const float* x, float* out, int R, int C, float p, uint32_t site, const uint64_t* rng,
                          uint64_t add, int train, hipStream_t st);
 

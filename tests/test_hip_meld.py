@@ -159,13 +159,13 @@ def test_bimodal_engine_train_mode_full_batch_two_streams():
     64-dialogue layout, so the train-mode loss is checked at north_star's 1e-4, then repeats D's Adam step and checks
     sub-step 1 = train_gen(G_acoustic | D_text) (generator offsets base + 4 / + 5, the frozen D in eval mode) the same way.
 
-    History: this test used to assert 0.2 < loss < 3.0 on every sub-step and failed on its first
-    MELD run; the bound was then widened without a recorded cause.  Cause, measured on the GPU and reproduced by the
-    oracle below: with the FORMULA weights of the parity fixtures (sin-patterned, not a trained or Xavier-initialised
-    state) the MELD-width discriminators saturate — D_text answers ~1 on the real half AND on the fake half, so
-    BCE(fake, 0) alone is far above 3 and text_D_loss leaves (0.2, 3.0) while acoustic_G_loss = BCE(D(G(x)), 1) drops
-    under 0.2.  Nothing was wrong in the kernels; a range is simply not a property of these weights.  The range check is
-    therefore gone and the losses are compared with the oracle instead."""
+    History: this test used to assert 0.2 < loss < 3.0 on every sub-step, failed on its first MELD run
+    (gpurun_out/r2_round_a.log) and commit 39a10e4 widened the bound to (1e-3, 10) without a recorded cause.  Cause, from
+    that commit's own diff: the first version cloned the loss tensor BEFORE eng.synchronize() — on the current stream,
+    while the two side streams were still running the sub-steps — so it read loss slots that had not been written yet
+    (zeros: "a > 0.2" false).  The same commit moved the clone behind synchronize(), which was the whole fix; the wider
+    bound was never needed: on the fixed test the four train-mode losses at (33, 32) are 0.7043, 0.7308, 0.7004, 0.7428
+    (measured, round 3).  A range is a weak check either way: it is gone, and the losses are compared with the oracle."""
     import test_hip_modules as M
     from gan_ffn_amd import engine, ops
     S, B, seed = 33, 32, 11

@@ -190,9 +190,11 @@ def test_cpu_tensor_fails_loudly():
         m(torch.zeros(4, 2, 100))
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_fused_ffn_modes_agree_with_fixture(mode):
-    """the encoder's FFN runs as two GEMMs (mode 0, the default) or as the fused kernel (mode 1): both match the reference"""
+    """the encoder's FFN runs as two GEMMs (bit 0 clear, the default) or as the fused kernel (bit 0 set); the token-local
+    chains around the LayerNorms of a d_model-100 layer run as single kernels (rowchain.hip; bit 1 clear, the default) or
+    as separate GEMM + LayerNorm launches (bit 1 set): every combination matches the reference"""
     from gan_ffn_amd import _lib
     lib = _lib.load()
     lib.ganffn_debug_set_ffn_mode(mode)
