@@ -82,6 +82,7 @@ SIGNATURES = {
     "ganffn_add_dropout_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U32, _P, _U64, _P]),
     "ganffn_general2_attention_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ganffn_general2_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ganffn_gemm_n100": (_I, [_P, _P, _I, _P, _P, _L, _I, _I, _I, C.POINTER(C.c_int), _P]),
     "ganffn_debug_set_ffn_mode": (_I, [_I]),
     "ganffn_drnn_skinny": (_I, [_I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "ganffn_drnn_saved_floats": (_L, [C.POINTER(DrnnCfg)]),

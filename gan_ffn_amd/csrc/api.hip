@@ -103,6 +103,11 @@ int g_ffn_fused = 0;
 // d_model = 100: the token-local chains around the LayerNorms run as single kernels (rowchain.hip); bit 1 of
 // ganffn_debug_set_ffn_mode switches back to the separate GEMM + LayerNorm launches (both paths are parity-tested)
 int g_rc_off = 0;
+// N = 100, long-K products (linear2 forward, linear1 dgrad) on the 112-wide 16x16x4 kernel (gemm_n100.hip); bit 2 of
+// ganffn_debug_set_ffn_mode switches back to the generic 64 x 64 tiles
+int g_n100_off = 0;
+extern int g_n100_force_splits;
+extern unsigned long long* g_n100_stamps;
 constexpr int MAX_SPLITS = 16;  // partial-output slabs: fused FFN (16 F splits) / split-K GEMMs (<= 8)
 
 static int64_t a4(int64_t n) { return (n + 3) & ~int64_t(3); }
@@ -247,9 +252,14 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
             EpiArgs e1;
             e1.bias = P + lo.b1; e1.p = c->p_enc; e1.site = site + 2; e1.rng = rng; e1.rng_add = add; e1.train = train;
             GF_TRY(launch_gemm_nt(sv + so.x1, E, P + lo.w1, E, sv + so.h, F, T, F, E, EPI_RELU_DROP, e1, st));
-            ea.bias = P + lo.b2;
-            splits = gemm_splitk_factor(T, E, F);      // few output tiles, K = 2048: split K, LN sums the slabs
-            GF_TRY(launch_gemm_nt(sv + so.h, F, P + lo.w2, F, tmp, E, T, E, F, EPI_NONE, ea, st, &splits, TE));
+            if (n100_supported(E, F) && !g_n100_off) {
+                splits = MAX_SPLITS;                   // K chunks = output slabs, summed by the LayerNorm kernel
+                GF_TRY(launch_gemm_n100(sv + so.h, F, P + lo.w2, F, 0, P + lo.b2, tmp, TE, T, F, &splits, st));
+            } else {
+                ea.bias = P + lo.b2;
+                splits = gemm_splitk_factor(T, E, F);      // few output tiles, K = 2048: split K, LN sums the slabs
+                GF_TRY(launch_gemm_nt(sv + so.h, F, P + lo.w2, F, tmp, E, T, E, F, EPI_NONE, ea, st, &splits, TE));
+            }
         }
         if (rc) {
             // LN2, then (all but the last layer) qkv of layer l + 1 from the fresh rows while they are in the workgroup
@@ -368,8 +378,13 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
         if (G) tn[ntn++] = TnDesc{dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T};
         if (!fused) {
             // d x1 = dh W1 (split-K slabs) + dz2, consumed directly by the LN1 backward
-            splits = gemm_splitk_factor(T, E, F);
-            GF_TRY(launch_gemm_nn(dh, F, P + lo.w1, E, tmp, E, T, E, F, EPI_NONE, none, st, &splits, TE));
+            if (n100_supported(E, F) && !g_n100_off) {
+                splits = MAX_SPLITS;
+                GF_TRY(launch_gemm_n100(dh, F, P + lo.w1, E, 1, nullptr, tmp, TE, T, F, &splits, st));
+            } else {
+                splits = gemm_splitk_factor(T, E, F);
+                GF_TRY(launch_gemm_nn(dh, F, P + lo.w1, E, tmp, E, T, E, F, EPI_NONE, none, st, &splits, TE));
+            }
         }
         if (rc) {
             // LN1 backward + the out-proj dgrad (d_attn = dyB W_o) on the rows while they are in the workgroup
@@ -585,9 +600,22 @@ extern "C" int ganffn_ffn_linear1_fwd(const float* x, const float* w1, const flo
     e.bias = b1; e.p = p; e.site = site; e.rng = rng; e.rng_add = add; e.train = train;
     return launch_gemm_nt(x, E, w1, E, h, F, T, F, E, EPI_RELU_DROP, e, (hipStream_t)stream);
 }
+extern "C" int ganffn_gemm_n100(const float* A, const float* W, int w_kmajor, const float* bias, float* slabs, int64_t slab_stride,
+                                int T, int K, int max_slabs, int* n_slabs, void* stream) {
+    GF_CHECK_ARG(n_slabs && max_slabs >= 1 && max_slabs <= MAX_SPLITS, "gemm_n100: max_slabs=%d out of [1,%d]", max_slabs, MAX_SPLITS);
+    GF_CHECK_ARG(n100_supported(100, K), "gemm_n100: K=%d must be a multiple of 32, >= 256", K);
+    int s = max_slabs;
+    GF_TRY(launch_gemm_n100(A, K, W, w_kmajor ? 100 : K, w_kmajor, bias, slabs, (long)slab_stride, T, K, &s, (hipStream_t)stream));
+    *n_slabs = s;
+    return 0;
+}
+// lab only, deliberately NOT declared in include/ganffn.h: in-kernel time stamps of gemm_n100 (5 x uint64 per workgroup)
+extern "C" int ganffn_lab_set_n100_stamps(void* dev_buf) { g_n100_stamps = (unsigned long long*)dev_buf; return 0; }
 extern "C" int ganffn_debug_set_ffn_mode(int bits) {
     g_ffn_fused = (bits & 1) ? 1 : 0;
     g_rc_off = (bits & 2) ? 1 : 0;
+    g_n100_off = (bits & 4) ? 1 : 0;
+    g_n100_force_splits = (bits >> 8) & 0xFF;       // lab: force the K-chunk count of gemm_n100 (0 = choose)
     return 0;
 }
 extern "C" int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h,

@@ -275,6 +275,12 @@ int launch_ln_param_reduce(int n, float* const* gw, float* const* gb, const floa
                            hipStream_t st);
 int launch_add_inplace(float* a, const float* b, int64_t n, hipStream_t st);
 
+// gemm_n100.hip — [T x K] x [K x 100] with a long K on 16x16x4 MFMAs (112-wide feature tile), K cut into output slabs
+bool n100_supported(int N, int K);
+int n100_splits(int T, int K, int max_splits, int w_kmajor);
+int launch_gemm_n100(const float* A, int lda, const float* W, int ldw, int w_kmajor, const float* bias, float* C, long slab_stride,
+                     int T, int K, int* splits_io, hipStream_t st);
+
 // rowchain.hip — d_model 100: out-proj + residual + dropout + LayerNorm1, LayerNorm2 + the next layer's in-proj, and the
 // mirror-image backward chains, one kernel each (16 token rows per workgroup)
 bool rc_supported(int E);

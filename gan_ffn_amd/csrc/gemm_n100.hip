@@ -1,0 +1,242 @@
+// gemm_n100.hip — [T x K] x [K x 100] products with a long K (linear2 forward and the linear1 dgrad of the d_model-100
+// feed-forward block: K = 2048; /root/reference/model.py:1210 -> torch TransformerEncoderLayer._ff_block and its backward).
+//
+// Why its own kernel: on the generic 64 x 64 tiles (gemm.hip) a 100-wide output is two column tiles = 128 columns, 22 %
+// of every MFMA is padding, and the shape ran at 36-45 % of the fp32 MFMA peak (profiles/r02_*: 22 us at T = 3008, 35 us at
+// T = 6016 for 7.9 / 15.7 us of arithmetic).  Here:
+//  * v_mfma_f32_16x16x4_f32 (exact fp32) with the output FEATURE on the m axis: 100 features = 7 tiles of 16 = 112
+//    (10.7 % padding instead of 22 %);
+//  * a wave owns ALL 7 feature tiles of 16 tokens: the 7 MFMAs of a k-step share the token operand, 8 operand registers
+//    feed 7 MFMAs (the 32 x 32 single-accumulator wave tile of the generic kernel needs 2 per MFMA);
+//  * a workgroup = 4 waves = 64 tokens; K is cut into 4..16 chunks (one output slab each, summed in slab order by the
+//    LayerNorm-side consumer, rowchain.hip — no atomics); the chunk count is chosen so that the launch's waves fill the
+//    1024 SIMDs in whole rounds (n100_splits);
+//  * operands go through LDS in 32-wide K tiles, XOR-swizzled 16-byte slots (conflict-free ds_read_b128 fragment reads),
+//    double-buffered with one barrier per tile; a tile is 56 MFMAs per wave (~1800 cycles), which covers the global-load
+//    latency of the next tile with a 1-deep register prefetch;
+//  * the weight comes either as rows of K (NT: linear2's W2 [100 x K]) or K-major (NN: linear1's W1 [K x 100], read with
+//    ds_read_b32) — no transposed copy is made.
+// k order inside a 16-wide group: lane group g takes k = 16 q + 4 g + j at the j-th MFMA, identically for both operands and
+// for every token (a dialogue's bits do not depend on its batch position).
+#include "common.h"
+
+namespace ganffn {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NE = 100, NT7 = 7, NBK = 32, NBM = 64;
+constexpr int LDWK = 116;          // K-major weight tile [32][116]: rows 4 apart sit 16 banks apart (116 = 4 mod 8)
+
+// K-contiguous LDS tile [rows][32]: 16-byte slot s of row r at slot s ^ ((r / 2) % 8) (gemm.hip kc_off<32>)
+__device__ __forceinline__ int sw32(int row, int slot) { return row * NBK + 4 * (slot ^ ((row >> 1) & 7)); }
+
+struct N100Args {
+    const float* A; int lda;       // activations [T x K]
+    const float* W; int ldw;       // NT: [100 x K] rows of K;  NN: [K x 100] rows of 100
+    const float* bias;             // [100] or null; added by chunk 0
+    float* C; long slab_stride;    // C + z * slab_stride: [T x 100] partial product of K chunk z
+    int T, K, kchunk;
+    unsigned long long* stamps;    // lab only (null in the product): per workgroup {realtime at entry, cycles at entry, after the
+                                   // prologue, after the K loop, at exit}
+};
+
+template <bool WKMAJOR>
+__global__ __launch_bounds__(256) void gemm_n100_kernel(N100Args a) {
+    constexpr int WT = WKMAJOR ? NBK * LDWK : 112 * NBK;          // weight tile floats
+    constexpr int STAGE = WT + NBM * NBK;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 4];          // + a dump slot for the loaders' surplus vectors
+    constexpr int DUMP = 2 * STAGE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * NBM, z = blockIdx.y;
+    const int kbeg = z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+    const int nt = (kend - kbeg) / NBK;                           // K, kchunk multiples of 32
+    unsigned long long* const stamp = (a.stamps && tid == 0) ? a.stamps + 5 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
+    if (stamp) { stamp[0] = __builtin_amdgcn_s_memrealtime(); stamp[1] = __builtin_amdgcn_s_memtime(); }
+
+    // loader geometry (loop-invariant element offsets, clamped rows).  Activations: 64 rows x 8 slots = 512 float4, 2 per
+    // thread.  Weights: NT 112 rows x 8 slots = 896 float4 (rows >= 100 clamped: they feed discarded features), NN 32 k rows
+    // x 25 float4 = 800: 4 per thread, the last one partly surplus — a surplus vector is loaded from a clamped address and
+    // stored to the dump slot, so no load or LDS store sits under a condition.  Everything is a NAMED scalar / vector: hipcc
+    // keeps small arrays that live across the K loop in scratch memory.
+#define GF_N100_AIDX(J)                                                                                             \
+    const int ia##J = tid + 256 * J, rowa##J = ia##J >> 3, sla##J = ia##J & 7;                                      \
+    const uint32_t offa##J = (uint32_t)min(m0 + rowa##J, a.T - 1) * (uint32_t)a.lda + (uint32_t)(sla##J << 2);      \
+    const int ldsa##J = WT + sw32(rowa##J, sla##J);
+    GF_N100_AIDX(0) GF_N100_AIDX(1)
+#define GF_N100_WIDX(J)                                                                                             \
+    const int iw##J = tid + 256 * J;                                                                                \
+    const bool okw##J = iw##J < (WKMAJOR ? NBK * 25 : 112 * 8);                                                     \
+    const int icw##J = min(iw##J, (WKMAJOR ? NBK * 25 : 112 * 8) - 1);                                              \
+    const int rw##J = WKMAJOR ? icw##J / 25 : icw##J >> 3;                                                          \
+    const int cw##J = WKMAJOR ? (icw##J - rw##J * 25) << 2 : (icw##J & 7);                                          \
+    const uint32_t offw##J = WKMAJOR ? (uint32_t)rw##J * (uint32_t)a.ldw + (uint32_t)cw##J                          \
+                                     : (uint32_t)min(rw##J, NE - 1) * (uint32_t)a.ldw + (uint32_t)(cw##J << 2);     \
+    const int ldw_in##J = WKMAJOR ? rw##J * LDWK + cw##J : sw32(rw##J, cw##J);                                      \
+    const int ldsw0_##J = okw##J ? ldw_in##J : DUMP, ldsw1_##J = okw##J ? STAGE + ldw_in##J : DUMP;
+    GF_N100_WIDX(0) GF_N100_WIDX(1) GF_N100_WIDX(2) GF_N100_WIDX(3)
+    // two register sets (A: even tiles, B: odd tiles): the loads of tile t + 2 are issued at step t, so a tile has two
+    // steps (~3600 MFMA cycles) to arrive — with one step of cover a lone workgroup on a CU was load-latency-bound
+    float4 qaA0, qaA1, qwA0, qwA1, qwA2, qwA3, qaB0, qaB1, qwB0, qwB1, qwB2, qwB3;
+#define GF_N100_GLOAD(R, TT)                                                                                        \
+    {                                                                                                               \
+        const int k0 = kbeg + min((TT), nt - 1) * NBK; /* (a prefetch beyond the last tile re-reads it: never consumed) */ \
+        const float* Ak = a.A + k0;                                                                                 \
+        const float* Wk = WKMAJOR ? a.W + (size_t)k0 * a.ldw : a.W + k0;                                            \
+        qa##R##0 = *reinterpret_cast<const float4*>(Ak + offa0); qa##R##1 = *reinterpret_cast<const float4*>(Ak + offa1); \
+        qw##R##0 = *reinterpret_cast<const float4*>(Wk + offw0); qw##R##1 = *reinterpret_cast<const float4*>(Wk + offw1); \
+        qw##R##2 = *reinterpret_cast<const float4*>(Wk + offw2); qw##R##3 = *reinterpret_cast<const float4*>(Wk + offw3); \
+    }
+#define GF_N100_SSTORE(R, BUF)                                                                                      \
+    {                                                                                                               \
+        float* const sdst = smem + (BUF) * STAGE;                                                                   \
+        *reinterpret_cast<float4*>(sdst + ldsa0) = qa##R##0; *reinterpret_cast<float4*>(sdst + ldsa1) = qa##R##1;   \
+        *reinterpret_cast<float4*>(smem + ((BUF) ? ldsw1_0 : ldsw0_0)) = qw##R##0;                                  \
+        *reinterpret_cast<float4*>(smem + ((BUF) ? ldsw1_1 : ldsw0_1)) = qw##R##1;                                  \
+        *reinterpret_cast<float4*>(smem + ((BUF) ? ldsw1_2 : ldsw0_2)) = qw##R##2;                                  \
+        *reinterpret_cast<float4*>(smem + ((BUF) ? ldsw1_3 : ldsw0_3)) = qw##R##3;                                  \
+    }
+
+    floatx4 acc[NT7];
+#pragma unroll
+    for (int m = 0; m < NT7; ++m) acc[m] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    if (WKMAJOR) {
+        // columns 100 .. 111 of the K-major weight tile are never written by the loader: zero them once (both stages)
+        for (int i = tid; i < 2 * NBK * 12; i += 256) {
+            const int st = i / (NBK * 12), r = (i / 12) % NBK, cc = i % 12;
+            smem[st * STAGE + r * LDWK + NE + cc] = 0.f;
+        }
+    }
+    // one K tile from LDS stage BUF: all fragment reads, then its 56 MFMAs
+    auto compute = [&](const int buf) __attribute__((always_inline)) {
+        const float* s = smem + buf * STAGE;
+        const float* sa = s + WT;
+        float4 bx[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) bx[q] = *reinterpret_cast<const float4*>(sa + sw32(wave * 16 + c, 4 * q + g));
+        float wv[2][NT7][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int m = 0; m < NT7; ++m) {
+                if (WKMAJOR) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wv[q][m][j] = s[(16 * q + 4 * g + j) * LDWK + 16 * m + c];
+                } else {
+                    const float4 v = *reinterpret_cast<const float4*>(s + sw32(16 * m + c, 4 * q + g));
+                    wv[q][m][0] = v.x; wv[q][m][1] = v.y; wv[q][m][2] = v.z; wv[q][m][3] = v.w;
+                }
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float bq[4] = {bx[q].x, bx[q].y, bx[q].z, bx[q].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < NT7; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][m][j], bq[j], acc[m], 0, 0, 0);
+        }
+    };
+    GF_N100_GLOAD(A, 0)
+    GF_N100_GLOAD(B, 1)
+    GF_N100_SSTORE(A, 0)
+    __syncthreads();
+    if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
+
+    // steps in pairs: even tiles live in register set A / LDS stage 0, odd tiles in set B / stage 1.  The sched_barriers
+    // keep the global loads ahead of the MFMAs of the step they are issued in (hipcc sinks them to their use otherwise).
+    for (int t = 0; t < nt; t += 2) {
+        GF_N100_GLOAD(A, t + 2)
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nt) GF_N100_SSTORE(B, 1)
+        __syncthreads();
+        if (t + 1 < nt) {                                  // wave-uniform
+            GF_N100_GLOAD(B, t + 3)
+            __builtin_amdgcn_sched_barrier(0);
+            compute(1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < nt) GF_N100_SSTORE(A, 0)
+            __syncthreads();
+        }
+    }
+#undef GF_N100_GLOAD
+#undef GF_N100_SSTORE
+#undef GF_N100_AIDX
+#undef GF_N100_WIDX
+
+    if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
+    // epilogue: lane (c, g) holds token m0 + 16 wave + c, features 16 m + 4 g .. + 3
+    const int tok = m0 + wave * 16 + c;
+    if (tok < a.T) {
+        float* crow = a.C + (size_t)z * a.slab_stride + (size_t)tok * NE;
+#pragma unroll
+        for (int m = 0; m < NT7; ++m) {
+            const int f = 16 * m + 4 * g;
+            if (f < NE) {
+                float4 o = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+                if (a.bias != nullptr && z == 0) {
+                    const float4 b = *reinterpret_cast<const float4*>(a.bias + f);
+                    o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+                }
+                *reinterpret_cast<float4*>(crow + f) = o;
+            }
+        }
+    }
+    if (stamp) stamp[4] = __builtin_amdgcn_s_memtime();
+}
+
+}  // namespace
+
+int g_n100_force_splits = 0;      // lab knob (ganffn_debug_set_ffn_mode bits 8..15): 0 = choose
+unsigned long long* g_n100_stamps = nullptr;   // lab knob (ganffn_lab_set_n100_stamps): device buffer for in-kernel time stamps
+
+bool n100_supported(int N, int K) { return N == NE && K >= 256 && (K % NBK) == 0; }
+
+// K chunks (= output slabs, <= max_splits).  Measured on MI355X (tools/lab/n100_lab.py, n100_stamps.py; K = 2048):
+//  * the K loop runs at 69 % MFMA utilisation with one workgroup per CU, 85 % with two, 94 % with three (in-kernel stamps),
+//    but every co-resident workgroup adds its prologue, and every slab is read again by the consumer;
+//  * rows-of-K weights: T = 3008: 5 / 10 / 16 chunks 18.7 / 18.9 / 19.0 us (flat: take the fewest slabs); T = 6016: 5 / 8 / 16
+//    chunks 30.0 / 29.8 / 32.9 us;
+//  * K-major weights (58 LDS reads per tile instead of 16): T = 3008: 5 / 10 / 16 chunks 22.7 / 20.1 / 18.3 us — co-residency
+//    pays; T = 6016: 5 / 8 / 16 chunks 32.3 / 30.6 / 33.2 us.
+// Rule: rows-of-K: the launch's waves (4 per 64 tokens and chunk) fill the 1024 SIMDs in whole rounds, a round costs the
+// chunk's K tiles, fewer slabs win ties; K-major: the same with rounds of 3 workgroups per CU (768 workgroups).
+int n100_splits(int T, int K, int max_splits, int w_kmajor) {
+    if (g_n100_force_splits > 0) return g_n100_force_splits < max_splits ? g_n100_force_splits : max_splits;
+    const int tiles_m = (T + NBM - 1) / NBM, ksteps = K / NBK;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= max_splits && s <= ksteps; ++s) {
+        const int per = (ksteps + s - 1) / s;
+        if ((s - 1) * per >= ksteps) continue;                       // an empty last chunk
+        const long wgs = (long)tiles_m * s;
+        const long rounds = w_kmajor ? (wgs + 767) / 768 : (wgs * 4 + 1023) / 1024;
+        const double cost = (double)rounds * per + (w_kmajor ? 0.02 : 0.15) * s;
+        if (cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
+// C slabs = A[T x K] . W^T (w_kmajor == 0: W [100 x K]) or A . W (w_kmajor == 1: W [K x 100]); *splits_io: in = cap, out = slabs written
+int launch_gemm_n100(const float* A, int lda, const float* W, int ldw, int w_kmajor, const float* bias, float* C, long slab_stride,
+                     int T, int K, int* splits_io, hipStream_t st) {
+    GF_CHECK_ARG(A && W && C && splits_io && T > 0 && n100_supported(NE, K), "gemm_n100: bad arguments (K=%d)", K);
+    GF_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(C) && (lda & 3) == 0 && (ldw & 3) == 0 && (slab_stride & 3) == 0 &&
+                     (!bias || aligned16(bias)), "gemm_n100: operands must be 16-byte aligned");
+    const int ksteps = K / NBK;
+    int s = n100_splits(T, K, *splits_io < 1 ? 1 : *splits_io, w_kmajor);
+    const int per = (ksteps + s - 1) / s;
+    s = (ksteps + per - 1) / per;
+    *splits_io = s;
+    N100Args a{A, lda, W, ldw, bias, C, slab_stride, T, K, per * NBK, g_n100_stamps};
+    const dim3 grid((T + NBM - 1) / NBM, s), blk(256);
+    if (w_kmajor) hipLaunchKernelGGL((gemm_n100_kernel<true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((gemm_n100_kernel<false>), grid, blk, 0, st, a);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ganffn

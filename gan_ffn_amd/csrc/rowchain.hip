@@ -9,22 +9,30 @@
 // As separate launches these were a [T x 100] x [100 x 100] GEMM (2 x 47 = 94 workgroups on 256 CUs), a [T x 100] x
 // [100 x 300] GEMM (235 workgroups) and a LayerNorm pass each: 5-12 us launch floors, ~18 % of the GPU time of a
 // d_model-100 pass for ~3 % of its FLOPs (profiles/r02_bench_streams1_by_launch_shape.txt).  Here a workgroup owns 16
-// token rows and runs the whole chain for them: the small GEMMs on v_mfma_f32_16x16x4_f32 (exact fp32) with the
-// weights read straight from L2 into the B-operand layout, the LayerNorm statistics by a 16-lane reduce + one LDS
-// exchange between the 4 waves, the row tile handed from the LayerNorm stage to the following GEMM through LDS.
-// 4 of the 9 (forward) / 9 (backward) launches of a layer disappear.
+// token rows and runs the whole chain for them: the small GEMMs on v_mfma_f32_16x16x4_f32 (exact fp32) with the weights
+// read straight from L2 into the operand layout, the LayerNorm statistics by two shuffles + one LDS exchange between the
+// 4 waves, the row tile handed from the LayerNorm stage to the following GEMM through LDS.  4 of the 9 launches of a
+// layer disappear in each direction.
 //
-// MFMA layout (v_mfma_f32_16x16x4_f32; lane = 16 g + c):  A: lane holds A[row c][k = g], B: lane holds B[k = g][col c],
-// D register r of the lane = D[row 4 g + r][col c].  Rows = the 16 tokens of the workgroup, columns = 16 output
-// features of one column tile: a lane owns 4 CONSECUTIVE TOKENS of one column — exactly one Philox call (common.h
-// drop_mult4: 4 consecutive rows of a column), and the layout of the 32x32 GEMM epilogues elsewhere.
-// k order: lane group g takes k = 16 q + 4 g + j for the j-th MFMA of group q (one 16-byte load per operand and group);
-// the same permutation on A and B, and the same for every row, so a dialogue's bits do not depend on its position in
-// the batch (tests/test_hip_properties.py::test_full_size_batch_permutation...).
-// The 4 waves split the column tiles (wave w owns tiles w, w + 4, ...); a tile beyond the last one is computed on a
-// clamped copy and discarded, so no MFMA sits under a run-time condition.
-// Deterministic: no atomics; the LayerNorm parameter gradients leave as per-workgroup partial rows that
-// ln_param_reduce_kernel (elementwise.hip) adds in block order.
+// These kernels are LATENCY-sized (188-376 workgroups, < 1 wave per SIMD), so they are written for few dependent round
+// trips and few memory instructions:
+//  * MFMA orientation: D[m][n] with m = output FEATURE, n = TOKEN.  Lane (c, g) (lane = 16 g + c) supplies A[m = c][k = g]
+//    (a weight row) and B[k = g][n = c] (a token row) and receives D[m = 4 g + r][n = c], r = 0..3: one token, 4 CONSECUTIVE
+//    features — every global access of the element-wise part (slabs, residual, outputs) is one 16-byte access per lane;
+//  * k order: lane group g takes k = 16 q + 4 g + j for the j-th MFMA of group q (one 16-byte load per operand and group),
+//    the same permutation on both operands and the same for every token, so a dialogue's bits do not depend on its
+//    position in the batch (tests/test_hip_properties.py::test_full_size_batch_permutation...);
+//  * every load that does not depend on computed data (weights of BOTH GEMM stages, slabs, residual, LayerNorm
+//    parameters) is issued before the first wait;
+//  * the 4 waves split the 7 feature tiles of a 100-wide row (wave w owns tiles w and w + 4; a tile beyond the last is
+//    computed on a clamped copy and discarded, so no MFMA sits under a run-time condition); the K = 300 product of the
+//    in-proj dgrad is split over the waves along K instead (each wave: all 7 tiles, a quarter of K; partial tiles are
+//    summed through LDS in wave order) so that its 54 operand loads per lane are one round trip;
+//  * dropout: the Philox contract is "one call = 4 consecutive TOKENS of one column" (common.h drop_mult4); lane ql of a
+//    quad (4 consecutive tokens, same features) evaluates the call of feature f0 + ql and the quad exchanges keep bits
+//    by DPP — one call per tile and lane, as in the GEMM epilogues.
+// Deterministic: no atomics; the LayerNorm parameter gradients leave as per-workgroup partial rows (summed over the 16
+// tokens in token order) that ln_param_reduce_kernel (elementwise.hip) adds in block order.
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -36,12 +44,13 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int RE = 100;              // d_model handled here
-constexpr int RT = (RE + 15) / 16;   // 7 column tiles of 16 over a 100-wide row
-constexpr int LDX = 116;             // LDS row stride of the 16 x 100 row tile handed to the trailing GEMM (zero-padded to 112)
+constexpr int RT = (RE + 15) / 16;   // 7 feature tiles of 16 over a 100-wide row
+constexpr int LDX = 116;             // LDS row stride of a 16 x 100 row tile (zero-padded to 112 columns)
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-// one lane's A or B fragments for K (a multiple of 4) from a K-contiguous row: group q = floats 16 q + 4 g .. + 3
+// one lane's operand fragments over K (a multiple of 4) from a K-contiguous row: group q = floats 16 q + 4 g .. + 3
 template <int K>
 struct Frag {
     static constexpr int KQ = (K + 15) / 16;
@@ -50,87 +59,57 @@ struct Frag {
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
             const int col = 16 * q + 4 * g;
-            const float4 t = *reinterpret_cast<const float4*>(row + min(col, K - 4));
+            const float4 t = f4(row + min(col, K - 4));
             v[q] = (16 * q + 12 < K || col < K) ? t : zero4();     // compile-time true except in the last group
         }
     }
 };
 
-// acc[i] += (this workgroup's 16 rows) x (W rows 16 nt_i + c)^T over K; wrow[i] = the lane's row of W for tile i.
-// B fragments are loaded CH groups at a time for all NI tiles, then the MFMAs of those groups run interleaved over the
-// tiles (independent accumulator chains).
+// acc[i] += W_i (16 features x K) . X^T (K x 16 tokens) for NI feature tiles; interleaved accumulator chains
 template <int K, int NI>
-__device__ __forceinline__ void gemm16(floatx4 (&acc)[NI], const Frag<K>& a, const float* const* wrow, int g) {
-    constexpr int KQ = Frag<K>::KQ;
-    constexpr int CH = (KQ * NI <= 16) ? KQ : (NI >= 3 ? 4 : 5);
+__device__ __forceinline__ void mma(floatx4 (&acc)[NI], const Frag<K> (&wf)[NI], const Frag<K>& xf) {
 #pragma unroll
-    for (int q0 = 0; q0 < KQ; q0 += CH) {
-        float4 b[NI][CH];
+    for (int q = 0; q < Frag<K>::KQ; ++q) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].v[q].x, xf.v[q].x, acc[i], 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int q = q0 + u;
-                if (q < KQ) {
-                    const int col = 16 * q + 4 * g;
-                    const float4 t = *reinterpret_cast<const float4*>(wrow[i] + min(col, K - 4));
-                    b[i][u] = (16 * q + 12 < K || col < K) ? t : zero4();
-                } else {
-                    b[i][u] = zero4();
-                }
-            }
+        for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].v[q].y, xf.v[q].y, acc[i], 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            if (q0 + u < KQ) {
-                const float4 av = a.v[q0 + u];
+        for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].v[q].z, xf.v[q].z, acc[i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b[i][u].x, acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b[i][u].y, acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b[i][u].z, acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b[i][u].w, acc[i], 0, 0, 0);
-            }
-        }
+        for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].v[q].w, xf.v[q].w, acc[i], 0, 0, 0);
     }
 }
 
-// sum over the 16 lanes of a lane group (same g): the 16 columns of a tile
-__device__ __forceinline__ float group16_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    return v;
+template <int R>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {          // value of lane R of this lane's quad (DPP quad_perm)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, R * 0x55, 0xF, 0xF, true);
 }
 
-// per-token sums of the 4 waves' partial row sums: part[r] (token 4 g + r, this wave's columns) -> the full row sum
-// (fixed order w = 0..3).  red: [4 waves][16 tokens], one buffer per exchange of a kernel (no barrier needed before the
-// write: a buffer is written once); one barrier inside.
-__device__ __forceinline__ void rows_allreduce(float (&part)[4], float* __restrict__ red, int w, int c, int g) {
+// dropout multipliers of (this lane's token, features f0 .. f0 + 3): lane ql of the quad evaluates the Philox call of
+// feature f0 + ql (4 consecutive tokens = the quad) and the keep bits are exchanged inside the quad
+__device__ __forceinline__ void drop_mult_quad(const DropCtx& dc, uint32_t rowgroup, int f0, int ql, float (&m)[4]) {
+    if (!dc.on) {
+        m[0] = m[1] = m[2] = m[3] = 1.f;
+        return;
+    }
+    uint32_t wd[4];
+    philox4(rowgroup * (uint32_t)RE + (uint32_t)(f0 + ql), dc.site, dc.o0, dc.o1, dc.k0, dc.k1, wd);
+    uint32_t mine = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) part[r] = group16_sum(part[r]);
-    if (c == 0) *reinterpret_cast<float4*>(red + w * 16 + 4 * g) = make_float4(part[0], part[1], part[2], part[3]);
-    __syncthreads();
+    for (int j = 0; j < 4; ++j) mine |= (wd[j] >= dc.thr ? 1u : 0u) << j;
+    const uint32_t b[4] = {quad_bcast<0>(mine), quad_bcast<1>(mine), quad_bcast<2>(mine), quad_bcast<3>(mine)};
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        part[r] = ((red[0 * 16 + 4 * g + r] + red[1 * 16 + 4 * g + r]) + red[2 * 16 + 4 * g + r]) + red[3 * 16 + 4 * g + r];
+    for (int r = 0; r < 4; ++r) m[r] = ((b[r] >> ql) & 1u) ? dc.scale : 0.f;
 }
-// two row sums in one exchange (red: [2][4 waves][16 tokens])
-__device__ __forceinline__ void rows_allreduce2(float (&pa)[4], float (&pb)[4], float* __restrict__ red, int w, int c, int g) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { pa[r] = group16_sum(pa[r]); pb[r] = group16_sum(pb[r]); }
-    if (c == 0) {
-        *reinterpret_cast<float4*>(red + w * 16 + 4 * g) = make_float4(pa[0], pa[1], pa[2], pa[3]);
-        *reinterpret_cast<float4*>(red + 64 + w * 16 + 4 * g) = make_float4(pb[0], pb[1], pb[2], pb[3]);
-    }
+
+// per-token sum over the 4 lane groups of a wave (this wave's features), then over the 4 waves through LDS (fixed order)
+__device__ __forceinline__ float token_allreduce(float v, float* __restrict__ red, int w, int c, int g) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (g == 0) red[w * 16 + c] = v;
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        pa[r] = ((red[0 * 16 + 4 * g + r] + red[1 * 16 + 4 * g + r]) + red[2 * 16 + 4 * g + r]) + red[3 * 16 + 4 * g + r];
-        pb[r] = ((red[64 + 0 * 16 + 4 * g + r] + red[64 + 1 * 16 + 4 * g + r]) + red[64 + 2 * 16 + 4 * g + r]) + red[64 + 3 * 16 + 4 * g + r];
-    }
+    return ((red[c] + red[16 + c]) + red[32 + c]) + red[48 + c];
 }
 
 struct RcFwdArgs {
@@ -148,157 +127,159 @@ struct RcFwdArgs {
 // z = x + dropout(y); out = LayerNorm(z); optionally the next layer's in-proj on the fresh rows
 template <bool PRE_GEMM, bool POST_GEMM>
 __global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[2 * 4 * 16];
+    constexpr int NP = 3 * RE, PT = (NP + 15) / 16;     // in-proj: 300 output features, 19 tiles
+    __shared__ __attribute__((aligned(16))) float red[2 * 64];
     __shared__ __attribute__((aligned(16))) float xs[POST_GEMM ? 16 * LDX : 4];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int t0 = blockIdx.x * 16;
-    const int T = a.T;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4, ql = c & 3;
+    const int t0 = blockIdx.x * 16, T = a.T;
+    const bool tok = t0 + c < T;
+    const size_t trow = (size_t)min(t0 + c, T - 1);
     const DropCtx dc = make_drop(a.rng, a.add, a.site, a.p, a.train);
 
-    // this wave's column tiles: w and w + 4 (tile 7 does not exist: wave 3 recomputes tile 6 and discards it)
-    int nt[2], col[2], colc[2];
-    bool cok[2];
+    // this wave's feature tiles: w and w + 4 (tile 7 does not exist: wave 3 recomputes tile 6 and discards it)
+    int mt[2], f0[2], f0c[2];
+    bool fok[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        nt[i] = w + 4 * i;
-        const bool tile_ok = nt[i] < RT;
-        col[i] = 16 * min(nt[i], RT - 1) + c;
-        cok[i] = tile_ok && col[i] < RE;
-        colc[i] = min(col[i], RE - 1);
-    }
-    size_t roff[4];                      // clamped row offsets (in rows) of this lane's 4 tokens
-    bool rok[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        rok[r] = t0 + 4 * g + r < T;
-        roff[r] = (size_t)min(t0 + 4 * g + r, T - 1);
+        mt[i] = min(w + 4 * i, RT - 1);
+        f0[i] = 16 * mt[i] + 4 * g;
+        fok[i] = (w + 4 * i < RT) && f0[i] < RE;
+        f0c[i] = min(f0[i], RE - 4);
     }
 
-    // ---------------- leading stage ----------------
-    float y[2][4];
+    // ---------------- every independent load, up front ----------------
+    Frag<RE> wpost[3];                   // trailing GEMM, tiles w, w + 4, w + 8 (all < 19)
+    if constexpr (POST_GEMM) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) wpost[j].load(a.post_w + (size_t)min(16 * (w + 4 * j) + c, NP - 1) * RE, g);
+    }
+    Frag<RE> xf, wf[2];
+    float4 bias[2], ysum[2];
     if constexpr (PRE_GEMM) {
-        Frag<RE> af;
-        af.load(a.pre_a + (size_t)min(t0 + c, T - 1) * RE, g);
-        const float* const wrow[2] = {a.pre_w + (size_t)colc[0] * RE, a.pre_w + (size_t)colc[1] * RE};
-        floatx4 acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
-        gemm16<RE, 2>(acc, af, wrow, g);
+        xf.load(a.pre_a + trow * RE, g);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float bias = a.pre_b[colc[i]];
+            wf[i].load(a.pre_w + (size_t)min(16 * mt[i] + c, RE - 1) * RE, g);
+            bias[i] = f4(a.pre_b + f0c[i]);
+        }
+    }
+    float4 xv[2], gam[2], bet[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[i][r] = acc[i][r] + bias;
+    for (int i = 0; i < 2; ++i) {
+        xv[i] = f4(a.x + trow * RE + f0c[i]);
+        gam[i] = f4(a.gamma + f0c[i]);
+        bet[i] = f4(a.beta + f0c[i]);
+        ysum[i] = zero4();
+    }
+    if constexpr (!PRE_GEMM) {
+        for (int s0 = 0; s0 < a.nslab; s0 += 8) {            // 8 slabs' loads in flight at a time, added in slab order
+            float4 v[8][2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float* ys = a.y + (size_t)min(s0 + j, a.nslab - 1) * a.slab_stride + trow * RE;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) v[j][i] = f4(ys + f0c[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float m = (s0 + j < a.nslab) ? 1.f : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ysum[i].x = __fmaf_rn(m, v[j][i].x, ysum[i].x); ysum[i].y = __fmaf_rn(m, v[j][i].y, ysum[i].y);
+                    ysum[i].z = __fmaf_rn(m, v[j][i].z, ysum[i].z); ysum[i].w = __fmaf_rn(m, v[j][i].w, ysum[i].w);
+                }
+            }
+        }
+    }
+
+    __builtin_amdgcn_sched_barrier(0);   // (keep the loads above ahead of everything below: one round trip)
+
+    // ---------------- leading GEMM ----------------
+    float y[2][4];
+    if constexpr (PRE_GEMM) {
+        floatx4 acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+        mma<RE, 2>(acc, wf, xf);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            y[i][0] = acc[i][0] + bias[i].x; y[i][1] = acc[i][1] + bias[i].y;
+            y[i][2] = acc[i][2] + bias[i].z; y[i][3] = acc[i][3] + bias[i].w;
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y[i][r] = 0.f;
-        for (int s0 = 0; s0 < a.nslab; s0 += 4) {           // 4 slabs' loads in flight at a time, added in slab order
-            float v[4][2][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float* ys = a.y + (size_t)min(s0 + j, a.nslab - 1) * a.slab_stride;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[j][i][r] = ys[roff[r] * RE + colc[i]];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float m = (s0 + j < a.nslab) ? 1.f : 0.f;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) y[i][r] = __fmaf_rn(m, v[j][i][r], y[i][r]);
-            }
-        }
+        for (int i = 0; i < 2; ++i) { y[i][0] = ysum[i].x; y[i][1] = ysum[i].y; y[i][2] = ysum[i].z; y[i][3] = ysum[i].w; }
     }
 
     // ---------------- residual + dropout + LayerNorm ----------------
-    float z[2][4], gam[2], bet[2];
-    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    float z[2][4];
+    float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        gam[i] = a.gamma[colc[i]];
-        bet[i] = a.beta[colc[i]];
-        float xv[4], mult[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xv[r] = a.x[roff[r] * RE + colc[i]];
-        drop_mult4(dc, (uint32_t)(t0 / 4 + g), (uint32_t)RE, (uint32_t)colc[i], mult);
+        float mult[4];
+        drop_mult_quad(dc, (uint32_t)(t0 / 4 + (c >> 2)), f0c[i], ql, mult);
+        const float xr[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            z[i][r] = cok[i] ? __fmaf_rn(y[i][r], mult[r], xv[r]) : 0.f;
-            sum[r] += z[i][r];
+            z[i][r] = fok[i] ? __fmaf_rn(y[i][r], mult[r], xr[r]) : 0.f;
+            sum += z[i][r];
         }
     }
-    rows_allreduce(sum, red, w, c, g);
     const float invE = 1.0f / (float)RE;
-    float mean[4], var[4] = {0.f, 0.f, 0.f, 0.f}, rs[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) mean[r] = sum[r] * invE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float d = cok[i] ? __fsub_rn(z[i][r], mean[r]) : 0.f;
-            var[r] = __fmaf_rn(d, d, var[r]);
-        }
-    rows_allreduce(var, red + 64, w, c, g);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) rs[r] = rsqrtf(var[r] * invE + a.eps);
+    const float mean = token_allreduce(sum, red, w, c, g) * invE;
+    float var = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float xh = __fmul_rn(__fsub_rn(z[i][r], mean[r]), rs[r]);
-            const float o = __fmaf_rn(xh, gam[i], bet[i]);
-            if (cok[i] && rok[r]) {
-                const size_t off = roff[r] * RE + col[i];
-                if (a.xhat) a.xhat[off] = xh;
-                a.out[off] = o;
-            }
-            if constexpr (POST_GEMM) {
-                // row tile -> LDS for the trailing GEMM; columns 100 .. 111 zero (tile 6's lanes c >= 4)
-                if (nt[i] < RT) xs[(4 * g + r) * LDX + 16 * nt[i] + c] = cok[i] ? o : 0.f;
-            }
+            const float d = fok[i] ? __fsub_rn(z[i][r], mean) : 0.f;
+            var = __fmaf_rn(d, d, var);
         }
-    if (a.rstd && w == 0 && c == 0) {
+    const float rs = rsqrtf(token_allreduce(var, red + 64, w, c, g) * invE + a.eps);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (rok[r]) a.rstd[t0 + 4 * g + r] = rs[r];
+    for (int i = 0; i < 2; ++i) {
+        const float gm[4] = {gam[i].x, gam[i].y, gam[i].z, gam[i].w}, bt[4] = {bet[i].x, bet[i].y, bet[i].z, bet[i].w};
+        float xh[4], o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xh[r] = __fmul_rn(__fsub_rn(z[i][r], mean), rs);
+            o[r] = __fmaf_rn(xh[r], gm[r], bt[r]);
+        }
+        if (fok[i] && tok) {
+            const size_t off = trow * RE + f0[i];
+            if (a.xhat) *reinterpret_cast<float4*>(a.xhat + off) = make_float4(xh[0], xh[1], xh[2], xh[3]);
+            *reinterpret_cast<float4*>(a.out + off) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        if constexpr (POST_GEMM) {
+            // row tile -> LDS for the trailing GEMM; columns 100 .. 111 zero (tile 6's lane groups g >= 1)
+            if (w + 4 * i < RT)
+                *reinterpret_cast<float4*>(xs + c * LDX + f0[i]) = fok[i] ? make_float4(o[0], o[1], o[2], o[3]) : zero4();
+        }
     }
+    if (a.rstd && w == 0 && g == 0 && tok) a.rstd[t0 + c] = rs;
 
-    // ---------------- trailing stage: in-proj of the next layer ----------------
+    // ---------------- trailing GEMM: in-proj of the next layer ----------------
     if constexpr (POST_GEMM) {
-        constexpr int NP = 3 * RE, PT = (NP + 15) / 16;     // 300 output features, 19 tiles
+        // second tile group (w + 12, w + 16) in flight while the first one multiplies
+        Frag<RE> wpost2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wpost2[j].load(a.post_w + (size_t)min(16 * (w + 12 + 4 * j) + c, NP - 1) * RE, g);
+        float4 pb[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) pb[j] = f4(a.post_b + min(16 * (w + 4 * j) + 4 * g, NP - 4));
         __syncthreads();
-        Frag<RE> af;                                        // rows beyond 100 columns read the zero padding
+        Frag<RE> af;                                        // (columns 100 .. 111 of the tile are the zero padding)
 #pragma unroll
-        for (int q = 0; q < Frag<RE>::KQ; ++q) af.v[q] = *reinterpret_cast<const float4*>(xs + c * LDX + 16 * q + 4 * g);
-        // wave w: tiles w, w + 4, w + 8 then w + 12, w + 16 (clamped duplicates beyond tile 18 are discarded)
+        for (int q = 0; q < Frag<RE>::KQ; ++q) af.v[q] = f4(xs + c * LDX + 16 * q + 4 * g);
+        floatx4 acc[3] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+        mma<RE, 3>(acc, wpost, af);
+        floatx4 acc2[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+        mma<RE, 2>(acc2, wpost2, af);
 #pragma unroll
-        for (int grp = 0; grp < 2; ++grp) {
-            constexpr int NI0 = 3;
-            const int ni = grp == 0 ? 3 : 2;
-            int pn[NI0];
-            const float* wrow[NI0];
-            floatx4 acc[NI0];
-#pragma unroll
-            for (int i = 0; i < NI0; ++i) {
-                const int tile = w + 4 * (3 * grp + i);
-                pn[i] = (i < ni && tile < PT) ? 16 * tile + c : -1;
-                wrow[i] = a.post_w + (size_t)min(max(pn[i], 0), NP - 1) * RE;
-                acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-            }
-            gemm16<RE, NI0>(acc, af, wrow, g);
-#pragma unroll
-            for (int i = 0; i < NI0; ++i) {
-                const bool ok = pn[i] >= 0 && pn[i] < NP;
-                const float bias = a.post_b[min(max(pn[i], 0), NP - 1)];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (ok && rok[r]) a.post_out[roff[r] * NP + pn[i]] = acc[i][r] + bias;
-            }
+        for (int j = 0; j < 5; ++j) {
+            const int pf = 16 * (w + 4 * j) + 4 * g;        // (tile 19 = wave 3's fifth: beyond the matrix, discarded)
+            const floatx4 r4 = j < 3 ? acc[j] : acc2[j - 3];
+            if (tok && (w + 4 * j) < PT && pf < NP)
+                *reinterpret_cast<float4*>(a.post_out + trow * NP + pf) =
+                    make_float4(r4[0] + pb[j].x, r4[1] + pb[j].y, r4[2] + pb[j].z, r4[3] + pb[j].w);
         }
     }
 }
@@ -318,139 +299,184 @@ struct RcBwdArgs {
 // PRE: 0 = d_out is one tensor, 1 = d_out is nslab partial slabs, 2 = d = pre_a . pre_wt^T (K = 3E)
 template <int PRE, bool POST_GEMM>
 __global__ __launch_bounds__(256) void rc_bwd_kernel(RcBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[2 * 4 * 16];
+    constexpr int K3 = 3 * RE, KQ3 = (K3 + 15) / 16, NQW = (KQ3 + 3) / 4;      // 19 k groups, <= 5 per wave
+    constexpr int LDP = 112;
+    // pp: PRE = 2: the waves' partial tiles [4][7][64] float4; afterwards (all kernels) the two 16 x 112 tiles whose column
+    // sums are the LayerNorm parameter gradients
+    __shared__ __attribute__((aligned(16))) float pp[PRE == 2 ? 4 * RT * 64 * 4 : 2 * 16 * LDP];
+    __shared__ __attribute__((aligned(16))) float red[2 * 64];
     __shared__ __attribute__((aligned(16))) float xs[POST_GEMM ? 16 * LDX : 4];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int t0 = blockIdx.x * 16;
-    const int T = a.T;
+    static_assert(4 * RT * 64 * 4 >= 2 * 16 * LDP, "pp must hold the two gradient tiles");
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4, ql = c & 3;
+    const int t0 = blockIdx.x * 16, T = a.T;
+    const bool tok = t0 + c < T;
+    const size_t trow = (size_t)min(t0 + c, T - 1);
     const DropCtx dc = make_drop(a.rng, a.add, a.site, a.p, a.train);
-    int nt[2], col[2], colc[2];
-    bool cok[2];
+    int mt[2], f0[2], f0c[2];
+    bool fok[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        nt[i] = w + 4 * i;
-        col[i] = 16 * min(nt[i], RT - 1) + c;
-        cok[i] = nt[i] < RT && col[i] < RE;
-        colc[i] = min(col[i], RE - 1);
-    }
-    size_t roff[4];
-    bool rok[4];
-    float rs[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        rok[r] = t0 + 4 * g + r < T;
-        roff[r] = (size_t)min(t0 + 4 * g + r, T - 1);
-        rs[r] = a.rstd[roff[r]];
+        mt[i] = min(w + 4 * i, RT - 1);
+        f0[i] = 16 * mt[i] + 4 * g;
+        fok[i] = (w + 4 * i < RT) && f0[i] < RE;
+        f0c[i] = min(f0[i], RE - 4);
     }
 
-    float d[2][4], xh[2][4];
+    // ---------------- every independent load, up front ----------------
+    Frag<RE> wpost[2];
+    if constexpr (POST_GEMM) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) wpost[i].load(a.post_wt + (size_t)min(16 * mt[i] + c, RE - 1) * RE, g);
+    }
+    float4 xh4[2], d4[2], gam[2];
+    const float rs = a.rstd[trow];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            xh[i][r] = a.xhat[roff[r] * RE + colc[i]];
-            d[i][r] = a.addend ? a.addend[roff[r] * RE + colc[i]] : 0.f;
-        }
+    for (int i = 0; i < 2; ++i) {
+        xh4[i] = f4(a.xhat + trow * RE + f0c[i]);
+        gam[i] = f4(a.gamma + f0c[i]);
+        d4[i] = a.addend ? f4(a.addend + trow * RE + f0c[i]) : zero4();
+    }
     if constexpr (PRE == 2) {
-        constexpr int K3 = 3 * RE;
-        Frag<K3> af;
-        af.load(a.pre_a + (size_t)min(t0 + c, T - 1) * K3, g);
-        const float* const wrow[2] = {a.pre_wt + (size_t)colc[0] * K3, a.pre_wt + (size_t)colc[1] * K3};
-        floatx4 acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
-        gemm16<K3, 2>(acc, af, wrow, g);
+        // K split over the waves: wave w takes k groups w, w + 4, ... of the 19 for ALL 7 feature tiles
+        float4 xq[NQW], wq[RT][NQW];
+#pragma unroll
+        for (int u = 0; u < NQW; ++u) {
+            const int q = w + 4 * u, col = 16 * q + 4 * g;
+            const bool ok = q < KQ3 && col < K3;
+            const int colc = min(col, K3 - 4);
+            const float4 tx = f4(a.pre_a + trow * K3 + colc);
+            xq[u] = ok ? tx : zero4();
+#pragma unroll
+            for (int m = 0; m < RT; ++m) {
+                const float4 tw = f4(a.pre_wt + (size_t)min(16 * m + c, RE - 1) * K3 + colc);
+                wq[m][u] = ok ? tw : zero4();
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // all 40 operand loads in flight before the first MFMA waits for one
+        floatx4 acc[RT];
+#pragma unroll
+        for (int m = 0; m < RT; ++m) acc[m] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NQW; ++u) {
+#pragma unroll
+            for (int m = 0; m < RT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[m][u].x, xq[u].x, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < RT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[m][u].y, xq[u].y, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < RT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[m][u].z, xq[u].z, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < RT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[m][u].w, xq[u].w, acc[m], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < RT; ++m)
+            *reinterpret_cast<float4*>(pp + ((w * RT + m) * 64 + lane) * 4) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d[i][r] += acc[i][r];
+            for (int ww = 0; ww < 4; ++ww) {                 // partial tiles in wave order
+                const float4 v = f4(pp + ((ww * RT + mt[i]) * 64 + lane) * 4);
+                d4[i].x += v.x; d4[i].y += v.y; d4[i].z += v.z; d4[i].w += v.w;
+            }
     } else {
         const int ns = PRE == 1 ? a.nslab : 1;
-        constexpr int NB = PRE == 1 ? 4 : 1;                // slabs in flight together; added in slab order
+        constexpr int NB = PRE == 1 ? 8 : 1;                // slabs in flight together; added in slab order
         for (int s0 = 0; s0 < ns; s0 += NB) {
-            float v[NB][2][4];
+            float4 v[NB][2];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const float* ds = a.d_out + (size_t)min(s0 + j, ns - 1) * a.slab_stride;
+                const float* ds = a.d_out + (size_t)min(s0 + j, ns - 1) * a.slab_stride + trow * RE;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[j][i][r] = ds[roff[r] * RE + colc[i]];
+                for (int i = 0; i < 2; ++i) v[j][i] = f4(ds + f0c[i]);
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const float m = (s0 + j < ns) ? 1.f : 0.f;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) d[i][r] += m * v[j][i][r];
+                for (int i = 0; i < 2; ++i) {
+                    d4[i].x += m * v[j][i].x; d4[i].y += m * v[j][i].y; d4[i].z += m * v[j][i].z; d4[i].w += m * v[j][i].w;
+                }
             }
         }
     }
 
     // g = d * gamma; dz = rstd * (g - mean(g) - xhat * mean(g * xhat))
-    float gv[2][4], aw[2], ab[2];
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float dd[2][4], xh[2][4], gv[2][4];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const float gam = a.gamma[colc[i]];
-        aw[i] = 0.f; ab[i] = 0.f;
+        const float dr[4] = {d4[i].x, d4[i].y, d4[i].z, d4[i].w}, hr[4] = {xh4[i].x, xh4[i].y, xh4[i].z, xh4[i].w};
+        const float gm[4] = {gam[i].x, gam[i].y, gam[i].z, gam[i].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool ok = cok[i] && rok[r];
-            const float dd = ok ? d[i][r] : 0.f, h = ok ? xh[i][r] : 0.f;
-            xh[i][r] = h;
-            aw[i] += dd * h;
-            ab[i] += dd;
-            gv[i][r] = dd * gam;
-            s1[r] += gv[i][r];
-            s2[r] += gv[i][r] * h;
+            const bool ok = fok[i] && tok;
+            dd[i][r] = ok ? dr[r] : 0.f;
+            xh[i][r] = ok ? hr[r] : 0.f;
+            gv[i][r] = dd[i][r] * gm[r];
+            s1 += gv[i][r];
+            s2 += gv[i][r] * xh[i][r];
         }
     }
-    rows_allreduce2(s1, s2, red, w, c, g);
+    if (PRE == 2) __syncthreads();                           // pp is about to be reused for the gradient tiles
+    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    if (g == 0) { red[w * 16 + c] = s1; red[64 + w * 16 + c] = s2; }
+    // LayerNorm weight / bias gradient terms of this lane's elements -> LDS tiles [16 tokens][112]
+    if (a.gpart) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (w + 4 * i < RT) {
+                *reinterpret_cast<float4*>(pp + c * LDP + f0[i]) =
+                    make_float4(dd[i][0] * xh[i][0], dd[i][1] * xh[i][1], dd[i][2] * xh[i][2], dd[i][3] * xh[i][3]);
+                *reinterpret_cast<float4*>(pp + 16 * LDP + c * LDP + f0[i]) = make_float4(dd[i][0], dd[i][1], dd[i][2], dd[i][3]);
+            }
+    }
+    __syncthreads();
     const float invE = 1.0f / (float)RE;
+    const float c1 = (((red[c] + red[16 + c]) + red[32 + c]) + red[48 + c]) * invE;
+    const float c2 = (((red[64 + c] + red[80 + c]) + red[96 + c]) + red[112 + c]) * invE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         float mult[4] = {1.f, 1.f, 1.f, 1.f};
-        if (a.dy) drop_mult4(dc, (uint32_t)(t0 / 4 + g), (uint32_t)RE, (uint32_t)colc[i], mult);
+        if (a.dy) drop_mult_quad(dc, (uint32_t)(t0 / 4 + (c >> 2)), f0c[i], ql, mult);
+        float v[4], vy[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float v = rs[r] * (gv[i][r] - s1[r] * invE - xh[i][r] * (s2[r] * invE));
-            const float vy = v * mult[r];
-            if (cok[i] && rok[r]) {
-                const size_t off = roff[r] * RE + col[i];
-                a.dz[off] = v;
-                if (a.dy) a.dy[off] = vy;
-            }
-            if constexpr (POST_GEMM) {
-                if (nt[i] < RT) xs[(4 * g + r) * LDX + 16 * nt[i] + c] = (cok[i] && rok[r]) ? vy : 0.f;
-            }
+            v[r] = rs * (gv[i][r] - c1 - xh[i][r] * c2);
+            vy[r] = v[r] * mult[r];
+        }
+        if (fok[i] && tok) {
+            const size_t off = trow * RE + f0[i];
+            *reinterpret_cast<float4*>(a.dz + off) = make_float4(v[0], v[1], v[2], v[3]);
+            if (a.dy) *reinterpret_cast<float4*>(a.dy + off) = make_float4(vy[0], vy[1], vy[2], vy[3]);
+        }
+        if constexpr (POST_GEMM) {
+            if (w + 4 * i < RT)
+                *reinterpret_cast<float4*>(xs + c * LDX + f0[i]) = (fok[i] && tok) ? make_float4(vy[0], vy[1], vy[2], vy[3]) : zero4();
         }
     }
-    // LayerNorm weight / bias gradient: this workgroup's 16-token partial sums, one row each
-    if (a.gpart) {
+    // column sums over the 16 tokens, in token order: this workgroup's partial row of the parameter gradients
+    if (a.gpart && tid < RE) {
+        float sw = 0.f, sb = 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float sw = aw[i], sb = ab[i];
-            sw += __shfl_xor(sw, 16, 64); sb += __shfl_xor(sb, 16, 64);
-            sw += __shfl_xor(sw, 32, 64); sb += __shfl_xor(sb, 32, 64);
-            if (g == 0 && cok[i]) {
-                a.gpart[((size_t)blockIdx.x * 2 + 0) * RE + col[i]] = sw;
-                a.gpart[((size_t)blockIdx.x * 2 + 1) * RE + col[i]] = sb;
-            }
+        for (int r = 0; r < 16; ++r) {
+            sw += pp[r * LDP + tid];
+            sb += pp[16 * LDP + r * LDP + tid];
         }
+        a.gpart[((size_t)blockIdx.x * 2 + 0) * RE + tid] = sw;
+        a.gpart[((size_t)blockIdx.x * 2 + 1) * RE + tid] = sb;
     }
     if constexpr (POST_GEMM) {
         __syncthreads();
         Frag<RE> af;
 #pragma unroll
-        for (int q = 0; q < Frag<RE>::KQ; ++q) af.v[q] = *reinterpret_cast<const float4*>(xs + c * LDX + 16 * q + 4 * g);
-        const float* const wrow[2] = {a.post_wt + (size_t)colc[0] * RE, a.post_wt + (size_t)colc[1] * RE};
+        for (int q = 0; q < Frag<RE>::KQ; ++q) af.v[q] = f4(xs + c * LDX + 16 * q + 4 * g);
         floatx4 acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
-        gemm16<RE, 2>(acc, af, wrow, g);
+        mma<RE, 2>(acc, wpost, af);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (cok[i] && rok[r]) a.post_out[roff[r] * RE + col[i]] = acc[i][r];
+            if (fok[i] && tok)
+                *reinterpret_cast<float4*>(a.post_out + trow * RE + f0[i]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
     }
 }
 
@@ -491,7 +517,8 @@ int launch_rc_outproj_ln_fwd(const float* attn_o, const float* wo, const float* 
                              const float* beta, float* out, float* xhat, float* rstd, int T, float eps, float p, uint32_t site,
                              const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
     GF_CHECK_ARG(attn_o && wo && bo && x && gamma && beta && out && T > 0, "rc_outproj_ln_fwd: bad arguments");
-    GF_CHECK_ARG(aligned16(attn_o) && aligned16(wo), "rc_outproj_ln_fwd: operands must be 16-byte aligned");
+    GF_CHECK_ARG(aligned16(attn_o) && aligned16(wo) && aligned16(bo) && aligned16(x) && aligned16(gamma) && aligned16(beta) &&
+                     aligned16(out) && (!xhat || aligned16(xhat)), "rc_outproj_ln_fwd: operands must be 16-byte aligned");
     RcFwdArgs a{};
     a.pre_a = attn_o; a.pre_w = wo; a.pre_b = bo; a.x = x; a.gamma = gamma; a.beta = beta; a.out = out; a.xhat = xhat; a.rstd = rstd;
     a.T = T; a.eps = eps; a.p = p; a.site = site; a.rng = rng; a.add = add; a.train = train;
@@ -505,7 +532,10 @@ int launch_rc_ln_inproj_fwd(const float* y, int nslab, long slab_stride, const f
                             float* out, float* xhat, float* rstd, const float* w_in, const float* b_in, float* qkv, int T,
                             float eps, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
     GF_CHECK_ARG(y && x && gamma && beta && out && T > 0 && nslab >= 1, "rc_ln_inproj_fwd: bad arguments");
-    GF_CHECK_ARG(!w_in || (b_in && qkv && aligned16(w_in)), "rc_ln_inproj_fwd: in-proj needs bias, output and a 16-byte aligned weight");
+    GF_CHECK_ARG(aligned16(y) && (slab_stride & 3) == 0 && aligned16(x) && aligned16(gamma) && aligned16(beta) && aligned16(out) &&
+                     (!xhat || aligned16(xhat)), "rc_ln_inproj_fwd: operands must be 16-byte aligned");
+    GF_CHECK_ARG(!w_in || (b_in && qkv && aligned16(w_in) && aligned16(b_in) && aligned16(qkv)),
+                 "rc_ln_inproj_fwd: in-proj needs bias, output and 16-byte aligned operands");
     RcFwdArgs a{};
     a.y = y; a.nslab = nslab; a.slab_stride = slab_stride; a.x = x; a.gamma = gamma; a.beta = beta; a.out = out; a.xhat = xhat;
     a.rstd = rstd; a.post_w = w_in; a.post_b = b_in; a.post_out = qkv;
@@ -526,7 +556,9 @@ int launch_rc_ln_bwd(const float* d_qkv, const float* w_in_t, const float* d_out
                      hipStream_t st) {
     GF_CHECK_ARG((d_qkv || d_out) && xhat && rstd && gamma && dz && T > 0, "rc_ln_bwd: bad arguments");
     GF_CHECK_ARG(!d_qkv || (w_in_t && aligned16(d_qkv) && aligned16(w_in_t)), "rc_ln_bwd: in-proj dgrad needs the transposed weight");
-    GF_CHECK_ARG(!wo_t || (d_attn && dy && aligned16(wo_t)), "rc_ln_bwd: out-proj dgrad needs dy and an output");
+    GF_CHECK_ARG(!wo_t || (d_attn && dy && aligned16(wo_t) && aligned16(d_attn)), "rc_ln_bwd: out-proj dgrad needs dy and an output");
+    GF_CHECK_ARG((!d_out || (aligned16(d_out) && (slab_stride & 3) == 0)) && (!addend || aligned16(addend)) && aligned16(xhat) &&
+                     aligned16(gamma) && aligned16(dz) && (!dy || aligned16(dy)), "rc_ln_bwd: operands must be 16-byte aligned");
     RcBwdArgs a{};
     a.pre_a = d_qkv; a.pre_wt = w_in_t; a.d_out = d_out; a.nslab = nslab; a.slab_stride = slab_stride; a.addend = addend;
     a.xhat = xhat; a.rstd = rstd; a.gamma = gamma; a.dz = dz; a.dy = dy; a.gpart = gpart; a.post_wt = wo_t; a.post_out = d_attn;

@@ -19,8 +19,8 @@
  *    affect results — the thread-local last-error string and, per (kernel, device, host thread),
  *    the facts that hipFuncSetAttribute has opted a kernel in to > 48 KiB of LDS and how many
  *    workgroups of the persistent short-K GEMM the device holds at once — and ONE debug switch,
- *    ganffn_debug_set_ffn_mode (default 0 = two GEMMs; 1 = the fused feed-forward kernel, which
- *    gives the same results to rounding and measured slower).
+ *    ganffn_debug_set_ffn_mode (default 0; its bits select the older launch sequences of three
+ *    d_model-100 sub-chains for A/B measurement — same results to rounding).
  *  - Results are bit-reproducible: no kernel accumulates with floating-point atomics (weight
  *    gradients, bias gradients, LayerNorm gradients and loss sums are owner-computed or reduced
  *    in a fixed order), so two runs from the same state and RNG offset give identical bits.
@@ -300,10 +300,21 @@ int ganffn_add_dropout_layernorm_bwd(const float* d_out, const float* xhat, cons
 int ganffn_dropout(const float* x, float* out, int R, int C, float p, uint32_t site,
                    const uint64_t* rng, uint64_t rng_offset_add, void* stream);
 
-/* A/B measurement hook (process-wide): non-zero = run the d_model-100 feed-forward block as the fused kernel of ffn.hip
- * instead of two GEMMs (the default, 0: measured faster in the step).  Both paths are parity-tested; results agree to
- * rounding. */
-int ganffn_debug_set_ffn_mode(int fused);
+/* [T x K] x [K x 100] with a long K (linear2 forward / linear1 dgrad of the d_model-100 feed-forward block,
+ * csrc/gemm_n100.hip): K is cut into *n_slabs (<= max_slabs <= 16) chunks, chunk z writes its partial product to
+ * slabs + z * slab_stride ([T x 100], plain stores); the consumer adds the slabs in order (no atomics).  w_kmajor = 0:
+ * W is [100 x K] (rows of K: out = A W^T), 1: W is [K x 100] (out = A W).  bias [100] (or NULL) is added by chunk 0.
+ * K % 32 == 0, K >= 256. */
+int ganffn_gemm_n100(const float* A, const float* W, int w_kmajor, const float* bias, float* slabs, int64_t slab_stride,
+                     int T, int K, int max_slabs, int* n_slabs, void* stream);
+
+/* A/B measurement hook (process-wide), a bit mask; 0 = the default path.
+ *   bit 0: run the d_model-100 feed-forward block as the fused kernel of ffn.hip instead of two GEMMs (measured slower);
+ *   bit 1: run the token-local chains around the LayerNorms of a d_model-100 layer (out-proj + LN1, LN2 + next in-proj and
+ *          their backward mirrors, csrc/rowchain.hip) as separate GEMM + LayerNorm launches;
+ *   bit 2: run the [T x 2048] x [2048 x 100] products on the generic 64 x 64 tiles instead of csrc/gemm_n100.hip.
+ * Every combination is parity-tested; results agree to rounding. */
+int ganffn_debug_set_ffn_mode(int bits);
 
 #ifdef __cplusplus
 }

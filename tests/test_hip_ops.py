@@ -266,6 +266,33 @@ def test_logsoftmax_nll_matches_reference_fixture(lib):
         assert rel_err(dl, x.grad) < 1e-5
 
 
+@pytest.mark.parametrize("T,K,kmajor,cap", [(3008, 2048, 0, 16), (6016, 2048, 1, 16), (6016, 2048, 0, 8), (3008, 2048, 1, 5),
+                                            (21, 256, 0, 16), (70, 2048, 1, 1), (1, 320, 1, 16), (2112, 2048, 0, 16)])
+def test_gemm_n100_slabs_sum_to_the_product(lib, T, K, kmajor, cap):
+    """[T x K] x [K x 100] on the 112-wide 16x16x4 kernel (csrc/gemm_n100.hip): the sum of its K-chunk slabs against fp64
+    torch, both weight layouts (rows of K = linear2's W2; K-major = linear1's W1 in the dgrad), bias on chunk 0; ragged T,
+    a single chunk, chunk counts that do not divide K / 32"""
+    g = torch.Generator().manual_seed(T * 7 + K + kmajor)
+    A = torch.randn(T, K, generator=g)
+    W = (torch.randn(K, 100, generator=g) if kmajor else torch.randn(100, K, generator=g)) / (K ** 0.5)
+    b = torch.randn(100, generator=g)
+    ref = A.double() @ (W.double() if kmajor else W.double().T) + b.double()
+    slabs = torch.full((cap, T, 100), float("nan"), device="cuda")
+    n = C.c_int(0)
+    Ad, Wd, bd = dev(A), dev(W), dev(b)
+    lib.call("ganffn_gemm_n100", ptr(Ad), ptr(Wd), kmajor, ptr(bd), ptr(slabs), C.c_int64(T * 100), T, K, cap, C.byref(n), stream())
+    assert 1 <= n.value <= cap
+    y = slabs[:n.value].sum(0)
+    assert bool(torch.isfinite(y).all())
+    assert rel_err(y, ref) < 2e-6
+    if n.value < cap:
+        assert bool(torch.isnan(slabs[n.value:]).all())          # nothing written beyond the slabs it reports
+    # deterministic: a second launch gives the same bits
+    slabs2 = torch.empty_like(slabs)
+    lib.call("ganffn_gemm_n100", ptr(Ad), ptr(Wd), kmajor, ptr(bd), ptr(slabs2), C.c_int64(T * 100), T, K, cap, C.byref(n), stream())
+    assert torch.equal(slabs2[:n.value], slabs[:n.value])
+
+
 @pytest.mark.parametrize("T", [3008, 6016, 14, 130, 33, 4097])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_ffn_fused_fwd_bwd(lib, T, p):

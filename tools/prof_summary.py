@@ -6,7 +6,7 @@ import sys
 rows = csv.DictReader(open(sys.argv[1]))
 agg = collections.defaultdict(list)
 for r in rows:
-    n = r['Kernel_Name'].replace('ganffn::', '').replace('void ', '').split('(')[0]
+    n = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('ganffn::', '').replace('void ', '').split('(')[0]
     key = (n, int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])), r['Grid_Size_Y'], r['Grid_Size_Z'])
     agg[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 tot = sum(sum(v) for v in agg.values())
