@@ -278,9 +278,9 @@ def time_skinny_kernel(B, reps=20):
 def run_drnn(args, dev, pg, rank, world):
     """BASELINE.json configs[4] on the GPUs given: GAN_FFN_DialogueRNN (three generators -> sum -> bidirectional
     DialogueRNN -> matching attention -> 6-class head; model.py:1485-1534) forward + MaskedNLLLoss + backward + Adam at
-    the reference's batch of 30 dialogues (train_IEMOCAP_DialogueRNN.py:580), every piece on the HIP path.  Data
-    parallel = one batch per rank, gradients averaged by one flat all-reduce (no reference counterpart: the reference
-    is single-device)."""
+    the reference's batch of 30 dialogues (train_IEMOCAP_DialogueRNN.py:580) on the C-ABI step runner
+    (engine.DrnnEngine).  Data parallel = one batch per rank, gradients all-reduced in buckets that overlap the
+    generators' backward (no reference counterpart: the reference is single-device)."""
     from gan_ffn_amd import model as M, ops
     torch.manual_seed(3407)
     net = M.GAN_FFN_DialogueRNN(M.AcousticGenerator(100), M.VisualGenerator(100), M.TextGenerator(100), 100, 500, 500, 100, 100,
@@ -289,29 +289,18 @@ def run_drnn(args, dev, pg, rank, world):
     ops.manual_seed(3407 + 1000 * rank, dev)
     batch = make_batch("iemocap", args.batch, args.seq, 3407 + rank, dev)
     S, B = batch["text"].shape[:2]
-    w = torch.tensor([1.2, 0.60072, 0.38066, 0.94019, 0.67924, 0.34332], device=dev)      # train_IEMOCAP_DialogueRNN.py:738
-    loss_fn = M.MaskedNLLLoss(w)
-    params = [p for p in net.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-5, fused=True)     # train_IEMOCAP_DialogueRNN.py:746
+    from gan_ffn_amd import engine
     if pg is not None:
         import torch.distributed as dist
-        for p in params:
+        for p in net.parameters():
             dist.broadcast(p.data, src=0)
+    # the step runner on the C ABI (engine.DrnnEngine): no autograd graph, fused Adam (lr 1e-4, weight decay 1e-5,
+    # train_IEMOCAP_DialogueRNN.py:746) on flat slabs, bucketed all-reduce
+    eng = engine.DrnnEngine(net, lr=1e-4, weight_decay=1e-5, process_group=pg,
+                            n_streams=int(os.environ.get("GANFFN_DRNN_STREAMS", "1")))
 
     def step():
-        opt.zero_grad()
-        lp = net(batch["acoustic"], batch["visual"], batch["text"], batch["qmask"], batch["umask"])[0]
-        loss = loss_fn(lp.transpose(0, 1).contiguous().view(-1, 6), batch["label"].view(-1), batch["umask"])
-        loss.backward()
-        if pg is not None:
-            gs = [p.grad for p in params if p.grad is not None]
-            flat = torch._utils._flatten_dense_tensors(gs)
-            dist.all_reduce(flat)
-            flat.div_(world)
-            for g, f in zip(gs, torch._utils._unflatten_dense_tensors(flat, gs)):
-                g.copy_(f)
-        opt.step()
-        return loss
+        return eng.step(batch, train=True)[0]
 
     def sync():
         torch.cuda.synchronize()

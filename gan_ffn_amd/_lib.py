@@ -90,6 +90,10 @@ SIGNATURES = {
     "ganffn_drnn_fwd": (_I, [C.POINTER(DrnnCfg), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _P]),
     "ganffn_drnn_bwd": (_I, [C.POINTER(DrnnCfg), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _P]),
     "ganffn_dropout": (_I, [_P, _P, _I, _I, _F, _U32, _P, _U64, _P]),
+    "ganffn_seq_reverse": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ganffn_drnn_join_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _U32, _U32, _P, _U64, _I, _P]),
+    "ganffn_drnn_join_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _U32, _U32, _P, _U64, _I, _P]),
+    "ganffn_mask_pos_inplace": (_I, [_P, _P, _F, _L, _P]),
 }
 
 _lib = None

@@ -107,6 +107,7 @@ int g_rc_off = 0;
 // ganffn_debug_set_ffn_mode switches back to the generic 64 x 64 tiles
 int g_n100_off = 0;
 extern int g_n100_force_splits;
+extern int g_tn100_off, g_tn100_force_splits;
 extern unsigned long long* g_n100_stamps;
 constexpr int MAX_SPLITS = 16;  // partial-output slabs: fused FFN (16 F splits) / split-K GEMMs (<= 8)
 
@@ -615,6 +616,8 @@ extern "C" int ganffn_debug_set_ffn_mode(int bits) {
     g_ffn_fused = (bits & 1) ? 1 : 0;
     g_rc_off = (bits & 2) ? 1 : 0;
     g_n100_off = (bits & 4) ? 1 : 0;
+    g_tn100_off = (bits & 8) ? 1 : 0;
+    g_tn100_force_splits = (bits >> 16) & 0xF;      // lab: force the token-chunk count of the d_model-100 grouped wgrad (0 = choose)
     g_n100_force_splits = (bits >> 8) & 0xFF;       // lab: force the K-chunk count of gemm_n100 (0 = choose)
     return 0;
 }

@@ -238,6 +238,10 @@ struct TnDesc {
 // evenly, the token range is split over 2..8 workgroups per tile; each writes its partial tile to the workspace and one
 // grouped reduce launch adds the partials in split order (deterministic).  Without a workspace: one owner per tile.
 int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws = nullptr, long part_floats = 0);
+// gemm_tn100.hip: the same for groups whose every problem has a 100-wide dimension (d_model-100 encoder passes), on
+// 112-wide 16x16x4 tiles; needs the partial-slab workspace
+bool tn100_supported(const TnDesc* d, int n);
+int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws, long part_floats);
 long gemm_tn_grouped_part_floats();
 
 // lse [B*H x S]: log-sum-exp of every score row, written by the forward (may be NULL: not kept) and, together with the

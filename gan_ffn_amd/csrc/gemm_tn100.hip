@@ -1,0 +1,332 @@
+// gemm_tn100.hip — the grouped weight-gradient launch of a d_model-100 encoder backward pass on 112-wide tiles.
+//
+// Every weight gradient of a d_model-100 layer has a 100-wide dimension: dW2 [100 x 2048], dW1 [2048 x 100], dWo [100 x 100],
+// dWin [300 x 100] (dW = dY^T X over the tokens; /root/reference/model.py:1210 -> the backward of torch's
+// TransformerEncoderLayer).  On the 64 x 64 tiles of gemm.hip that dimension is 2 tiles = 128: 22 % of every MFMA of the
+// launch that dominates the step's GPU time is padding (profiles/r02_*: 447 us per launch, 49 % of the fp32 MFMA peak on
+// useful FLOPs although the MFMAs it executes run at 80 %).  Here, as in gemm_n100.hip:
+//  * v_mfma_f32_16x16x4_f32 (exact fp32) with the 100-wide dimension on the m axis: 7 tiles of 16 = 112 (10.7 % padding);
+//  * a wave owns all 7 of them for 16 columns of the other dimension: the 7 MFMAs of a k-step share one operand;
+//  * a workgroup = 4 waves = a 112 x 64 output tile; k = the token axis, read from LDS tiles of 32 tokens (both operands
+//    are token-major, so both are read with ds_read_b32; row strides 116 / 68 floats put rows 4 apart 16 banks apart);
+//  * the token range is cut into 2..8 chunks so that the launch has several times 768 workgroups (3 resident per CU: the
+//    K loop then runs at > 90 % MFMA utilisation, gemm_n100.hip) and the CUs finish within one short workgroup of each
+//    other; chunk z writes its partial tile to slab z and one ordered reduce launch adds the slabs to the gradient —
+//    no atomics, bit-reproducible;
+//  * bias gradients (column sums of dY over the tokens) are accumulated from the operand registers the MFMAs read anyway;
+//  * workgroup ids are remapped so that one XCD (one L2) gets a contiguous range of the (problem, chunk, tile) list: the
+//    tiles of a problem share its 100-wide operand panel ([T x 100], 2.4 MB at T = 6016) through that L2, the wide operand
+//    is read exactly once.
+#include "common.h"
+
+namespace ganffn {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int WE = 100, WT7 = 7, WBK = 32, WBN = 64;
+constexpr int LDU = 116, LDV = 68;            // = 4 (mod 8): ds_read_b32 of rows g and g + 1 (4 k apart... see above) conflict-free
+constexpr int WMAXP = 40, WMAXSPLIT = 8;
+
+struct W100Problem {
+    const float* U; const float* V;            // U: [K x 100] (the 100-wide operand), V: [K x Nn]
+    float* C; float* colsum;                   // gradient [M x N] (ldc) and bias gradient [M] (or null)
+    int ldu, ldv, ldc, Nn;
+    int side;                                  // 0: U = dY (C rows = the 100-wide dim), 1: U = X (C columns = the 100-wide dim)
+    int K, kchunk;
+    int ntiles, block0;                        // 64-wide tiles over Nn; first workgroup of this problem
+    int M, N;                                  // the gradient's shape (partial-slab layout: [M x N] dense, then [M] column sums)
+    long part_off;
+};
+struct W100Group {
+    W100Problem p[WMAXP];
+    int n, splits;
+    float* part; long part_stride;
+};
+
+__global__ __launch_bounds__(256) void tn100_kernel(W100Group grp) {
+    constexpr int UT = WBK * LDU, STAGE = UT + WBK * LDV;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 4];
+    constexpr int DUMP = 2 * STAGE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    // XCD-aware order (gemm.hip gemm_tn_grouped_kernel): the workgroups of one XCD get a contiguous range of the logical list
+    int pi = 0;
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xl = blockIdx.x & 7;
+    const int b = (xl < r8 ? xl * (q8 + 1) : r8 * (q8 + 1) + (xl - r8) * q8) + (blockIdx.x >> 3);
+#pragma unroll 1
+    for (int i = 1; i < grp.n; ++i)
+        if (b >= grp.p[i].block0) pi = i;
+    const W100Problem& q = grp.p[pi];
+    const int local = b - q.block0, z = local / q.ntiles, tile = local - z * q.ntiles;
+    const int n0 = tile * WBN;
+    const int kbeg = min(z * q.kchunk, q.K), kend = min(q.K, kbeg + q.kchunk);
+    const int nt = (kend - kbeg + WBK - 1) / WBK;
+    const float* const Ug = q.U;
+    const float* const Vg = q.V;
+    const int ldu = q.ldu, ldv = q.ldv, Nn = q.Nn;
+
+    // loaders (named scalars: hipcc keeps small arrays that live across the K loop in scratch).  U tile: 32 token rows x 25
+    // float4 = 800, 4 per thread (the last partly surplus -> dump slot); V tile: 32 rows x 16 float4 = 512, 2 per thread.
+#define GF_W_UIDX(J)                                                                                  \
+    const int iu##J = tid + 256 * J;                                                                  \
+    const bool oku##J = iu##J < WBK * 25;                                                             \
+    const int icu##J = min(iu##J, WBK * 25 - 1), ru##J = icu##J / 25, cu##J = (icu##J - ru##J * 25) << 2; \
+    const uint32_t offu##J = (uint32_t)cu##J;                                                         \
+    const int ldsu0_##J = oku##J ? ru##J * LDU + cu##J : DUMP, ldsu1_##J = oku##J ? STAGE + ru##J * LDU + cu##J : DUMP;
+    GF_W_UIDX(0) GF_W_UIDX(1) GF_W_UIDX(2) GF_W_UIDX(3)
+#define GF_W_VIDX(J)                                                                                  \
+    const int iv##J = tid + 256 * J, rv##J = iv##J >> 4, cv##J = (iv##J & 15) << 2;                   \
+    const uint32_t offv##J = (uint32_t)max(min(n0 + cv##J, Nn - 4), 0);                               \
+    const int ldsv##J = UT + rv##J * LDV + cv##J;
+    GF_W_VIDX(0) GF_W_VIDX(1)
+    float4 qu0, qu1, qu2, qu3, qv0, qv1;
+    // rows (tokens) beyond kend are clamped onto the last valid token and zeroed when they go to LDS (wave-uniform tail test)
+#define GF_W_GLOAD(TT)                                                                                \
+    {                                                                                                 \
+        const int k0 = kbeg + min((TT), nt - 1) * WBK, kl = kend - 1;                                 \
+        qu0 = *reinterpret_cast<const float4*>(Ug + (size_t)min(k0 + ru0, kl) * ldu + offu0);         \
+        qu1 = *reinterpret_cast<const float4*>(Ug + (size_t)min(k0 + ru1, kl) * ldu + offu1);         \
+        qu2 = *reinterpret_cast<const float4*>(Ug + (size_t)min(k0 + ru2, kl) * ldu + offu2);         \
+        qu3 = *reinterpret_cast<const float4*>(Ug + (size_t)min(k0 + ru3, kl) * ldu + offu3);         \
+        qv0 = *reinterpret_cast<const float4*>(Vg + (size_t)min(k0 + rv0, kl) * ldv + offv0);         \
+        qv1 = *reinterpret_cast<const float4*>(Vg + (size_t)min(k0 + rv1, kl) * ldv + offv1);         \
+    }
+#define GF_W_MASK(Q, ROW) { const float f_ = (ROW) < kv ? 1.f : 0.f; Q.x *= f_; Q.y *= f_; Q.z *= f_; Q.w *= f_; }
+#define GF_W_SSTORE(BUF, TT)                                                                          \
+    {                                                                                                 \
+        const int kv = kend - (kbeg + (TT) * WBK);          /* valid token rows of this tile */         \
+        if (kv < WBK) { GF_W_MASK(qu0, ru0) GF_W_MASK(qu1, ru1) GF_W_MASK(qu2, ru2) GF_W_MASK(qu3, ru3) GF_W_MASK(qv0, rv0) GF_W_MASK(qv1, rv1) } \
+        float* const sdst = smem + (BUF) * STAGE;                                                     \
+        *reinterpret_cast<float4*>(smem + ((BUF) ? ldsu1_0 : ldsu0_0)) = qu0;                         \
+        *reinterpret_cast<float4*>(smem + ((BUF) ? ldsu1_1 : ldsu0_1)) = qu1;                         \
+        *reinterpret_cast<float4*>(smem + ((BUF) ? ldsu1_2 : ldsu0_2)) = qu2;                         \
+        *reinterpret_cast<float4*>(smem + ((BUF) ? ldsu1_3 : ldsu0_3)) = qu3;                         \
+        *reinterpret_cast<float4*>(sdst + ldsv0) = qv0;                                               \
+        *reinterpret_cast<float4*>(sdst + ldsv1) = qv1;                                               \
+    }
+
+    floatx4 acc[WT7];
+#pragma unroll
+    for (int m = 0; m < WT7; ++m) acc[m] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // bias gradient = column sums of dY over the tokens.  side 0: dY = U (its 100 columns): wave 0 of the tile-0 workgroup
+    // sums the A operand values it reads; side 1: dY = V: every wave sums the B operand values of its 16 columns.
+    const bool cs_u = q.colsum != nullptr && q.side == 0 && tile == 0 && wave == 0;
+    const bool cs_v = q.colsum != nullptr && q.side == 1;
+    float csu[WT7], csv = 0.f;
+#pragma unroll
+    for (int m = 0; m < WT7; ++m) csu[m] = 0.f;
+
+    // columns 100 .. 111 of the U tile are never written by the loader: zero them once (both stages)
+    for (int i = tid; i < 2 * WBK * 12; i += 256) {
+        const int st = i / (WBK * 12), r = (i / 12) % WBK, cc = i % 12;
+        smem[st * STAGE + r * LDU + WE + cc] = 0.f;
+    }
+    if (nt > 0) {
+        GF_W_GLOAD(0)
+        GF_W_SSTORE(0, 0)
+    }
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        GF_W_GLOAD(t + 1)
+        __builtin_amdgcn_sched_barrier(0);       // the next tile's loads stay ahead of this tile's MFMAs
+        const float* s = smem + (t & 1) * STAGE;
+        const float* sv = s + UT + wave * 16 + c;
+        const float* su = s + c;
+        // 8 k-steps of 4 tokens: at the j-th MFMA of a half, lane group g takes token 16 half + 4 g + j (rows of the lane groups
+        // 4 apart: conflict-free ds_read_b32 with the 116 / 68 row strides)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float av[4][WT7], bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kr = 16 * half + 4 * g + j;
+                bv[j] = sv[kr * LDV];
+#pragma unroll
+                for (int m = 0; m < WT7; ++m) av[j][m] = su[kr * LDU + 16 * m];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < WT7; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][m], bv[j], acc[m], 0, 0, 0);
+            if (cs_v) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) csv += bv[j];
+            }
+            if (cs_u) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < WT7; ++m) csu[m] += av[j][m];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nt) GF_W_SSTORE((t + 1) & 1, t + 1)
+        __syncthreads();
+    }
+#undef GF_W_GLOAD
+#undef GF_W_SSTORE
+#undef GF_W_MASK
+#undef GF_W_UIDX
+#undef GF_W_VIDX
+
+    // ---------------- epilogue: lane (c, g) holds m = 16 mt + 4 g + r (the 100-wide dim), n = n0 + 16 wave + c ----------------
+    const int n = n0 + wave * 16 + c;
+    const bool nok = n < Nn;
+    float* const slab = grp.splits > 1 ? grp.part + (size_t)z * grp.part_stride + q.part_off : nullptr;
+    if (q.side == 0) {
+        // gradient [100 x Nn]: element (m, n)
+#pragma unroll
+        for (int m = 0; m < WT7; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mm = 16 * m + 4 * g + r;
+                if (mm < WE && nok) {
+                    if (slab) slab[(size_t)mm * q.N + n] = acc[m][r];
+                    else q.C[(size_t)mm * q.ldc + n] += acc[m][r];
+                }
+            }
+    } else {
+        // gradient [Nn x 100]: element (n, m): 4 consecutive m = one 16-byte access
+        if (nok) {
+#pragma unroll
+            for (int m = 0; m < WT7; ++m) {
+                const int mm = 16 * m + 4 * g;
+                if (mm < WE) {
+                    if (slab) {
+                        *reinterpret_cast<float4*>(slab + (size_t)n * q.N + mm) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+                    } else {
+                        float* dst = q.C + (size_t)n * q.ldc + mm;
+                        const float4 o = *reinterpret_cast<const float4*>(dst);
+                        *reinterpret_cast<float4*>(dst) = make_float4(o.x + acc[m][0], o.y + acc[m][1], o.z + acc[m][2], o.w + acc[m][3]);
+                    }
+                }
+            }
+        }
+    }
+    if (cs_v) {            // wave-uniform
+        csv += __shfl_xor(csv, 16, 64);
+        csv += __shfl_xor(csv, 32, 64);
+        if (g == 0 && nok) {
+            if (slab) slab[(size_t)q.M * q.N + n] = csv;
+            else q.colsum[n] += csv;
+        }
+    }
+    if (cs_u) {
+#pragma unroll
+        for (int m = 0; m < WT7; ++m) {
+            float v = csu[m];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int mm = 16 * m + c;
+            if (g == 0 && mm < WE) {
+                if (slab) slab[(size_t)q.M * q.N + mm] = v;
+                else q.colsum[mm] += v;
+            }
+        }
+    }
+}
+
+// C_i += sum_z part[z][i], colsum_i += sum_z part[z][M N + i], slabs in chunk order; blockIdx.y = problem
+__global__ __launch_bounds__(256) void tn100_reduce_kernel(W100Group grp) {
+    const W100Problem& q = grp.p[blockIdx.y];
+    const float* part = grp.part + q.part_off;
+    const long nC = (long)q.M * q.N;
+    for (long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i4 < nC; i4 += (long)gridDim.x * 1024) {
+        float4 v[WMAXSPLIT];                                    // all slabs' loads in flight together
+#pragma unroll
+        for (int z = 0; z < WMAXSPLIT; ++z)
+            v[z] = *reinterpret_cast<const float4*>(part + (size_t)min(z, grp.splits - 1) * grp.part_stride + i4);
+        const long row = i4 / q.N, col = i4 - row * q.N;      // N % 4 == 0: a float4 stays inside one row
+        float* dst = q.C + row * q.ldc + col;
+        const float4 old = *reinterpret_cast<const float4*>(dst);
+        float4 s = v[0];
+#pragma unroll
+        for (int z = 1; z < WMAXSPLIT; ++z)
+            if (z < grp.splits) { s.x += v[z].x; s.y += v[z].y; s.z += v[z].z; s.w += v[z].w; }
+        *reinterpret_cast<float4*>(dst) = make_float4(old.x + s.x, old.y + s.y, old.z + s.z, old.w + s.w);
+    }
+    if (q.colsum != nullptr)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < q.M; i += gridDim.x * 256) {
+            float s = part[nC + i];
+            for (int z = 1; z < grp.splits; ++z) s += part[(size_t)z * grp.part_stride + nC + i];
+            q.colsum[i] += s;
+        }
+}
+
+}  // namespace
+
+int g_tn100_force_splits = 0;     // lab knob (ganffn_debug_set_ffn_mode bits 16..19): 0 = choose
+
+// every problem has a 100-wide dimension, 16-byte aligned dense operands
+bool tn100_supported(const TnDesc* d, int n) {
+    if (n < 1 || n > WMAXP) return false;
+    for (int i = 0; i < n; ++i) {
+        if (d[i].M != WE && d[i].N != WE) return false;
+        if ((d[i].M & 3) || (d[i].N & 3) || (d[i].lda & 3) || (d[i].ldb & 3) || (d[i].ldc & 3)) return false;
+        if (!aligned16(d[i].At) || !aligned16(d[i].B) || !aligned16(d[i].C)) return false;
+    }
+    return true;
+}
+
+long tn100_part_floats(const TnDesc* d, int n) {
+    long per = 0;
+    for (int i = 0; i < n; ++i) per += (((long)d[i].M * d[i].N + d[i].M) + 3) & ~3L;
+    return per;
+}
+
+int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws, long part_floats) {
+    GF_CHECK_ARG(tn100_supported(d, n), "gemm_tn100_grouped: unsupported group");
+    W100Group grp;
+    grp.n = n;
+    long tiles = 0, per_split = tn100_part_floats(d, n);
+    int kmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const int Nn = d[i].M == WE ? d[i].N : d[i].M;
+        tiles += (Nn + WBN - 1) / WBN;
+        kmax = d[i].K > kmax ? d[i].K : kmax;
+    }
+    // chunks of the token range: aim at ~6.6 workgroups per CU (1700 for a whole 8-layer pass = 568 tiles x 3: the CUs then
+    // finish within 5 % of each other), at least 256 tokens per workgroup, within the workspace
+    int splits = 1;
+    if (part_ws != nullptr && aligned16(part_ws)) {
+        splits = (int)((1700 + tiles - 1) / tiles);
+        if (splits > WMAXSPLIT) splits = WMAXSPLIT;
+        if (splits > kmax / 256) splits = kmax / 256;
+        if (g_tn100_force_splits > 0) splits = g_tn100_force_splits;
+        if ((long)splits * per_split > part_floats) splits = (int)(part_floats / per_split);
+        if (splits < 2) splits = 1;
+    }
+    grp.splits = splits;
+    grp.part = splits > 1 ? part_ws : nullptr;
+    grp.part_stride = per_split;
+    int total = 0;
+    long off = 0;
+    for (int i = 0; i < n; ++i) {
+        W100Problem& q = grp.p[i];
+        const bool side0 = d[i].M == WE;                 // (a 100 x 100 gradient: dY is the U operand)
+        q.U = side0 ? d[i].At : d[i].B;
+        q.V = side0 ? d[i].B : d[i].At;
+        q.ldu = side0 ? d[i].lda : d[i].ldb;
+        q.ldv = side0 ? d[i].ldb : d[i].lda;
+        q.Nn = side0 ? d[i].N : d[i].M;
+        q.side = side0 ? 0 : 1;
+        q.C = d[i].C; q.colsum = d[i].colsum; q.ldc = d[i].ldc; q.M = d[i].M; q.N = d[i].N; q.K = d[i].K;
+        q.kchunk = splits > 1 ? (int)((((long)d[i].K + splits - 1) / splits + WBK - 1) / WBK * WBK) : d[i].K;
+        q.ntiles = (q.Nn + WBN - 1) / WBN;
+        q.block0 = total;
+        q.part_off = off;
+        off += (((long)d[i].M * d[i].N + d[i].M) + 3) & ~3L;
+        total += q.ntiles * splits;
+    }
+    hipLaunchKernelGGL(tn100_kernel, dim3(total), dim3(256), 0, st, grp);
+    GF_LAUNCH_CHECK();
+    if (splits > 1) {
+        hipLaunchKernelGGL(tn100_reduce_kernel, dim3(64, n), dim3(256), 0, st, grp);
+        GF_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace ganffn

@@ -753,3 +753,254 @@ class Phase2Engine(GanEngine):
     def predictions(log_prob):
         """argmax over classes in the reference's batch-major flattening (train_IEMOCAP.py:154,158)"""
         return log_prob.transpose(0, 1).reshape(-1, log_prob.shape[2]).argmax(1)
+
+
+# ================================================================================================
+# Configuration 5: GAN_FFN_DialogueRNN classifier step     (/root/reference/train_IEMOCAP_DialogueRNN.py:705-760,
+#                                                          model.py:975-1062, 1465-1528)
+# ================================================================================================
+SITE_JOIN_F, SITE_JOIN_B, SITE_HIDDEN = 5, 6, 7       # dropout sites of the head (the recurrence uses 8..14, the encoders 16+)
+
+
+class DrnnEngine(GanEngine):
+    """One train / eval step of GAN_FFN_DialogueRNN on the C ABI, no autograd graph: the three generators (n_streams = 3
+    runs their forward and backward passes concurrently on three HIP streams; measured SLOWER than one stream on this
+    workload — 20.8 against 19.1 ms per step, tools/lab/drnn_ab.py: the step is a chain of latency-sized launches whose
+    pace follows the clock, and the denser generator phase leaves the clock lower for the recurrence that follows —
+    so one stream is the default), fusion = their sum, BiModel's two
+    DialogueRNN directions through one chain of launches (ganffn_drnn_fwd / _bwd), the matching attention
+    (ganffn_general2_attention_*), linear + ReLU + dropout, the class head, MaskedNLLLoss with class weights, and Adam
+    (lr, L2-coupled weight decay; train_IEMOCAP_DialogueRNN.py:746) on flat slabs: one fused launch per generator and one
+    for the whole head.  Data-parallel: the generators' gradients go through the bucketed GradReducer (all-reduce of a
+    bucket overlaps the rest of that generator's backward, Adam per bucket), the head's slab is one more bucket.
+    Supports the configuration the reference script trains (general context attention, no listener, two parties); the
+    module path (model.GAN_FFN_DialogueRNN.forward under autograd) stays available for everything else."""
+
+    def __init__(self, net, lr=1e-4, weight_decay=1e-5, class_weights=CLASS_WEIGHTS, process_group=None, n_buckets=3,
+                 n_streams=1):
+        from . import dialogue_rnn as DR
+        self.module = net
+        bm = net.bi_model
+        cf, cr = bm.dialog_rnn_f.dialogue_cell, bm.dialog_rnn_r.dialogue_cell
+        if cf.listener_state or getattr(cf.attention, "att_type", None) != "general" or cf.D_g != cf.D_p or cf.D_g > 512:
+            raise ValueError("DrnnEngine runs the trained configuration only (general context attention, no listener, "
+                             "D_g = D_p <= 512); use the module path for the other variants")
+        gens = {"acoustic": net.acoustic_generator, "visual": net.visual_generator, "text": net.text_generator}
+        self.G = {k: NetState(m, lr, (0.9, 0.999), weight_decay) for k, m in gens.items()}
+        self.D = {}
+        self._init_common(next(iter(self.G.values())).slab.device, process_group, n_buckets)
+        dev = self.dev
+        self.lr, self.wd = lr, weight_decay
+        self.Dm, self.H, self.He, self.Dh2 = cf.D_m, cf.D_g, cf.D_e, bm.linear.weight.shape[0]
+        self.n_classes = bm.smax_fc.weight.shape[0]
+        self.p_rec, self.p_join, self.p_hid = float(cf.dropout.p), float(bm.dropout_rec.p), float(bm.dropout.p)
+        # ---- head parameters -> one slab (views keep the module's parameters alive on it)
+        plist = []
+        for cell in (cf, cr):
+            sd = dict(cell.named_parameters())
+            plist += [sd[k] for k in ops.DRNN_KEYS]
+        plist += [bm.matchatt.transform.weight, bm.matchatt.transform.bias, bm.linear.weight, bm.linear.bias,
+                  bm.smax_fc.weight, bm.smax_fc.bias]
+        offs, total = [], 0
+        for p_ in plist:
+            offs.append(total)
+            total += (p_.numel() + 3) & ~3
+        self.h_slab = torch.zeros(total, device=dev)
+        with torch.no_grad():
+            for p_, o in zip(plist, offs):
+                self.h_slab[o:o + p_.numel()].copy_(p_.detach().reshape(-1))
+                p_.data = self.h_slab[o:o + p_.numel()].view_as(p_)
+        self._hparams, self._hoffs, self.h_total = plist, offs, total
+        self.h_grad = torch.zeros_like(self.h_slab)
+        self.h_m, self.h_v = torch.zeros_like(self.h_slab), torch.zeros_like(self.h_slab)
+        self.h_step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.class_w = torch.tensor(class_weights, device=dev, dtype=torch.float32) if class_weights is not None else None
+        self.n_streams = max(1, min(3, n_streams))
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(3)] if self.n_streams > 1 else None
+        self.loss = torch.zeros(1, device=dev)
+        self._shape = None
+        self._cap_S = self._cap_B = 0
+        self._adds = 0
+        self._base_add = 0
+
+    def _hp(self, i, grad=False):
+        o, n = self._hoffs[i], self._hparams[i].numel()
+        return (self.h_grad if grad else self.h_slab)[o:o + n]
+
+    def reserve(self, S, B):
+        self._cap_S, self._cap_B = max(self._cap_S, S), max(self._cap_B, B)
+
+    def _prepare5(self, S, B):
+        if self._shape == (S, B):
+            return
+        if B > 32:
+            raise ValueError("DrnnEngine: at most 32 dialogues per step (the recurrence's tile); got %d" % B)
+        if self._shape is None or S > self._alloc_S or B > self._alloc_B:
+            cS = self._cap_S = max(self._cap_S, S)
+            cB = self._cap_B = max(self._cap_B, B)
+            self._alloc_S, self._alloc_B = cS, cB
+            dev = self.dev
+            self.pass_G = {k: _Pass(n, cS, cB, dev, True) for k, n in self.G.items()}
+            f32 = dict(device=dev, dtype=torch.float32)
+            self.ws3 = {k: torch.empty(p_.n_ws, **f32) for k, p_ in self.pass_G.items()}     # one workspace per generator stream
+            cfgc = _lib.DrnnCfg(cS, cB, self.Dm, self.H, self.He, self.p_rec, 1)
+            lib = _lib.load()
+            n_saved, n_ws = int(lib.ganffn_drnn_saved_floats(C.byref(cfgc))), int(lib.ganffn_drnn_workspace_floats(C.byref(cfgc)))
+            if n_saved < 0 or n_ws < 0:
+                _lib.check(-1, "ganffn_drnn_*_floats")
+            T, D2, Cn = cS * cB, 2 * self.He, self.n_classes
+            z = lambda n: torch.empty(n, **f32)
+            self._f = dict(fusion=z(T * self.Dm), rev_U=z(T * self.Dm), e_f=z(T * self.He), e_b=z(T * self.He),
+                           alpha_f=z(cB * cS * cS), alpha_b=z(cB * cS * cS), emotions=z(T * D2), xq=z(T * D2), att=z(T * D2),
+                           alpha2=z(cB * cS * cS), tanh_s=z(cB * cS * cS), du=z(cB * cS * cS), hidden=z(T * self.Dh2),
+                           logits=z(T * Cn), log_prob=z(T * Cn), dlogits=z(T * Cn), d_hidden=z(T * self.Dh2), d_att=z(T * D2),
+                           d_xq=z(T * D2), d_mem=z(T * D2), d_em=z(T * D2), d_e_f=z(T * self.He), d_e_b=z(T * self.He),
+                           dU_f=z(T * self.Dm), dU_b=z(T * self.Dm), saved_f=z(n_saved), saved_b=z(n_saved), ws_f=z(n_ws),
+                           ws_b=z(n_ws), lin_ws=z(int(lib.ganffn_linear_bwd_workspace_floats(T, D2, D2)) + 64))
+            self.ws2 = torch.zeros(4, **f32)
+        self._shape = (S, B)
+        for p_ in self.pass_G.values():
+            p_.resize(S, B)
+        self.cfg_train = _lib.DrnnCfg(S, B, self.Dm, self.H, self.He, self.p_rec, 1)
+        self.cfg_eval = _lib.DrnnCfg(S, B, self.Dm, self.H, self.He, self.p_rec, 0)
+
+    # ------------------------------------------------------------------------------------------
+    def _drnn_ptrs(self, grad):
+        out = []
+        for z in range(2):
+            s = _lib.DrnnPtrs()
+            for j, name in enumerate(_lib.DRNN_PARAM_FIELDS):
+                setattr(s, name, self._hp(13 * z + j, grad).data_ptr())
+            out.append(s)
+        return (_lib.DrnnPtrs * 2)(*out)
+
+    def step(self, batch, train=True):
+        """batch: acoustic/visual/text (S,B,.), qmask (S,B,2) one-hot (zero rows on padding), umask (B,S), label (B,S) int64.
+        Returns (loss tensor, log_prob (S,B,C)).  train=False: forward + loss only (model.eval())."""
+        S, B = batch["text"].shape[:2]
+        self._prepare5(S, B)
+        self._check_slabs()
+        if self._hparams[0].data_ptr() != self.h_slab.data_ptr():
+            raise RuntimeError("the DialogueRNN head was re-allocated after the engine was built: build DrnnEngine after the last .to()")
+        P, st_ = ops._ptr, ops._stream
+        T, Dm, He, D2, Cn = S * B, self.Dm, self.He, 2 * self.He, self.n_classes
+        f = self._f
+        self._adds = 0
+        self._base_add = self.rng.next_add(10)          # 3 generators x (encoder, head), the recurrence, the head's dropouts
+        a_rec, a_head = self._base_add + 6, self._base_add + 7
+        rng = self.rng.state
+        umask, qmask = batch["umask"], batch["qmask"]
+        # per-batch index data (tiny): dialogue lengths, speaker index / value per step, in both directions
+        lens = umask.sum(1).to(torch.int32)
+        spk_f = torch.argmax(qmask, 2).to(torch.int32).contiguous()
+        mval_f = qmask.max(2).values.contiguous()
+        t_idx = torch.arange(S, device=self.dev).unsqueeze(1)
+        src = (lens.to(torch.long).unsqueeze(0) - 1 - t_idx).clamp(min=0)
+        valid = (t_idx < lens.unsqueeze(0))
+        spk_b = (spk_f.gather(0, src) * valid).to(torch.int32).contiguous()
+        mval_b = (mval_f.gather(0, src) * valid).contiguous()
+
+        # ---- three generators, concurrently
+        keys = ("acoustic", "visual", "text")                        # model.py:1521-1523
+        adds = {}
+        cur = torch.cuda.current_stream()
+        if self.streams is not None:
+            fork = torch.cuda.Event()
+            fork.record(cur)
+        for i, k in enumerate(keys):
+            self.ws = self.ws3[k]
+            if self.streams is not None:
+                self.streams[i].wait_event(fork)
+                if batch[k].is_cuda:
+                    batch[k].record_stream(self.streams[i])      # the caller may drop the batch while this stream still reads it
+                with torch.cuda.stream(self.streams[i]):
+                    adds[k] = self._net_fwd(self.G[k], self.pass_G[k], batch[k], train=train, save=train)
+            else:
+                adds[k] = self._net_fwd(self.G[k], self.pass_G[k], batch[k], train=train, save=train)
+        if self.streams is not None:
+            for s_ in self.streams:
+                cur.wait_stream(s_)
+        st = st_()
+        _lib.call("ganffn_add3", P(self.pass_G["acoustic"].out), P(self.pass_G["visual"].out), P(self.pass_G["text"].out),
+                  P(f["fusion"]), C.c_int64(T * Dm), st)
+        _lib.call("ganffn_seq_reverse", P(f["fusion"]), P(lens), P(f["rev_U"]), S, B, Dm, 0, st)
+        # ---- the recurrence, both directions
+        cfg = self.cfg_train if train else self.cfg_eval
+        arr = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])
+        U_, spk_, mval_ = arr([f["fusion"], f["rev_U"]]), arr([spk_f, spk_b]), arr([mval_f, mval_b])
+        e_, al_, sv_, ws_ = arr([f["e_f"], f["e_b"]]), arr([f["alpha_f"], f["alpha_b"]]), arr([f["saved_f"], f["saved_b"]]), arr([f["ws_f"], f["ws_b"]])
+        Pp = self._drnn_ptrs(False)
+        _lib.call("ganffn_drnn_fwd", C.byref(cfg), 2, U_, spk_, mval_, Pp, e_, al_, sv_, ws_, P(rng), C.c_uint64(a_rec), st)
+        # ---- head: emotions -> matching attention -> linear/relu/dropout -> classes -> loss
+        tr = 1 if train else 0
+        _lib.call("ganffn_drnn_join_fwd", P(f["e_f"]), P(f["e_b"]), P(lens), P(f["emotions"]), S, B, He, C.c_float(self.p_join),
+                  C.c_uint32(SITE_JOIN_F), C.c_uint32(SITE_JOIN_B), P(rng), C.c_uint64(a_head), tr, st)
+        w_t, b_t, w_l, b_l, w_s, b_s = (self._hp(26 + j) for j in range(6))
+        ops.linear_fwd_raw(f["emotions"], w_t, b_t, f["xq"], T, D2, D2)
+        _lib.call("ganffn_general2_attention_fwd", P(f["xq"]), P(f["emotions"]), P(umask), P(f["att"]), P(f["alpha2"]), P(f["tanh_s"]),
+                  S, B, D2, st)
+        _lib.call("ganffn_ffn_linear1_fwd", P(f["att"]), P(w_l), P(b_l), P(f["hidden"]), T, D2, self.Dh2, C.c_float(self.p_hid),
+                  C.c_uint32(SITE_HIDDEN), P(rng), C.c_uint64(a_head), tr, st)
+        ops.linear_fwd_raw(f["hidden"], w_s, b_s, f["logits"], T, self.Dh2, Cn)
+        log_prob = f["log_prob"][:T * Cn].view(S, B, Cn)
+        ops.logsoftmax_nll_raw(f["logits"], batch["label"], umask, self.class_w, log_prob, self.loss,
+                               f["dlogits"] if train else None, self.ws2, S, B, Cn)
+        if not train:
+            return self.loss, log_prob
+        # ---- backward through the head
+        self.h_grad.zero_()
+        g_t, gb_t, g_l, gb_l, g_s, gb_s = (self._hp(26 + j, True) for j in range(6))
+        ops.linear_bwd_raw(f["dlogits"], f["hidden"], w_s, f["d_hidden"], g_s, gb_s, T, self.Dh2, Cn, f["lin_ws"])
+        mscale = 1.0 / (1.0 - self.p_hid) if self.p_hid > 0 else 1.0
+        _lib.call("ganffn_mask_pos_inplace", P(f["d_hidden"]), P(f["hidden"]), C.c_float(mscale), C.c_int64(T * self.Dh2), st)
+        ops.linear_bwd_raw(f["d_hidden"], f["att"], w_l, f["d_att"], g_l, gb_l, T, D2, self.Dh2, f["lin_ws"])
+        _lib.call("ganffn_general2_attention_bwd", P(f["d_att"]), P(f["xq"]), P(f["emotions"]), P(umask), P(f["alpha2"]), P(f["tanh_s"]),
+                  P(f["du"]), P(f["d_xq"]), P(f["d_mem"]), S, B, D2, st)
+        ops.linear_bwd_raw(f["d_xq"], f["emotions"], w_t, f["d_em"], g_t, gb_t, T, D2, D2, f["lin_ws"])
+        f["d_em"][:T * D2].add_(f["d_mem"][:T * D2])          # memory path of the attention + its transform(mem) path
+        _lib.call("ganffn_drnn_join_bwd", P(f["d_em"]), P(lens), P(f["d_e_f"]), P(f["d_e_b"]), S, B, He, C.c_float(self.p_join),
+                  C.c_uint32(SITE_JOIN_F), C.c_uint32(SITE_JOIN_B), P(rng), C.c_uint64(a_head), tr, st)
+        # ---- the recurrence backward (weight gradients accumulate into the zeroed head slab)
+        Gp = self._drnn_ptrs(True)
+        de_, dU_ = arr([f["d_e_f"], f["d_e_b"]]), arr([f["dU_f"], f["dU_b"]])
+        _lib.call("ganffn_drnn_bwd", C.byref(cfg), 2, de_, U_, spk_, mval_, Pp, Gp, dU_, al_, sv_, ws_, P(rng), C.c_uint64(a_rec), st)
+        # d fusion = dU_f + reverse(dU_b)
+        _lib.call("ganffn_seq_reverse", P(f["dU_b"]), P(lens), P(f["dU_f"]), S, B, Dm, 1, st)
+        d_fusion = f["dU_f"][:T * Dm].view(S, B, Dm)
+        # ---- head optimizer step (its all-reduce, when data-parallel, runs beside the generators' backward)
+        red_h = None
+        if self.pg is not None:
+            red_h = GradReducer(self.pg)
+            red_h.reduce_async(self.h_grad)
+        # ---- three generator backward passes + Adam, concurrently
+        if self.streams is not None:
+            fork = torch.cuda.Event()
+            fork.record(cur)
+        for i, k in enumerate(keys):
+            net = self.G[k]
+            self.ws = self.ws3[k]
+
+            def bwd():
+                net.grad.zero_()
+                cb, finish = self._make_reducer(net)
+                self._net_bwd(net, self.pass_G[k], d_fusion, True, adds[k], True, cb)
+                finish(("G", k))
+            if self.streams is not None:
+                self.streams[i].wait_event(fork)
+                with torch.cuda.stream(self.streams[i]):
+                    bwd()
+            else:
+                bwd()
+        if red_h is not None:
+            red_h.finish()
+        ops.adam_step_raw(self.h_slab, self.h_grad, self.h_m, self.h_v, self.h_step, self.h_total, self.lr, 0.9, 0.999, 1e-8,
+                          self.wd, 1.0 / self.world)
+        if self.streams is not None:
+            for s_ in self.streams:
+                cur.wait_stream(s_)
+        assert self._adds <= 6, self._adds
+        return self.loss, log_prob
+
+    @staticmethod
+    def predictions(log_prob):
+        return log_prob.transpose(0, 1).reshape(-1, log_prob.shape[2]).argmax(1)

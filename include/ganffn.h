@@ -236,6 +236,22 @@ int ganffn_drnn_bwd(const ganffn_drnn_cfg* cfg, int ndir, const float* const* d_
                     const float* const* saved, float* const* workspace, const uint64_t* rng,
                     uint64_t rng_offset_add, void* stream);
 
+/* Data movement of BiModel.forward around the recurrence (model.py:1008-1062), one launch each (csrc/drnn_head.hip):
+ * ganffn_seq_reverse: out[s, b, :] (+)= s < lens[b] ? x[lens[b]-1-s, b, :] : 0 — BiModel._reverse_seq and, being its own
+ *   transpose, its gradient (accumulate != 0 adds into out); x, out [S x B x D], D % 4 == 0.
+ * ganffn_drnn_join_fwd: emotions [S x B x 2 D_e] = cat(dropout(e_f), dropout(reverse(e_b))) with p = dropout_rec + ...
+ *   (BiModel.dropout_rec), two dropout sites; ganffn_drnn_join_bwd: the gradients of e_f and of e_b (in the reverse
+ *   direction's own order) from d_emotions, same masks.
+ * ganffn_mask_pos_inplace: d[i] = aux[i] > 0 ? d[i] * mscale : 0 — backward through dropout(relu(.)) from the saved output. */
+int ganffn_seq_reverse(const float* x, const int32_t* lens, float* out, int S, int B, int D, int accumulate, void* stream);
+int ganffn_drnn_join_fwd(const float* e_f, const float* e_b, const int32_t* lens, float* emotions, int S, int B, int De,
+                         float p, uint32_t site_f, uint32_t site_b, const uint64_t* rng, uint64_t rng_offset_add, int train,
+                         void* stream);
+int ganffn_drnn_join_bwd(const float* d_emotions, const int32_t* lens, float* d_e_f, float* d_e_b, int S, int B, int De,
+                         float p, uint32_t site_f, uint32_t site_b, const uint64_t* rng, uint64_t rng_offset_add, int train,
+                         void* stream);
+int ganffn_mask_pos_inplace(float* d, const float* aux, float mscale, int64_t n, void* stream);
+
 /* one launch of the recurrence's skinny product, `copies` (<= 4) independent problems sharing A: C_i[M x N] = A[M x K]
  * W_i^T (nn = 0, W_i [N x K]) or A W_i (nn = 1, W_i [K x N]); W / C hold the copies back to back; M <= 32 (unit tests and
  * the roofline leg of bench.py --config drnn) */
@@ -312,7 +328,10 @@ int ganffn_gemm_n100(const float* A, const float* W, int w_kmajor, const float* 
  *   bit 0: run the d_model-100 feed-forward block as the fused kernel of ffn.hip instead of two GEMMs (measured slower);
  *   bit 1: run the token-local chains around the LayerNorms of a d_model-100 layer (out-proj + LN1, LN2 + next in-proj and
  *          their backward mirrors, csrc/rowchain.hip) as separate GEMM + LayerNorm launches;
- *   bit 2: run the [T x 2048] x [2048 x 100] products on the generic 64 x 64 tiles instead of csrc/gemm_n100.hip.
+ *   bit 2: run the [T x 2048] x [2048 x 100] products on the generic 64 x 64 tiles instead of csrc/gemm_n100.hip;
+ *   bit 3: run the grouped weight-gradient launch of a d_model-100 pass on the generic 64 x 64 tiles instead of
+ *          csrc/gemm_tn100.hip;
+ *   bits 8..19: lab knobs (forced chunk counts of the two kernels above; 0 = choose).
  * Every combination is parity-tested; results agree to rounding. */
 int ganffn_debug_set_ffn_mode(int bits);
 

@@ -337,6 +337,44 @@ def test_ffn_fused_fwd_bwd(lib, T, p):
     assert rel_err(dx, dx_ref) < 3e-5
 
 
+@pytest.mark.parametrize("mode_bits", [0, 8, 2 << 16, 5 << 16])
+@pytest.mark.parametrize("K", [6016, 3008, 333, 40])
+def test_gemm_tn_grouped_d100_group(lib, K, mode_bits):
+    """the weight-gradient group of a d_model-100 encoder pass (every problem 100-wide on one side; two layers' worth, some
+    without a bias gradient, one with a strided gradient) on the 112-wide kernel (csrc/gemm_tn100.hip: default, and with
+    forced token-chunk counts) and on the generic 64 x 64 tiles (bit 3): gradients and bias gradients against fp64,
+    accumulation into non-zero slabs, ragged token counts (K % 32 != 0), bit-reproducible"""
+    probs = [(100, 2048), (2048, 100), (100, 100), (300, 100)] * 2
+    g = torch.Generator().manual_seed(K)
+    At = [dev(torch.randn(K, m, generator=g)) for (m, n) in probs]
+    Bm = [dev(torch.randn(K, n, generator=g)) for (m, n) in probs]
+    C0 = [torch.randn(m, n, generator=g) for (m, n) in probs]
+    S0 = [torch.randn(m, generator=g) for (m, n) in probs]
+    n = len(probs)
+    nws = int(lib.load().ganffn_gemm_tn_grouped_workspace_floats())
+    ws = torch.full((nws,), float("nan"), device="cuda")
+    arr = lambda ts: (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in ts])
+    Ms, Ns, Ks = (C.c_int * n)(*[p[0] for p in probs]), (C.c_int * n)(*[p[1] for p in probs]), (C.c_int * n)(*[K] * n)
+
+    def run():
+        Cd = [dev(c.clone()) for c in C0]
+        Sd = [dev(s_.clone()) if i != 5 else None for i, s_ in enumerate(S0)]         # problem 5: no bias gradient wanted
+        lib.call("ganffn_gemm_tn_grouped", n, arr(At), arr(Bm), arr(Cd), arr(Sd), Ms, Ns, Ks, ptr(ws), nws, stream())
+        return Cd, Sd
+    lib.load().ganffn_debug_set_ffn_mode(mode_bits)
+    try:
+        Cd, Sd = run()
+        Cd2, Sd2 = run()
+    finally:
+        lib.load().ganffn_debug_set_ffn_mode(0)
+    for i, (m, nn) in enumerate(probs):
+        ref = C0[i].double() + At[i].double().cpu().T @ Bm[i].double().cpu()
+        assert rel_err(Cd[i], ref) < 3e-6 * max(1, K ** 0.5), (i, probs[i])
+        if Sd[i] is not None:
+            assert rel_err(Sd[i], S0[i].double() + At[i].double().cpu().sum(0)) < 3e-6 * max(1, K ** 0.5), (i, probs[i])
+        assert torch.equal(Cd[i], Cd2[i]) and (Sd[i] is None or torch.equal(Sd[i], Sd2[i]))
+
+
 @pytest.mark.parametrize("use_ws", [False, True])
 def test_gemm_tn_grouped(lib, use_ws):
     """several weight-gradient GEMMs in one launch == each computed separately; with a workspace the narrow group splits
