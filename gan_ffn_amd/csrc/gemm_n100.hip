@@ -203,7 +203,7 @@ bool n100_supported(int N, int K) { return N == NE && K >= 256 && (K % NBK) == 0
 //  * K-major weights (58 LDS reads per tile instead of 16): T = 3008: 5 / 10 / 16 chunks 22.7 / 20.1 / 18.3 us — co-residency
 //    pays; T = 6016: 5 / 8 / 16 chunks 32.3 / 30.6 / 33.2 us.
 // Rule: rows-of-K: the launch's waves (4 per 64 tokens and chunk) fill the 1024 SIMDs in whole rounds, a round costs the
-// chunk's K tiles, fewer slabs win ties; K-major: the same with rounds of 3 workgroups per CU (768 workgroups).
+// chunk's K tiles; K-major: the same with rounds of 3 workgroups per CU (768 workgroups); plus the slab traffic.
 int n100_splits(int T, int K, int max_splits, int w_kmajor) {
     if (g_n100_force_splits > 0) return g_n100_force_splits < max_splits ? g_n100_force_splits : max_splits;
     const int tiles_m = (T + NBM - 1) / NBM, ksteps = K / NBK;
@@ -214,7 +214,9 @@ int n100_splits(int T, int K, int max_splits, int w_kmajor) {
         if ((s - 1) * per >= ksteps) continue;                       // an empty last chunk
         const long wgs = (long)tiles_m * s;
         const long rounds = w_kmajor ? (wgs + 767) / 768 : (wgs * 4 + 1023) / 1024;
-        const double cost = (double)rounds * per + (w_kmajor ? 0.02 : 0.15) * s;
+        // every slab is written here and read again by the LayerNorm-side consumer: 2 x T x 400 bytes of HBM traffic,
+        // ~0.8 tile-times per slab at T = 3008 (the consumer at T = 6016 with 8 slabs is bandwidth-bound on them: 19 MB)
+        const double cost = (double)rounds * per + 0.8 * ((double)T / 3008.0) * s;
         if (cost < best_cost) { best_cost = cost; best = s; }
     }
     return best;

@@ -88,6 +88,44 @@ def test_weight_resident_short_k_kernel_gives_the_generic_kernels_bits(lib):
     assert torch.equal(big2[:, :1000], small2)
 
 
+@pytest.mark.parametrize("mode_bits", [0])
+@pytest.mark.parametrize("T,p", [(3008, 0.1), (6016, 0.0), (21, 0.1), (1, 0.1), (333, 0.1)])
+def test_ffn_linear1_fwd_epilogue(lib, T, p, mode_bits):
+    """h = dropout(relu(x W1^T + b1)) (K = 100 -> 2048, the weight-resident kernel of gemm.hip): against fp64 with the Philox
+    mask of the contract, a second launch bit-identical, and a row's bits independent of its position (rows permuted in
+    -> rows permuted out)"""
+    E, F = 100, 2048
+    g = torch.Generator().manual_seed(T)
+    x, w1, b1 = torch.randn(T, E, generator=g), torch.randn(F, E, generator=g) / 10, torch.randn(F, generator=g) / 10
+    seed, off, add, site = 4242, 3, 11, 18
+    keep = torch.from_numpy(philox.keep_mask(T, F, p, site, seed, off + add)).double() / (1 - p) if p > 0 else torch.ones(T, F).double()
+    ref = torch.relu(x.double() @ w1.double().T + b1.double()) * keep
+    rng = torch.tensor([seed, off], dtype=torch.int64, device="cuda")
+    xd, wd, bd = dev(x), dev(w1), dev(b1)
+    lib.load().ganffn_debug_set_ffn_mode(mode_bits)
+    try:
+        h = torch.full((T, F), float("nan"), device="cuda")
+        lib.call("ganffn_ffn_linear1_fwd", ptr(xd), ptr(wd), ptr(bd), ptr(h), T, E, F, C.c_float(p), C.c_uint32(site), ptr(rng),
+                 C.c_uint64(add), 1, stream())
+        h2 = torch.empty_like(h)
+        lib.call("ganffn_ffn_linear1_fwd", ptr(xd), ptr(wd), ptr(bd), ptr(h2), T, E, F, C.c_float(p), C.c_uint32(site), ptr(rng),
+                 C.c_uint64(add), 1, stream())
+        assert torch.equal(h, h2)
+        # relu kinks: an element within rounding of zero may differ in sign; compare where |pre-activation| is not tiny
+        pre = x.double() @ w1.double().T + b1.double()
+        ok = pre.abs() > 1e-5
+        assert float(((h.double().cpu() - ref).abs() * ok).max()) < 5e-6 * float(ref.abs().max())
+        if p == 0.0 and T >= 64:
+            perm = torch.randperm(T, generator=g)
+            hp = torch.empty_like(h)
+            xp = dev(x[perm])
+            lib.call("ganffn_ffn_linear1_fwd", ptr(xp), ptr(wd), ptr(bd), ptr(hp), T, E, F, C.c_float(0.0), C.c_uint32(site), ptr(rng),
+                     C.c_uint64(add), 1, stream())
+            assert torch.equal(hp, h[perm.cuda()])
+    finally:
+        lib.load().ganffn_debug_set_ffn_mode(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 100, 3008), (2048, 100, 3008), (100, 2048, 3008), (1536, 512, 282),
                                    (100, 100, 14), (4, 4, 5), (68, 20, 65), (16, 64, 3008), (2048, 512, 6016)])
 def test_gemm_tn_acc(lib, M, N, K):
