@@ -195,6 +195,7 @@ class _Runner:
     """network-level forward / backward / Adam on preallocated buffers — shared by the GAN step runner and the
     phase-2 (classifier) step runner"""
     n_streams = 1
+    early_gen = False
     _cur_stream = None
     _base_add = 0
     _adds = 0
@@ -251,6 +252,7 @@ class GanEngine(_Runner):
             # eager streams additionally overlap consecutive iterations
             self.use_graph = use_graph = False
         self.stream_map = stream_maps[self.n_streams]
+        self.early_gen = self.n_streams > 1 and os.environ.get("GANFFN_EARLY_GEN", "0") == "1"
         if os.environ.get("GANFFN_STREAM_MAP"):
             self.stream_map = [int(x) for x in os.environ["GANFFN_STREAM_MAP"].split(",")]
             assert len(self.stream_map) == len(self.schedule) and max(self.stream_map) < self.n_streams
@@ -315,14 +317,16 @@ class GanEngine(_Runner):
         self._scratch_flat = [dict(ws=torch.empty(n_ws, **f32), x_cat=torch.empty(cS * 2 * cB * Dh, **f32),
                                    obj_out=torch.empty(cS * cB * Dh, **f32), dprob2=torch.empty(cS * 2 * cB, **f32),
                                    dprob1=torch.empty(cS * cB, **f32), d_real=torch.empty(cS * cB * Dh, **f32))
-                              for _ in range(self.n_streams)]
+                              for _ in range(self.n_streams * (2 if self.early_gen else 1))]
         if (S, B) != (cS, cB):
             self._resize_passes(S, B)
         self._view_scratch(S, B)
         if self.n_streams > 1 and self.streams is None:
             prio = [int(x) for x in os.environ.get("GANFFN_STREAM_PRIO", "").split(",") if x.strip()]
             prio = (prio + [0] * self.n_streams)[:self.n_streams]
-            self.streams = [torch.cuda.Stream(device=dev, priority=prio[i]) for i in range(self.n_streams)]
+            # main streams, then (early generator forward) one helper stream per main stream
+            self.streams = [torch.cuda.Stream(device=dev, priority=prio[i % self.n_streams])
+                            for i in range(self.n_streams * (2 if self.early_gen else 1))]
         self._res = {}
         self.static_batch = None
 
@@ -379,11 +383,15 @@ class GanEngine(_Runner):
         return self._base_add + v
 
     # ------------------------------------------------------------------------------------------
-    def _net_fwd(self, net, ps, x, train, save):
-        """encoder + head forward into ps.out; returns (enc_add, head_add) rng offsets used."""
+    def _net_fwd(self, net, ps, x, train, save, adds=None):
+        """encoder + head forward into ps.out; returns (enc_add, head_add) rng offsets used.  adds: the two dropout
+        offsets (relative to the iteration's block) when the caller assigns them by sub-step; else the next two."""
         cfg = ps.cfg_train if train else ps.cfg_eval
         hcfg = ps.hcfg_train if train else ps.hcfg_eval
-        a0, a1 = self._next_add(), self._next_add()
+        if adds is None:
+            a0, a1 = self._next_add(), self._next_add()
+        else:
+            a0, a1 = self._base_add + adds[0], self._base_add + adds[1]
         ops.encoder_fwd_raw(cfg, x, net.pe, net.slab, ps.enc_out, ps.saved if save else None, self.ws, self.rng.state, a0)
         w = net.w
         w3 = w("fc3.weight") if net.kind == 1 else None
@@ -451,15 +459,18 @@ class GanEngine(_Runner):
         S, B = batch[who].shape[:2]
         Dn, Gn = self.D[who], self.G[partner]
         pg_, pd = self.pass_G_nosave[partner], self.pass_D2[who]
+        # dropout offsets are assigned by sub-step (4 per sub-step: generator encoder / head, discriminator encoder / head), so
+        # they do not depend on the order in which streams issue their launches
+        a = ADDS_PER_SUBSTEP * loss_slot
         # fusion = G(real_gen) in eval mode, nothing saved (detach(), :218-219)
-        self._net_fwd(Gn, pg_, batch[partner], train=False, save=False)
+        self._net_fwd(Gn, pg_, batch[partner], train=False, save=False, adds=(a, a + 1))
         # real input of D_m is raw modality m; VisualDiscriminator maps 512 -> 100 first (model.py:1355-1356)
         x_real = batch[who]
         if Dn.has_obj:
             ops.linear_fwd_raw(x_real, Dn.w("object.weight"), Dn.w("object.bias"), self.obj_out, S * B, Dn.obj_in, self.D_h)
             x_real = self.obj_out
         torch.cat((x_real, pg_.out), dim=1, out=self.x_cat)
-        adds = self._net_fwd(Dn, pd, self.x_cat, train=True, save=True)
+        adds = self._net_fwd(Dn, pd, self.x_cat, train=True, save=True, adds=(a + 2, a + 3))
         n = S * 2 * B
         ops._lib.call("ganffn_bce2_fwd", ops._ptr(pd.out), C.c_float(1.0), C.c_float(0.0), 2 * B, B, n, C.c_float(1.0),
                       ops._ptr(self.losses[loss_slot:loss_slot + 1]), 0, ops._stream())
@@ -476,13 +487,21 @@ class GanEngine(_Runner):
                 cb(Dn.enc_floats, Dn.enc_floats + Dn.obj_floats, last=True)
         finish(("D", who))
 
-    def train_gen(self, who, partner, batch, loss_slot):
-        """train_IEMOCAP.py:230-252."""
+    def train_gen_forward(self, who, batch, loss_slot):
+        """the generator's own forward of train_gen (train mode, saved for backward): it reads nothing but the generator's
+        parameters and the batch, so the multi-stream scheduler may issue it ahead of the sub-step"""
+        a = ADDS_PER_SUBSTEP * loss_slot
+        return self._net_fwd(self.G[who], self.pass_G[who], batch[who], train=True, save=True, adds=(a, a + 1))
+
+    def train_gen(self, who, partner, batch, loss_slot, g_adds=None):
+        """train_IEMOCAP.py:230-252.  g_adds: the generator forward has already been issued (train_gen_forward)."""
         S, B = batch[who].shape[:2]
         Gn, Dn = self.G[who], self.D[partner]
         pg_, pd = self.pass_G[who], self.pass_D1[partner]
-        g_adds = self._net_fwd(Gn, pg_, batch[who], train=True, save=True)
-        d_adds = self._net_fwd(Dn, pd, pg_.out, train=False, save=True)       # disc.eval(), :243
+        a = ADDS_PER_SUBSTEP * loss_slot
+        if g_adds is None:
+            g_adds = self.train_gen_forward(who, batch, loss_slot)
+        d_adds = self._net_fwd(Dn, pd, pg_.out, train=False, save=True, adds=(a + 2, a + 3))       # disc.eval(), :243
         n = S * B
         ops.bce_fwd_raw(pd.out, 1.0, n, 1.0, self.losses[loss_slot:loss_slot + 1], False)
         ops.bce_bwd_raw(pd.out, 1.0, n, 1.0, self.dprob1)
@@ -507,6 +526,7 @@ class GanEngine(_Runner):
             # eager: this iteration's block of dropout offsets comes from the device's one allocator (shared with the
             # module path and every other engine); iterations may overlap, the offsets are host-side arguments
             self._base_add = self.rng.next_add(ADDS_PER_SUBSTEP * len(self.schedule))
+        self._adds = ADDS_PER_SUBSTEP * len(self.schedule)       # (offsets are assigned by sub-step: train_disc / train_gen)
         if self.n_streams == 1:
             for i, (kind, who, partner) in enumerate(self.schedule):
                 (self.train_disc if kind == "D" else self.train_gen)(who, partner, batch, i)
@@ -522,8 +542,32 @@ class GanEngine(_Runner):
                 for k in self.modalities:
                     if batch[k].is_cuda:
                         batch[k].record_stream(st)
+            early = {}
+            nsub = len(self.schedule)
             for i, (kind, who, partner) in enumerate(self.schedule):
                 st = self.streams[smap[i]]
+                # Early generator forward: the train-mode forward of the NEXT sub-step's generator reads only that generator's
+                # parameters (which this sub-step does not write) and the batch, so it is issued now, on this stream's helper
+                # stream, and runs beside this sub-step instead of after it.  (The visual generator's four sub-steps are a
+                # cycle — each needs the parameters the previous one wrote: its two train-mode forwards leave that chain.)
+                # Results do not change: same parameters, same dropout offsets (the multi-stream tests pass bit for bit with
+                # it on).  MEASURED SLOWER and therefore OFF by default (GANFFN_EARLY_GEN=1 enables it): 37.8 against 35.55 ms
+                # per step — the three streams already saturate the chip, more kernels in flight only slow each other down.
+                j = i + 1
+                if self.early_gen and j < nsub and self.schedule[j][0] == "G" and smap[j] == smap[i] and \
+                        (kind, who) != ("G", self.schedule[j][1]):
+                    gwho = self.schedule[j][1]
+                    hs = self.streams[self.n_streams + smap[j]]
+                    self._use_scratch(self.n_streams + smap[j])
+                    with torch.cuda.stream(hs):
+                        self._wait_writers(hs, [("G", gwho), ("buf", "G", gwho)])
+                        self._wait_readers(hs, [("buf", "G", gwho)])
+                        early[j] = self.train_gen_forward(gwho, batch, j)
+                        ev = torch.cuda.Event()
+                        ev.record(hs)
+                        self._r(("G", gwho)).reads.append(ev)        # a later writer of these parameters waits for this read
+                        rb = self._r(("buf", "G", gwho))
+                        rb.last_write, rb.reads = ev, []             # (the sub-step itself waits for it as the buffer's writer)
                 trained = (kind, who)
                 other = ("G" if kind == "D" else "D", partner)
                 # pass buffers are resources too (same (net, role) buffer reused by a later sub-step)
@@ -537,7 +581,10 @@ class GanEngine(_Runner):
                 with torch.cuda.stream(st):
                     self._wait_writers(st, [trained, other] + bufs)
                     self._wait_readers(st, bufs)
-                    (self.train_disc if kind == "D" else self.train_gen)(who, partner, batch, i)
+                    if kind == "D":
+                        self.train_disc(who, partner, batch, i)
+                    else:
+                        self.train_gen(who, partner, batch, i, g_adds=early.get(i))
                     self._done(st, reads=[other], writes=[trained] + bufs)
                 self._cur_stream = None
             self._cur_pg = self.pg
