@@ -73,7 +73,7 @@ def wgrad_groups(S, B, config="iemocap"):
             (2, [(m, n, T1) for _ in range(8) for (m, n) in e512])]
 
 
-TRAFFIC_FILE = "profiles/r02_wgrad_traffic.json"
+TRAFFIC_FILE = "profiles/r03_wgrad_traffic.json"
 
 
 def wgrad_algorithmic_bytes(S, B, config="iemocap"):
@@ -181,20 +181,75 @@ def time_linear1_kernel(S, B, reps=3):
     return e0.elapsed_time(e1) * 1e-3 / (reps * n), flops, n
 
 
-IN_STEP_FILE = "profiles/r02_bench_streams1_by_launch_shape.txt"
+def time_n100_kernel(S, B, reps=3):
+    """Live HIP-event timing (launch stream) of the [T x 2048] x [2048 x 100] family `gemm_n100_kernel` (csrc/gemm_n100.hip):
+    linear2 forward (weight rows of K; 112 launches at T = S*B and 48 at T = 2*S*B per iteration) and the linear1 dgrad
+    (K-major weight; 80 and 48).  Returns (avg seconds per launch, avg algorithmic flops per launch, launches)."""
+    from gan_ffn_amd import _lib, ops
+    st = ops._stream()
+    K = 2048
+    calls = []
+    for T, c_nt, c_km in ((S * B, 112, 80), (2 * S * B, 48, 48)):
+        A = torch.rand(T, K, device="cuda") - 0.5
+        Wn, Wk = (torch.rand(100, K, device="cuda") - 0.5) * 0.05, (torch.rand(K, 100, device="cuda") - 0.5) * 0.05
+        b, slabs, n = torch.zeros(100, device="cuda"), torch.empty(16, T, 100, device="cuda"), C.c_int(0)
+        calls.append((c_nt, T, (A, Wn, 0, b, slabs, n)))
+        calls.append((c_km, T, (A, Wk, 1, None, slabs, n)))
+
+    def one_iteration():
+        for cnt, T, (A, W, km, b, slabs, n) in calls:
+            for _ in range(cnt):
+                _lib.call("ganffn_gemm_n100", ops._ptr(A), ops._ptr(W), km, ops._ptr(b), ops._ptr(slabs), C.c_int64(T * 100), T, K, 16,
+                          C.byref(n), st)
+    one_iteration()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        one_iteration()
+    e1.record()
+    torch.cuda.synchronize()
+    nl = sum(c[0] for c in calls)
+    flops = sum(c[0] * 2.0 * c[1] * 100 * K for c in calls) / nl
+    return e0.elapsed_time(e1) * 1e-3 / (reps * nl), flops, nl
 
 
-def in_step_kernel_us(symbol_prefix, grid):
-    """average duration of a (kernel, grid) row of the committed single-stream rocprofv3 summary, or None"""
+IN_STEP_FILE = "profiles/r03_bench_streams1_by_launch_shape.txt"
+
+
+def in_step_kernel_us(symbol_prefix, grid=None):
+    """launch-weighted average duration of the (kernel, grid) rows of the committed single-stream rocprofv3 summary whose
+    symbol starts with symbol_prefix (grid: one row only), or None"""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), IN_STEP_FILE)
+    tot, n = 0.0, 0
     try:
         for line in open(path):
             f = line.split()
-            if len(f) >= 5 and f[3] == grid and " ".join(f[4:]).startswith(symbol_prefix):
-                return float(f[2])
+            if len(f) >= 5 and f[0].endswith("%") and " ".join(f[4:]).startswith(symbol_prefix) and (grid is None or f[3] == grid):
+                tot += float(f[2]) * int(f[1])
+                n += int(f[1])
     except Exception:
         pass
-    return None
+    return tot / n if n else None
+
+
+def in_step_wgrad_us():
+    """per logical weight-gradient launch, inside the single-stream step: (tn100_kernel + tn100_reduce_kernel) and
+    gemm_tn_grouped_kernel rows of the committed summary, weighted by launches"""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), IN_STEP_FILE)
+    tot, n = 0.0, 0
+    try:
+        for line in open(path):
+            f = line.split()
+            if len(f) >= 5 and f[0].endswith("%"):
+                name = " ".join(f[4:])
+                if name.startswith("tn100_kernel") or name.startswith("gemm_tn_grouped_kernel"):
+                    tot += float(f[2]) * int(f[1]); n += int(f[1])
+                elif name.startswith("tn100_reduce_kernel"):
+                    tot += float(f[2]) * int(f[1])
+    except Exception:
+        pass
+    return round(tot / n, 1) if n else None
 
 
 def cpu_baseline(S, B_sample, threads, dropout=True, config="iemocap"):
@@ -501,34 +556,51 @@ def main():
                        "step_tflops_reference_equivalent": round(step_tflops, 2),
                        "step_frac_of_fp32_mfma_peak": round(step_tflops * 1e12 / (FP32_MFMA_PEAK * world), 4),
                        "last_losses": {k: round(v, 4) for k, v in losses.items()}},
-            "roofline": {"bound": "mfma", "kernel": "gemm_tn_grouped_kernel (all 32 weight-gradient GEMMs of one encoder backward pass in one "
-                                                     "launch: one owner workgroup per output tile over the whole token range, no atomics); "
-                                                     "%d launches per iteration; the (kernel, launch shape) with the largest share of GPU "
-                                                     "time in the single-stream profile" % klaunch,
+            "roofline": {"bound": "mfma", "kernel": "the grouped weight-gradient launch = all 32 weight-gradient GEMMs (+ bias gradients) of one "
+                                                     "encoder backward pass: tn100_kernel + its ordered slab reduce for the d_model-100 "
+                                                     "networks (112-wide 16x16x4 tiles, csrc/gemm_tn100.hip), gemm_tn_grouped_kernel<false,128> "
+                                                     "for the d_model-512 generator; no atomics; %d launches per iteration; the kernel "
+                                                     "family with the largest share of GPU time in the single-stream profile" % klaunch,
                          "achieved": round(kflop / kt / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": round(kflop / kt / FP32_MFMA_PEAK, 4), "traffic": traffic,
                          "traffic_unit": "bytes per launch (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE, separate "
                                          "rocprofv3 --pmc passes: " + TRAFFIC_FILE + ")" if traffic is not None else None,
                          "algorithmic_bytes_per_launch": round(wgrad_algorithmic_bytes(S, B, cfgname)),
                          "avg_kernel_us": round(kt * 1e6, 2), "avg_gflop_per_launch": round(kflop / 1e9, 4),
-                         "how": "HIP events around one iteration's launch mix of this kernel replayed in isolation on the launch stream"},
+                         "how": "HIP events around one iteration's launch mix of this launch replayed in isolation on the launch "
+                                "stream; in_step_avg_us = the same launches inside the single-stream step, from the committed "
+                                "rocprofv3 summary " + IN_STEP_FILE,
+                         "in_step_avg_us": in_step_wgrad_us() if (cfgname == "iemocap" and (S, B) == (94, 32)) else None},
         }
         if cfgname == "iemocap":
-            # the heavy kernel (>= 5 % of GPU time in profiles/r02_bench_streams1_*) that sits LOWEST on its roofline
+            # heavy kernel FAMILIES (>= 5 % of GPU time in profiles/r03_bench_streams1_*: the K = 100 -> 2048 products of the
+            # d_model-100 feed-forward block, 16.6 %, and the 2048 -> 100 ones, 13.4 %), each timed live; the one that sits
+            # lowest on its roofline is reported as roofline_worst, the other beside it
             lt, lflop, ln = time_linear1_kernel(S, B)
-            ins = in_step_kernel_us("gemm_wres_kernel<0, 1, 100>", "(512,1,1)") if (S, B) == (94, 32) else None
-            out["roofline_worst"] = {
-                "bound": "mfma", "kernel": "gemm_wres_kernel<0,1,100> = linear1 of the d_model-100 feed-forward block with fused "
-                                           "bias + ReLU + dropout ([T x 100] x [2048 x 100]^T, K = 100; persistent, weight "
-                                           "fragments register-resident); %d launches per iteration (T = S*B and 2*S*B)" % ln,
-                "achieved": round(lflop / lt / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": round(lflop / lt / FP32_MFMA_PEAK, 4), "avg_kernel_us": round(lt * 1e6, 2),
-                "avg_gflop_per_launch": round(lflop / 1e9, 4), "traffic": None,
-                "in_step_avg_us": ins,
-                "in_step_frac": round(lflop / (ins * 1e-6) / FP32_MFMA_PEAK, 4) if ins else None,
-                "how": "HIP events around one iteration's launch mix of this kernel replayed in isolation on the launch stream; "
-                       "in_step_* = the same symbol's average over the same launch mix inside the single-stream step, from the "
-                       "committed rocprofv3 summary " + IN_STEP_FILE}
+            nt_, nflop, nn = time_n100_kernel(S, B)
+            full = (S, B) == (94, 32)
+            cands = [
+                {"kernel": "gemm_wres_kernel<0,1,100> = linear1 of the d_model-100 feed-forward block with fused bias + ReLU + "
+                           "dropout ([T x 100] x [2048 x 100]^T, K = 100; persistent, weight fragments register-resident); "
+                           "%d launches per iteration (T = S*B and 2*S*B)" % ln,
+                 "achieved": round(lflop / lt / 1e12, 2), "frac": round(lflop / lt / FP32_MFMA_PEAK, 4), "avg_kernel_us": round(lt * 1e6, 2),
+                 "avg_gflop_per_launch": round(lflop / 1e9, 4), "in_step_avg_us": in_step_kernel_us("gemm_wres_kernel<0, 1, 100>") if full else None},
+                {"kernel": "gemm_n100_kernel = [T x 2048] x [2048 x 100] on 16x16x4 MFMAs, 112-wide feature tile, K-chunk slabs "
+                           "(linear2 forward and the linear1 dgrad; csrc/gemm_n100.hip); %d launches per iteration" % nn,
+                 "achieved": round(nflop / nt_ / 1e12, 2), "frac": round(nflop / nt_ / FP32_MFMA_PEAK, 4), "avg_kernel_us": round(nt_ * 1e6, 2),
+                 "avg_gflop_per_launch": round(nflop / 1e9, 4), "in_step_avg_us": in_step_kernel_us("gemm_n100_kernel") if full else None},
+            ]
+            for c_ in cands:
+                c_.update({"bound": "mfma", "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "traffic": None})
+                if c_["in_step_avg_us"]:
+                    c_["in_step_frac"] = round(c_["avg_gflop_per_launch"] * 1e9 / (c_["in_step_avg_us"] * 1e-6) / FP32_MFMA_PEAK, 4)
+            cands.sort(key=lambda c_: c_["frac"])
+            out["roofline_worst"] = dict(cands[0])
+            out["roofline_worst"]["how"] = ("HIP events around one iteration's launch mix of this kernel replayed in isolation on the "
+                                            "launch stream; chosen as the lowest roofline fraction among the kernel families with >= 5 % "
+                                            "of GPU time; in_step_* = the same symbol's launch-weighted average inside the single-stream "
+                                            "step, from the committed rocprofv3 summary " + IN_STEP_FILE)
+            out["roofline_worst"]["other_heavy_families"] = cands[1:]
         if world == 1 and not args.no_cpu_baseline:
             threads = host_threads()
             print("[bench] cpu_baseline on %d host threads (affinity / cgroup share)" % threads, file=sys.stderr, flush=True)
