@@ -24,6 +24,16 @@ int launch_disc_tail_fwd(const float* a2, const float* w3, const float* b3, floa
 int launch_disc_tail_bwd(const float* dprob, const float* prob, const float* a2, const float* u2, const float* w3,
                          float* d_pre2, float* gw3, float* gb3, int T, int D2, float p, const uint64_t* rng, uint64_t add,
                          int train, hipStream_t st, float* gpart);
+int launch_disc_tail_reduce(const float* gpart, int nblk_, int D2, float* gw3, float* gb3, hipStream_t st);
+// disc_head.hip: the d_model-100 discriminator head (100 -> 64 -> 16 -> 1) as one kernel per direction
+bool disc_head_fused_supported(int E, int D1, int D2);
+int disc_head_blocks(int T);
+int launch_disc_head_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                         const float* b3, float* g0, float* u1, float* a1, float* u2, float* a2, float* prob, float* out, int T,
+                         float p, const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+int launch_disc_head_bwd(const float* dprob, const float* x, const float* w1, const float* w2, const float* w3, const float* u1,
+                         const float* u2, const float* a2, const float* prob, float* dx, float* d_pre1, float* d_pre2, float* gpart,
+                         int T, float p, const uint64_t* rng, uint64_t add, int train, hipStream_t st);
 int launch_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int T, int K, int N, hipStream_t st);
 int launch_small_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* gw, float* gb, int T, int K,
                             int N, hipStream_t st);
@@ -106,6 +116,9 @@ int g_rc_off = 0;
 // N = 100, long-K products (linear2 forward, linear1 dgrad) on the 112-wide 16x16x4 kernel (gemm_n100.hip); bit 2 of
 // ganffn_debug_set_ffn_mode switches back to the generic 64 x 64 tiles
 int g_n100_off = 0;
+// the discriminator head as one kernel per direction (disc_head.hip); bit 5 of ganffn_debug_set_ffn_mode switches back to
+// the separate GELU / GEMM / tail launches
+int g_dhead_off = 0;
 extern int g_n100_force_splits;
 extern int g_tn100_off, g_tn100_force_splits;
 extern unsigned long long* g_n100_stamps;
@@ -458,7 +471,8 @@ static int64_t head_part1(const ganffn_head_cfg* c) { return a4(gemm_tn_part_flo
 extern "C" int64_t ganffn_head_workspace_floats(const ganffn_head_cfg* c) {
     if (check_head(c) != 0) return -1;
     const int64_t T = c->T;
-    return a4(T * c->D1) + a4(T * c->D2) + head_part2(c) + head_part1(c) + ((T + 255) / 256) * 36 + 64;
+    const int64_t tail_blocks = disc_head_blocks((int)T) > (T + 255) / 256 ? disc_head_blocks((int)T) : (T + 255) / 256;
+    return a4(T * c->D1) + a4(T * c->D2) + head_part2(c) + head_part1(c) + tail_blocks * 36 + 64;
 }
 
 extern "C" int ganffn_head_fwd(const ganffn_head_cfg* c, const float* x, const float* w1, const float* b1, const float* w2,
@@ -482,6 +496,10 @@ extern "C" int ganffn_head_fwd(const ganffn_head_cfg* c, const float* x, const f
         GF_TRY(launch_gemm_nt(s0, E, w1, E, a1, D1, T, D1, E, EPI_DROP_GELU, e, st));
         e.bias = b2; e.site = SITE_HEAD2; e.aux_out = u2;
         GF_TRY(launch_gemm_nt(a1, D1, w2, D1, out, D2, T, D2, D1, EPI_DROP_GELU, e, st));
+    } else if (disc_head_fused_supported(E, D1, D2) && !g_dhead_off) {
+        float* a2 = u2 + (int64_t)T * D2;
+        float* prob = a2 + (int64_t)T * D2;
+        GF_TRY(launch_disc_head_fwd(x, w1, b1, w2, b2, w3, b3, s0, u1, a1, u2, a2, prob, out, T, c->p, rng, add, train, st));
     } else {
         float* a2 = u2 + (int64_t)T * D2;
         float* prob = a2 + (int64_t)T * D2;
@@ -518,6 +536,17 @@ extern "C" int ganffn_head_bwd(const ganffn_head_cfg* c, const float* d_out, con
     float* part2 = d_pre2 + a4((int64_t)T * D2);     // split-K slabs of gw2
     float* part1 = part2 + head_part2(c);            // split-K slabs of gw1
     float* tailp = part1 + head_part1(c);            // discriminator tail: per-block sums
+    if (c->kind == 1 && disc_head_fused_supported(E, D1, D2) && !g_dhead_off) {
+        // one kernel: dprob -> d_pre3 -> d_pre2 -> d_pre1 -> dx; the fc1 / fc2 weight gradients (token reductions) stay GEMMs
+        const float* a2 = u2 + (int64_t)T * D2;
+        const float* prob = a2 + (int64_t)T * D2;
+        GF_TRY(launch_disc_head_bwd(d_out, x, w1, w2, w3, u1, u2, a2, prob, dx, gw1 ? d_pre1 : nullptr, gw2 ? d_pre2 : nullptr,
+                                    gw3 ? tailp : nullptr, T, c->p, rng, add, train, st));
+        if (gw3) GF_TRY(launch_disc_tail_reduce(tailp, disc_head_blocks(T), D2, gw3, gb3, st));
+        if (gw2) GF_TRY(launch_gemm_tn_acc(d_pre2, D2, a1, D1, gw2, D1, gb2, D2, D1, T, st, part2, head_part2(c)));
+        if (gw1) GF_TRY(launch_gemm_tn_acc(d_pre1, D1, s0, E, gw1, E, gb1, D1, E, T, st, part1, head_part1(c)));
+        return 0;
+    }
     if (c->kind == 0) {
         // d_pre2 = d_out * gelu'(u2) * m2
         GF_TRY(launch_gelu_bwd_drop(d_out, u2, d_pre2, T, D2, c->p, SITE_HEAD2, rng, add, train, st));
@@ -616,6 +645,7 @@ extern "C" int ganffn_debug_set_ffn_mode(int bits) {
     g_ffn_fused = (bits & 1) ? 1 : 0;
     g_rc_off = (bits & 2) ? 1 : 0;
     g_n100_off = (bits & 4) ? 1 : 0;
+    g_dhead_off = (bits & 32) ? 1 : 0;
     g_tn100_off = (bits & 8) ? 1 : 0;
     g_tn100_force_splits = (bits >> 16) & 0xF;      // lab: force the token-chunk count of the d_model-100 grouped wgrad (0 = choose)
     g_n100_force_splits = (bits >> 8) & 0xFF;       // lab: force the K-chunk count of gemm_n100 (0 = choose)

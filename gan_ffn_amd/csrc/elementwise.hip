@@ -392,13 +392,19 @@ __global__ __launch_bounds__(256) void disc_tail_bwd_kernel(const float* __restr
         if (threadIdx.x == 32) gpart[blockIdx.x * 36 + 32] = red[0][32] + red[1][32] + red[2][32] + red[3][32];
     }
 }
-__global__ void disc_tail_reduce_kernel(const float* __restrict__ gpart, int nblk, int D2, float* __restrict__ gw3,
-                                        float* __restrict__ gb3) {
-    const int k = threadIdx.x;
-    if (k >= D2 && k != 32) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += gpart[b * 36 + k];
-    if (k == 32) gb3[0] += s; else gw3[k] += s;
+// one wave per output (gw3[0..D2-1], gb3 = slot 32): lanes stride over the blocks, fixed-order wave reduction
+__global__ __launch_bounds__(1024) void disc_tail_reduce_kernel(const float* __restrict__ gpart, int nblk, int D2, float* __restrict__ gw3,
+                                                                float* __restrict__ gb3) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int k = w; k <= D2; k += 16) {
+        const int slot = k < D2 ? k : 32;
+        float s = 0.f;
+        for (int b = lane; b < nblk; b += 64) s += gpart[b * 36 + slot];
+        s = wave_sum(s);
+        if (lane == 0) {
+            if (k < D2) gw3[k] += s; else gb3[0] += s;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -732,9 +738,17 @@ int launch_disc_tail_bwd(const float* dprob, const float* prob, const float* a2,
                        D2, p, rng, add, train, gpart);
     GF_LAUNCH_CHECK();
     if (gw3 != nullptr) {
-        hipLaunchKernelGGL(disc_tail_reduce_kernel, dim3(1), dim3(64), 0, st, (const float*)gpart, nb, D2, gw3, gb3);
+        hipLaunchKernelGGL(disc_tail_reduce_kernel, dim3(1), dim3(1024), 0, st, (const float*)gpart, nb, D2, gw3, gb3);
         GF_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// gw3[k] += sum_b gpart[b][k], gb3 += sum_b gpart[b][32] (partial sums in block order)
+int launch_disc_tail_reduce(const float* gpart, int nblk_, int D2, float* gw3, float* gb3, hipStream_t st) {
+    GF_CHECK_ARG(gpart && gw3 && gb3 && D2 <= 32 && nblk_ >= 1, "disc tail reduce: bad arguments");
+    hipLaunchKernelGGL(disc_tail_reduce_kernel, dim3(1), dim3(1024), 0, st, gpart, nblk_, D2, gw3, gb3);
+    GF_LAUNCH_CHECK();
     return 0;
 }
 

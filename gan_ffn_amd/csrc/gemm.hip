@@ -963,12 +963,18 @@ int launch_gemm_nn(const float* A, int lda, const float* Bm, int ldb, float* C, 
     EPI_SWITCH(MODE_NN, g, st)
 }
 
+// A one- or two-tile gradient (the discriminator head's fc1 [64 x 100] / fc2 [16 x 64]) used to be cut into K / 64 = 94
+// slabs: the 6 us GEMM was followed by a 40 us reduce launch whose 2-7 workgroups walk 94 slabs one batch of loads after
+// the other (profiles/r02_*: tn_reduce_kernel 1.4 % of the step).  16 slabs keep the GEMM as short and the reduce at its floor.
+constexpr long TN_ACC_MAXSPLIT = 16;
+
 // floats of partial-slab workspace a split TN launch of this shape can use (0: it will not split)
 long gemm_tn_part_floats(int M, int N, int K) {
     const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
     long splits = (768 + tiles - 1) / tiles;             // ~3 blocks per CU measured best (tools/gemm_bench.py)
     const long maxsplits = (K + 63) / 64;                // at least 64 k per block
     if (splits > maxsplits) splits = maxsplits;
+    if (splits > TN_ACC_MAXSPLIT) splits = TN_ACC_MAXSPLIT;
     if (splits <= 1) return 0;
     return splits * ((long)M * N + M);
 }
@@ -996,6 +1002,7 @@ int launch_gemm_tn_acc(const float* At, int lda, const float* Bm, int ldb, float
     long splits = (768 + tiles - 1) / tiles;
     const long maxsplits = (K + 63) / 64;
     if (splits > maxsplits) splits = maxsplits;
+    if (splits > TN_ACC_MAXSPLIT) splits = TN_ACC_MAXSPLIT;
     if (part_ws == nullptr) splits = 1;
     else if (splits * per > part_floats) splits = part_floats / per;
     if (splits < 1) splits = 1;

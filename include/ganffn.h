@@ -331,6 +331,7 @@ int ganffn_gemm_n100(const float* A, const float* W, int w_kmajor, const float* 
  *   bit 2: run the [T x 2048] x [2048 x 100] products on the generic 64 x 64 tiles instead of csrc/gemm_n100.hip;
  *   bit 3: run the grouped weight-gradient launch of a d_model-100 pass on the generic 64 x 64 tiles instead of
  *          csrc/gemm_tn100.hip;
+ *   bit 5: run the discriminator head as separate GELU / GEMM / tail launches instead of csrc/disc_head.hip;
  *   bits 8..19: lab knobs (forced chunk counts of the two kernels above; 0 = choose).
  * Every combination is parity-tested; results agree to rounding. */
 int ganffn_debug_set_ffn_mode(int bits);
