@@ -322,7 +322,11 @@ class GanEngine(_Runner):
             self._resize_passes(S, B)
         self._view_scratch(S, B)
         if self.n_streams > 1 and self.streams is None:
-            prio = [int(x) for x in os.environ.get("GANFFN_STREAM_PRIO", "").split(",") if x.strip()]
+            # stream priorities: the visual generator's chain (stream 2 of the 3-stream map: its four sub-steps are a cycle
+            # through G_v's parameters and pace the iteration) gets the high priority — measured 35.34 -> 34.90 ms per step
+            # (GANFFN_STREAM_PRIO="0,0,0" restores equal priorities; "-1,-1,0" measured 35.6)
+            default_prio = "0,0,-1" if (self.n_streams == 3 and len(self.schedule) == 12) else ""
+            prio = [int(x) for x in os.environ.get("GANFFN_STREAM_PRIO", default_prio).split(",") if x.strip()]
             prio = (prio + [0] * self.n_streams)[:self.n_streams]
             # main streams, then (early generator forward) one helper stream per main stream
             self.streams = [torch.cuda.Stream(device=dev, priority=prio[i % self.n_streams])
