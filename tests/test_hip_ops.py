@@ -413,6 +413,31 @@ def test_gemm_tn_grouped_d100_group(lib, K, mode_bits):
         assert torch.equal(Cd[i], Cd2[i]) and (Sd[i] is None or torch.equal(Sd[i], Sd2[i]))
 
 
+@pytest.mark.parametrize("T,K,N", [(2820, 200, 6), (3008, 100, 6), (37, 13, 3), (1, 4, 1), (500, 70, 7)])
+def test_linear_bwd_small_class_head(lib, T, K, N):
+    """ganffn_linear_fwd / _bwd on shapes the MFMA kernels do not take (N or K not a multiple of 4: the 6-class heads of
+    GAN_FFN.fc and BiModel.smax_fc, model.py:1432,1062): y, dx, dW (+=) and db (+=) against fp64; the weight gradient is
+    reduced over the tokens in a fixed order (second run bit-identical)"""
+    g = torch.Generator().manual_seed(T + K + N)
+    x, w, b, dy = torch.randn(T, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g), torch.randn(T, N, generator=g)
+    gw0, gb0 = torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+    y = torch.empty(T, N, device="cuda")
+    lib.call("ganffn_linear_fwd", ptr(xd), ptr(wd), ptr(bd), ptr(y), T, K, N, stream())
+    assert rel_err(y, x.double() @ w.double().T + b.double()) < 3e-6
+
+    def run():
+        dx, gw, gb = torch.empty(T, K, device="cuda"), dev(gw0.clone()), dev(gb0.clone())
+        lib.call("ganffn_linear_bwd", ptr(dyd), ptr(xd), ptr(wd), ptr(dx), ptr(gw), ptr(gb), T, K, N, None, C.c_int64(0), stream())
+        return dx, gw, gb
+    dx, gw, gb = run()
+    assert rel_err(dx, dy.double() @ w.double()) < 3e-6
+    assert rel_err(gw, gw0.double() + dy.double().T @ x.double()) < 3e-6 * max(1, T ** 0.5)
+    assert rel_err(gb, gb0.double() + dy.double().sum(0)) < 3e-6 * max(1, T ** 0.5)
+    dx2, gw2, gb2 = run()
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2) and torch.equal(dx, dx2)
+
+
 @pytest.mark.parametrize("use_ws", [False, True])
 def test_gemm_tn_grouped(lib, use_ws):
     """several weight-gradient GEMMs in one launch == each computed separately; with a workspace the narrow group splits
