@@ -437,6 +437,10 @@ def main():
                          "classifier step at batch 30")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step-only", action="store_true",
+                    help="time the step and print the line without the isolated kernel replays (roofline / roofline_worst) and "
+                         "without the CPU baseline: what tools/gpu_round.sh profiles, so that the rocprofv3 summaries hold the "
+                         "step's own launches only")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams running independent sub-steps concurrently")
     ap.add_argument("--cpu-sample-batch", type=int, default=None,
                     help="dialogues of the CPU-baseline sample (default: the whole batch, BASELINE.md §3)")
@@ -532,7 +536,11 @@ def main():
         print("[bench] gpu: %.3f ms/step, %.1f utterances/s (%s)" % (ms_per_step, value, "hipGraph" if use_graph else "eager"),
               file=sys.stderr, flush=True)
 
-    if rank == 0:
+    if rank == 0 and args.step_only:
+        print(json.dumps({"metric": "utterances/sec per GAN train step (step only)", "value": round(value, 2), "unit": "utterances/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+                          "config": {"workload": cfgname, "streams": eng.n_streams}}), flush=True)
+    elif rank == 0:
         kt, kflop, klaunch = time_dominant_kernel(S, B, config=cfgname)
         traffic = committed_traffic(S, B) if cfgname == "iemocap" else None
         fpt = flops_per_token(S, cfgname)
