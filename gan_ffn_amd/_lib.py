@@ -53,6 +53,7 @@ SIGNATURES = {
     "ganffn_pe_table": (_I, [_P, _I, _I, _P]),
     "ganffn_encoder_fwd": (_I, [_PE, _P, _P, _P, _P, _P, _P, _P, _U64, _P]),
     "ganffn_encoder_bwd": (_I, [_PE, _I, _I, _P, _P, _P, _P, _P, _P, _U64, _P]),
+    "ganffn_encoder_bwd2": (_I, [_PE, _I, _I, _P, _P, _P, _P, _P, _P, _U64, _I, _P]),
     "ganffn_head_fwd": (_I, [_PH, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _P]),
     "ganffn_head_bwd": (_I, [_PH, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U64, _P]),
     "ganffn_linear_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -119,6 +119,8 @@ int g_n100_off = 0;
 // the discriminator head as one kernel per direction (disc_head.hip); bit 5 of ganffn_debug_set_ffn_mode switches back to
 // the separate GELU / GEMM / tail launches
 int g_dhead_off = 0;
+// bit 6: positional encoding + dropout and layer 0's in-proj as two launches instead of rowchain.hip's one
+int g_pe_off = 0;
 extern int g_n100_force_splits;
 extern int g_tn100_off, g_tn100_force_splits;
 extern unsigned long long* g_n100_stamps;
@@ -225,14 +227,20 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
     float* pack = tmp + (int64_t)MAX_SPLITS * TE;
     const int64_t PK = fused ? ffn_pack_floats(F) : 0;
     if (fused) GF_TRY(launch_ffn_pack(params, lo.total, lo.w1, lo.w2, pack, L, F, 0, st));
-    GF_TRY(launch_pe_dropout(x_in, pe, Xcur, S, B, E, c->p_pe, rng, add, train, st));
-    // d_model 100: out-proj + residual + dropout + LN1 is one kernel, and LN2 carries the NEXT layer's in-proj (rowchain.hip)
+    // d_model 100: out-proj + residual + dropout + LN1 is one kernel, and LN2 carries the NEXT layer's in-proj (rowchain.hip);
+    // the positional encoding + dropout at the head of the stack carries layer 0's
     const bool rc = rc_supported(E) && !g_rc_off;
     auto layer_saved = [&](int l) { return saved ? saved + so.layers + (int64_t)l * so.per_layer : workspace + 2 * TE; };
-    if (rc) {
-        EpiArgs e0;
-        e0.bias = params + lo.in_b;
-        GF_TRY(launch_gemm_nt(Xcur, E, params + lo.in_w, E, layer_saved(0) + so.qkv, 3 * E, T, 3 * E, E, EPI_NONE, e0, st));
+    if (rc && !g_pe_off) {
+        GF_TRY(launch_rc_pe_inproj_fwd(x_in, pe, Xcur, params + lo.in_w, params + lo.in_b, layer_saved(0) + so.qkv, T, B, c->p_pe, rng,
+                                       add, train, st));
+    } else {
+        GF_TRY(launch_pe_dropout(x_in, pe, Xcur, S, B, E, c->p_pe, rng, add, train, st));
+        if (rc) {
+            EpiArgs e0;
+            e0.bias = params + lo.in_b;
+            GF_TRY(launch_gemm_nt(Xcur, E, params + lo.in_w, E, layer_saved(0) + so.qkv, 3 * E, T, 3 * E, E, EPI_NONE, e0, st));
+        }
     }
 
     for (int l = 0; l < L; ++l) {
@@ -295,9 +303,17 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
 // ------------------------------------------------------------------------------------------
 // encoder stack backward over layers [lo_l, hi_l)
 // ------------------------------------------------------------------------------------------
+extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int layer_hi, float* dx, const float* params,
+                                   float* grads, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
+                                   int need_dx_in, void* stream);
 extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int layer_hi, float* dx, const float* params,
                                   float* grads, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
                                   void* stream) {
+    return ganffn_encoder_bwd2(c, layer_lo, layer_hi, dx, params, grads, saved, workspace, rng, add, 1, stream);
+}
+extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int layer_hi, float* dx, const float* params,
+                                   float* grads, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
+                                   int need_dx_in, void* stream) {
     GF_TRY(check_cfg(c));
     GF_CHECK_ARG(dx && params && saved && workspace, "encoder_bwd: null pointer");
     GF_CHECK_ARG(0 <= layer_lo && layer_lo < layer_hi && layer_hi <= c->L, "encoder_bwd: bad layer range [%d,%d)", layer_lo, layer_hi);
@@ -435,12 +451,12 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
             GF_TRY(launch_gemm_nn(d_qkv, 3 * E, P + lo.in_w, E, tmp, E, T, E, 3 * E, EPI_NONE, eadd, st, &sp, TE));
             dxin = tmp;
             dxin_slabs = sp;
-        } else {
+        } else if (layer_lo > 0 || need_dx_in) {
             GF_TRY(launch_gemm_nn(d_qkv, 3 * E, P + lo.in_w, E, dx, E, T, E, 3 * E, EPI_NONE, eadd, st));
-        }
+        }   // (else: the stack's input needs no gradient — autograd would not compute this product either)
     }
     if (nred > 0) GF_TRY(launch_ln_param_reduce(nred, r_gw, r_gb, r_part, r_nb, E, st));
-    if (layer_lo == 0) GF_TRY(launch_dropout_bwd_inplace(dx, T, E, c->p_pe, SITE_PE, rng, add, train, st));
+    if (layer_lo == 0 && need_dx_in) GF_TRY(launch_dropout_bwd_inplace(dx, T, E, c->p_pe, SITE_PE, rng, add, train, st));
     return 0;
 }
 
@@ -648,6 +664,7 @@ extern "C" int ganffn_debug_set_ffn_mode(int bits) {
     g_rc_off = (bits & 2) ? 1 : 0;
     g_n100_off = (bits & 4) ? 1 : 0;
     g_dhead_off = (bits & 32) ? 1 : 0;
+    g_pe_off = (bits & 64) ? 1 : 0;
     g_tn100_off = (bits & 8) ? 1 : 0;
     g_tn100_force_splits = (bits >> 16) & 0xF;      // lab: force the token-chunk count of the d_model-100 grouped wgrad (0 = choose)
     g_n100_force_splits = (bits >> 8) & 0xFF;       // lab: force the K-chunk count of gemm_n100 (0 = choose)

@@ -279,13 +279,15 @@ __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __rest
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
     const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
-    float* Qs = smem;            // scaled q
-    float* Ks = Qs + MAT;
-    float* Vs = Ks + MAT;
-    float* Os = Vs + MAT;        // dO
-    float* Ls = Os + MAT;        // [ROWS] log-sum-exp per query (+big for padded rows)
+    // K, LSE and D live for the whole kernel; scaled q, V and dO are dead once dV / dK are accumulated, and the dS image
+    // takes their place (one more barrier) — at S = 94 that is 43 KB instead of 57 KB a workgroup: three per CU, not two
+    float* Ks = smem;
+    float* Ls = Ks + MAT;        // [ROWS] log-sum-exp per query (+big for padded rows)
     float* Ds = Ls + ROWS;       // [ROWS] D_i = sum_d dO_id O_id
-    float* SS = Ds + ROWS;       // [ROWS][LDS_S] dS
+    float* Qs = Ds + ROWS;       // scaled q
+    float* Vs = Qs + MAT;
+    float* Os = Vs + MAT;        // dO
+    float* SS = Qs;              // [ROWS][LDS_S] dS, over q / V / dO
     const int ld3 = 3 * E;
     const float scale = rsqrtf((float)HD);
     const DropCtx dc = make_drop(rng, add, site, p, train);
@@ -394,7 +396,8 @@ __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __rest
             }
         }
     }
-    // dS -> LDS [query][key]
+    // dS -> LDS [query][key], over the operands every wave has finished reading
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -440,7 +443,8 @@ template <int HD>
 static size_t fwd_lds(int nt) { return (size_t)3 * (16 * nt * A16<HD>::LD + A16<HD>::TAIL) * sizeof(float); }
 template <int HD>
 static size_t bwd_lds(int nt) {
-    return ((size_t)4 * (16 * nt * A16<HD>::LD + A16<HD>::TAIL) + 2 * 16 * nt + (size_t)16 * nt * (16 * nt + 4)) * sizeof(float);
+    const size_t mat = (size_t)16 * nt * A16<HD>::LD + A16<HD>::TAIL, img = (size_t)16 * nt * (16 * nt + 4);
+    return (mat + 2 * 16 * nt + (img > 3 * mat ? img : 3 * mat)) * sizeof(float);
 }
 
 template <int HD, int NT>

@@ -294,6 +294,8 @@ int launch_rc_pack(const float* params, long layer_stride, long off_in, long off
 int launch_rc_outproj_ln_fwd(const float* attn_o, const float* wo, const float* bo, const float* x, const float* gamma,
                              const float* beta, float* out, float* xhat, float* rstd, int T, float eps, float p, uint32_t site,
                              const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+int launch_rc_pe_inproj_fwd(const float* x_in, const float* pe, float* out, const float* w_in, const float* b_in, float* qkv, int T,
+                            int B, float p, const uint64_t* rng, uint64_t add, int train, hipStream_t st);
 int launch_rc_ln_inproj_fwd(const float* y, int nslab, long slab_stride, const float* x, const float* gamma, const float* beta,
                             float* out, float* xhat, float* rstd, const float* w_in, const float* b_in, float* qkv, int T,
                             float eps, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st);

@@ -113,7 +113,8 @@ __device__ __forceinline__ float token_allreduce(float v, float* __restrict__ re
 }
 
 struct RcFwdArgs {
-    // leading stage: y = pre_a . pre_w^T + pre_b (GEMM)  or  y = sum of nslab partial slabs
+    // leading stage (PRE): 1: y = pre_a . pre_w^T + pre_b (GEMM);  0: y = sum of nslab partial slabs;
+    // 2: no LayerNorm at all — out = dropout(x + y[t / B]) with y the positional-encoding table (model.py:1196-1197)
     const float* pre_a; const float* pre_w; const float* pre_b;
     const float* y; int nslab; long slab_stride;
     const float* x;                  // residual input [T x E]
@@ -121,11 +122,11 @@ struct RcFwdArgs {
     float* out; float* xhat; float* rstd;     // xhat / rstd may be null (nothing kept for backward)
     // trailing stage (optional): post_out [T x 3E] = out . post_w^T + post_b
     const float* post_w; const float* post_b; float* post_out;
-    int T; float eps, p; uint32_t site; const uint64_t* rng; uint64_t add; int train;
+    int T, B; float eps, p; uint32_t site; const uint64_t* rng; uint64_t add; int train;
 };
 
 // z = x + dropout(y); out = LayerNorm(z); optionally the next layer's in-proj on the fresh rows
-template <bool PRE_GEMM, bool POST_GEMM>
+template <int PRE, bool POST_GEMM>
 __global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
     constexpr int NP = 3 * RE, PT = (NP + 15) / 16;     // in-proj: 300 output features, 19 tiles
     __shared__ __attribute__((aligned(16))) float red[2 * 64];
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
     }
     Frag<RE> xf, wf[2];
     float4 bias[2], ysum[2];
-    if constexpr (PRE_GEMM) {
+    if constexpr (PRE == 1) {
         xf.load(a.pre_a + trow * RE, g);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -167,11 +168,16 @@ __global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         xv[i] = f4(a.x + trow * RE + f0c[i]);
-        gam[i] = f4(a.gamma + f0c[i]);
-        bet[i] = f4(a.beta + f0c[i]);
-        ysum[i] = zero4();
+        if constexpr (PRE == 2) {
+            gam[i] = bet[i] = zero4();
+            ysum[i] = f4(a.y + (trow / (size_t)a.B) * RE + f0c[i]);
+        } else {
+            gam[i] = f4(a.gamma + f0c[i]);
+            bet[i] = f4(a.beta + f0c[i]);
+            ysum[i] = zero4();
+        }
     }
-    if constexpr (!PRE_GEMM) {
+    if constexpr (PRE == 0) {
         for (int s0 = 0; s0 < a.nslab; s0 += 8) {            // 8 slabs' loads in flight at a time, added in slab order
             float4 v[8][2];
 #pragma unroll
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
 
     // ---------------- leading GEMM ----------------
     float y[2][4];
-    if constexpr (PRE_GEMM) {
+    if constexpr (PRE == 1) {
         floatx4 acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
         mma<RE, 2>(acc, wf, xf);
 #pragma unroll
@@ -219,21 +225,25 @@ __global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
         const float xr[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            z[i][r] = fok[i] ? __fmaf_rn(y[i][r], mult[r], xr[r]) : 0.f;
+            if constexpr (PRE == 2) z[i][r] = __fmul_rn(__fadd_rn(xr[r], y[i][r]), mult[r]);
+            else z[i][r] = fok[i] ? __fmaf_rn(y[i][r], mult[r], xr[r]) : 0.f;
             sum += z[i][r];
         }
     }
     const float invE = 1.0f / (float)RE;
-    const float mean = token_allreduce(sum, red, w, c, g) * invE;
-    float var = 0.f;
+    float mean = 0.f, rs = 1.f;
+    if constexpr (PRE != 2) {
+        mean = token_allreduce(sum, red, w, c, g) * invE;
+        float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float d = fok[i] ? __fsub_rn(z[i][r], mean) : 0.f;
-            var = __fmaf_rn(d, d, var);
-        }
-    const float rs = rsqrtf(token_allreduce(var, red + 64, w, c, g) * invE + a.eps);
+            for (int r = 0; r < 4; ++r) {
+                const float d = fok[i] ? __fsub_rn(z[i][r], mean) : 0.f;
+                var = __fmaf_rn(d, d, var);
+            }
+        rs = rsqrtf(token_allreduce(var, red + 64, w, c, g) * invE + a.eps);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const float gm[4] = {gam[i].x, gam[i].y, gam[i].z, gam[i].w}, bt[4] = {bet[i].x, bet[i].y, bet[i].z, bet[i].w};
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             xh[r] = __fmul_rn(__fsub_rn(z[i][r], mean), rs);
-            o[r] = __fmaf_rn(xh[r], gm[r], bt[r]);
+            o[r] = PRE == 2 ? z[i][r] : __fmaf_rn(xh[r], gm[r], bt[r]);
         }
         if (fok[i] && tok) {
             const size_t off = trow * RE + f0[i];
@@ -522,7 +532,7 @@ int launch_rc_outproj_ln_fwd(const float* attn_o, const float* wo, const float* 
     RcFwdArgs a{};
     a.pre_a = attn_o; a.pre_w = wo; a.pre_b = bo; a.x = x; a.gamma = gamma; a.beta = beta; a.out = out; a.xhat = xhat; a.rstd = rstd;
     a.T = T; a.eps = eps; a.p = p; a.site = site; a.rng = rng; a.add = add; a.train = train;
-    hipLaunchKernelGGL((rc_fwd_kernel<true, false>), dim3(rc_blocks(T)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((rc_fwd_kernel<1, false>), dim3(rc_blocks(T)), dim3(256), 0, st, a);
     GF_LAUNCH_CHECK();
     return 0;
 }
@@ -540,8 +550,22 @@ int launch_rc_ln_inproj_fwd(const float* y, int nslab, long slab_stride, const f
     a.y = y; a.nslab = nslab; a.slab_stride = slab_stride; a.x = x; a.gamma = gamma; a.beta = beta; a.out = out; a.xhat = xhat;
     a.rstd = rstd; a.post_w = w_in; a.post_b = b_in; a.post_out = qkv;
     a.T = T; a.eps = eps; a.p = p; a.site = site; a.rng = rng; a.add = add; a.train = train;
-    if (w_in) hipLaunchKernelGGL((rc_fwd_kernel<false, true>), dim3(rc_blocks(T)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((rc_fwd_kernel<false, false>), dim3(rc_blocks(T)), dim3(256), 0, st, a);
+    if (w_in) hipLaunchKernelGGL((rc_fwd_kernel<0, true>), dim3(rc_blocks(T)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((rc_fwd_kernel<0, false>), dim3(rc_blocks(T)), dim3(256), 0, st, a);
+    GF_LAUNCH_CHECK();
+    return 0;
+}
+
+// forward 0: x0 = dropout(x_in + pe[s]) and qkv of layer 0 = x0 . w_in^T + b_in — the head of an encoder stack as one launch
+int launch_rc_pe_inproj_fwd(const float* x_in, const float* pe, float* out, const float* w_in, const float* b_in, float* qkv, int T,
+                            int B, float p, const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
+    GF_CHECK_ARG(x_in && pe && out && w_in && b_in && qkv && T > 0 && B > 0, "rc_pe_inproj_fwd: bad arguments");
+    GF_CHECK_ARG(aligned16(x_in) && aligned16(pe) && aligned16(out) && aligned16(w_in) && aligned16(b_in) && aligned16(qkv),
+                 "rc_pe_inproj_fwd: operands must be 16-byte aligned");
+    RcFwdArgs a{};
+    a.y = pe; a.x = x_in; a.out = out; a.post_w = w_in; a.post_b = b_in; a.post_out = qkv;
+    a.T = T; a.B = B; a.p = p; a.site = SITE_PE; a.rng = rng; a.add = add; a.train = train;
+    hipLaunchKernelGGL((rc_fwd_kernel<2, true>), dim3(rc_blocks(T)), dim3(256), 0, st, a);
     GF_LAUNCH_CHECK();
     return 0;
 }

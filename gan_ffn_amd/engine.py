@@ -404,8 +404,9 @@ class GanEngine(_Runner):
                          ps.out, ps.hsaved, self.ws, self.rng.state, a1)
         return a0, a1
 
-    def _net_bwd(self, net, ps, d_out, train, adds, want_wgrad, reduce_cb=None):
-        """head + encoder backward; ps.dx <- dL/d(network input).  Weight grads accumulate into net.grad."""
+    def _net_bwd(self, net, ps, d_out, train, adds, want_wgrad, reduce_cb=None, need_dx=None):
+        """head + encoder backward; ps.dx <- dL/d(network input) when `need_dx` (default: exactly when the network is the
+        frozen one that only passes gradient through).  Weight grads accumulate into net.grad."""
         cfg = ps.cfg_train if train else ps.cfg_eval
         hcfg = ps.hcfg_train if train else ps.hcfg_eval
         a0, a1 = adds
@@ -417,15 +418,20 @@ class GanEngine(_Runner):
                          g("fc3.weight") if net.kind == 1 else None, g("fc3.bias") if net.kind == 1 else None,
                          ps.dx, ps.hsaved, self.ws, self.rng.state, a1)
         gslab = net.grad if want_wgrad else None
+        # the network being trained reads a raw modality or detached fakes: nobody consumes dL/d(its input)
+        # (train_IEMOCAP.py:200-252) — except the visual discriminator's `object` layer; the frozen discriminator of
+        # train_gen passes its input gradient on to the generator
+        if need_dx is None:
+            need_dx = not want_wgrad
         if reduce_cb is None or not want_wgrad:
-            ops.encoder_bwd_raw(cfg, 0, net.L, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0)
+            ops.encoder_bwd_raw(cfg, 0, net.L, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0, need_dx)
         else:
             # bucketed: backward a group of layers, then hand that slice of the grad slab to the all-reduce
             bks = net.buckets(self.n_buckets)
             reduce_cb(*bks[0], last=False)                       # head (+object handled by caller before this)
             for i, (lo_f, hi_f) in enumerate(bks[1:]):
                 lo, hi = lo_f // net.layer_floats, hi_f // net.layer_floats
-                ops.encoder_bwd_raw(cfg, lo, hi, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0)
+                ops.encoder_bwd_raw(cfg, lo, hi, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0, need_dx)
                 reduce_cb(lo_f, hi_f, last=(i == len(bks) - 2))
 
     def _adam(self, net):
@@ -482,7 +488,7 @@ class GanEngine(_Runner):
                       ops._ptr(self.dprob2), ops._stream())
         Dn.grad.zero_()                                              # opt.zero_grad(), :216
         cb, finish = self._make_reducer(Dn)
-        self._net_bwd(Dn, pd, self.dprob2, True, adds, True, cb)
+        self._net_bwd(Dn, pd, self.dprob2, True, adds, True, cb, need_dx=Dn.has_obj)
         if Dn.has_obj:
             self.d_real.copy_(pd.dx[:, :B])                      # gradient of the real half of the batch
             ops.linear_bwd_raw(self.d_real, batch[who], Dn.w("object.weight"), None, Dn.w("object.weight", True),

@@ -138,9 +138,11 @@ def encoder_fwd_raw(cfg, x, pe, slab, out, saved, ws, rng, add):
               _ptr(rng), C.c_uint64(add), _stream())
 
 
-def encoder_bwd_raw(cfg, lo, hi, dx, slab, gslab, saved, ws, rng, add):
-    _lib.call("ganffn_encoder_bwd", C.byref(cfg), lo, hi, _ptr(dx), _ptr(slab), _ptr(gslab), _ptr(saved), _ptr(ws),
-              _ptr(rng), C.c_uint64(add), _stream())
+def encoder_bwd_raw(cfg, lo, hi, dx, slab, gslab, saved, ws, rng, add, need_dx_in=True):
+    """need_dx_in=False: the stack's input needs no gradient — with lo == 0 the bottom in-proj dgrad and the PE dropout
+    backward are skipped (as autograd skips them) and dx is undefined afterwards."""
+    _lib.call("ganffn_encoder_bwd2", C.byref(cfg), lo, hi, _ptr(dx), _ptr(slab), _ptr(gslab), _ptr(saved), _ptr(ws),
+              _ptr(rng), C.c_uint64(add), 1 if need_dx_in else 0, _stream())
 
 
 def head_fwd_raw(cfg, x, w1, b1, w2, b2, w3, b3, out, saved, ws, rng, add):
@@ -254,7 +256,8 @@ class EncoderFn(torch.autograd.Function):
         ws = torch.empty(n_ws, device=dx.device, dtype=torch.float32)
         want_w = any(ctx.needs_input_grad[4:])
         gslab = torch.zeros_like(ctx.slab) if want_w else None
-        encoder_bwd_raw(cfg, 0, cfg.L, dx, ctx.slab, gslab, ctx.saved, ws, ctx.rng_state, ctx.add)
+        encoder_bwd_raw(cfg, 0, cfg.L, dx, ctx.slab, gslab, ctx.saved, ws, ctx.rng_state, ctx.add,
+                        need_dx_in=ctx.needs_input_grad[0])
         grads = [None] * len(meta["views"])
         if want_w:
             for i, (off, shape) in enumerate(meta["views"]):

@@ -120,6 +120,14 @@ int ganffn_encoder_bwd(const ganffn_enc_cfg* cfg, int layer_lo, int layer_hi, fl
                        const float* params, float* grads, const float* saved, float* workspace,
                        const uint64_t* rng, uint64_t rng_offset_add, void* stream);
 
+/* The same with need_dx_in = 0 when the stack's input needs no gradient (a network trained on data or on detached
+ * fakes: train_disc / train_gen, train_IEMOCAP.py:200-252 — the networks' own inputs there are raw modalities or `.detach()`ed): with layer_lo == 0
+ * the bottom layer's in-proj dgrad and the PE dropout backward are skipped, as autograd skips them for an input that does
+ * not require grad, and dx is then left UNDEFINED on exit.  need_dx_in = 1 is ganffn_encoder_bwd. */
+int ganffn_encoder_bwd2(const ganffn_enc_cfg* cfg, int layer_lo, int layer_hi, float* dx,
+                        const float* params, float* grads, const float* saved, float* workspace,
+                        const uint64_t* rng, uint64_t rng_offset_add, int need_dx_in, void* stream);
+
 /* ---- A3-A6: heads ------------------------------------------------------------------- */
 /* x [T x E] = encoder output.  w1[D1,E] b1[D1] w2[D2,D1] b2[D2]; disc only: w3[1,D2] b3[1].
  * out: gen -> fusion [T x D2]; disc -> prob [T x 1]. */
@@ -332,6 +340,8 @@ int ganffn_gemm_n100(const float* A, const float* W, int w_kmajor, const float* 
  *   bit 3: run the grouped weight-gradient launch of a d_model-100 pass on the generic 64 x 64 tiles instead of
  *          csrc/gemm_tn100.hip;
  *   bit 5: run the discriminator head as separate GELU / GEMM / tail launches instead of csrc/disc_head.hip;
+ *   bit 6: run the head of a d_model-100 encoder stack (positional encoding + dropout, layer 0's in-proj) as two launches
+ *          instead of one (csrc/rowchain.hip);
  *   bits 8..19: lab knobs (forced chunk counts of the two kernels above; 0 = choose).
  * Every combination is parity-tested; results agree to rounding. */
 int ganffn_debug_set_ffn_mode(int bits);

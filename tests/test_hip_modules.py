@@ -190,7 +190,7 @@ def test_cpu_tensor_fails_loudly():
         m(torch.zeros(4, 2, 100))
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 6, 8, 32, 46])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 6, 8, 32, 46, 64])
 def test_fused_ffn_modes_agree_with_fixture(mode):
     """the encoder's FFN runs as two GEMMs (bit 0 clear, the default) or as the fused kernel (bit 0 set); the token-local
     chains around the LayerNorms of a d_model-100 layer run as single kernels (rowchain.hip; bit 1 clear, the default) or
