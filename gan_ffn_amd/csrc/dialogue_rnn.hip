@@ -12,9 +12,10 @@
 // Why not one kernel per dialogue: a step needs every cell's full weight matrix (12.7 MB per direction); one workgroup
 // per dialogue would stream that through ONE CU 94 times.  Instead the dialogues are the N axis (<= 32 per tile) of
 // skinny matrix products that spread a cell's weight rows over ~100-200 workgroups, and the S steps are a chain of small
-// launches (4 per step forward, 4 backward, both directions of BiModel in the same launches; independent pieces of a step
-// share a launch: the global cell's gate math with the step's context attention, the party-gradient assembly with the
-// next step's party gate kernel):
+// launches (3 per step forward, 3 backward, both directions of BiModel in the same launches; independent pieces of a step
+// share a launch: within step t the global and the party cell do not depend on each other — the party cell reads the
+// context over g_0 .. g_{t-1}, not g_t — so their four products are one launch and their gate kernels another; round 2
+// ran them one after the other, 4 + 4 launches per step):
 //   * everything that depends on U alone is hoisted out of the recurrence into three ordinary GEMMs over all steps
 //     (x-parts of the g / p cells incl. b_ih, and the attention query W_a U_t);
 //   * skinny_nt / skinny_nn: C[B x N] = A[B x K] W^T resp. A W on v_mfma_f32_16x16x4_f32 (exact fp32): a workgroup owns
@@ -48,7 +49,7 @@ struct SkinnyProb {
     int M, N, K;
 };
 struct SkinnyGroup {
-    SkinnyProb p[4];
+    SkinnyProb p[8];      // a step's products of both cells (2 each) in both directions
 };
 
 // NT: C[b][n] = sum_k A[b][k] W[n][k] (+ Cin[b][n] + bias[n]).  Workgroup = 16 weight rows x 32 dialogues, 4 waves split K.
@@ -248,6 +249,12 @@ template <int PARTY>
 __global__ __launch_bounds__(256) void gru_gate_fwd_kernel(GateArgs a) {
     gru_gate_fwd_body<PARTY>(a, a.d[blockIdx.z], blockIdx.x * 256 + threadIdx.x);
 }
+// both cells of a step in one launch (they are independent: the party cell reads the context of g_0 .. g_{t-1}, not g_t):
+// blockIdx.y = 0 global cell, 1 party cell
+__global__ __launch_bounds__(256) void drnn_gates_fwd_kernel(GateArgs g, GateArgs p) {
+    if (blockIdx.y == 0) gru_gate_fwd_body<0>(g, g.d[blockIdx.z], blockIdx.x * 256 + threadIdx.x);
+    else gru_gate_fwd_body<1>(p, p.d[blockIdx.z], blockIdx.x * 256 + threadIdx.x);
+}
 
 struct GateBwdDir {
     const float* dh;        // [B x H] gradient wrt the cell output AFTER dropout (g / e cells) or wrt Q[t+1][spk] (party cell)
@@ -312,6 +319,12 @@ __device__ __forceinline__ void gru_gate_bwd_body(const GateBwdArgs& a, const Ga
 template <int PARTY>
 __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(GateBwdArgs a) {
     gru_gate_bwd_body<PARTY>(a, a.d[blockIdx.z], blockIdx.x * 256 + threadIdx.x);
+}
+// both cells' gate gradients of a step in one launch: dG[t+1] is final once step t + 1 is through, so the global cell does
+// not have to wait for this step's party products and attention
+__global__ __launch_bounds__(256) void drnn_gates_bwd_kernel(GateBwdArgs g, GateBwdArgs p) {
+    if (blockIdx.y == 0) gru_gate_bwd_body<0>(g, g.d[blockIdx.z], blockIdx.x * 256 + threadIdx.x);
+    else gru_gate_bwd_body<1>(p, p.d[blockIdx.z], blockIdx.x * 256 + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -405,15 +418,6 @@ __device__ __forceinline__ void drnn_attn_fwd_body(const AttnArgs& a, const Attn
 }
 __global__ __launch_bounds__(DR_AT) void drnn_attn_fwd_kernel(AttnArgs a) { drnn_attn_fwd_body(a, a.d[blockIdx.z], blockIdx.x); }
 
-// One launch for two INDEPENDENT pieces of a step: the global cell's gate math (needs this step's skinny products) and
-// the context attention of the same step (needs only g_0 .. g_{t-1}).  Blocks [0, gate_blocks) run the gate body with
-// 1024 threads each, the rest one dialogue's attention each.
-struct GateAttnArgs { GateArgs g; AttnArgs at; int gate_blocks; };
-__global__ __launch_bounds__(DR_AT) void drnn_gate_attn_fwd_kernel(GateAttnArgs a) {
-    if ((int)blockIdx.x < a.gate_blocks) gru_gate_fwd_body<0>(a.g, a.g.d[blockIdx.z], blockIdx.x * DR_AT + threadIdx.x);
-    else drnn_attn_fwd_body(a.at, a.at.d[blockIdx.z], blockIdx.x - a.gate_blocks);
-}
-
 struct AttnBwdDir {
     const float* dCT;    // [B x H]
     const float* XA;     // [B x H]
@@ -472,14 +476,6 @@ __device__ __forceinline__ void drnn_attn_bwd_body(const AttnBwdArgs& a, const A
     if (!half && k < a.H) d.dXA[(size_t)b * a.H + k] = dx + part[k];
 }
 __global__ __launch_bounds__(DR_AT) void drnn_attn_bwd_kernel(AttnBwdArgs a) { drnn_attn_bwd_body(a, a.d[blockIdx.z], blockIdx.x); }
-
-// backward counterpart of drnn_gate_attn_fwd_kernel: the attention backward of step t (adds into dG rows <= t, writes
-// dXA[t]) and the global cell's gate backward of the same step (reads dG row t+1 and the saved gates) touch disjoint data
-struct GateAttnBwdArgs { GateBwdArgs g; AttnBwdArgs at; int gate_blocks; };
-__global__ __launch_bounds__(DR_AT) void drnn_gate_attn_bwd_kernel(GateAttnBwdArgs a) {
-    if ((int)blockIdx.x < a.gate_blocks) gru_gate_bwd_body<0>(a.g, a.g.d[blockIdx.z], blockIdx.x * DR_AT + threadIdx.x);
-    else drnn_attn_bwd_body(a.at, a.at.d[blockIdx.z], blockIdx.x - a.gate_blocks);
-}
 
 // ------------------------------------------------------------------------------------------
 // Emotion cell as ONE chain per dialogue (round 2).  e_t = drop(GRU_e(q_t[spk], e_{t-1})) takes q_t from the party cell
@@ -666,19 +662,19 @@ static DrnnSaved drnn_saved(const ganffn_drnn_cfg* c) {
     return s;
 }
 struct DrnnWs {
-    int64_t GI, GH, dGIg, dGHg, dGIp, dGHp, dGIe, dGHe, dXA, dCT, dG, dQa, dQb, dEa, dEb, dQsel, dQSp, dQSg, dhdir, dQN, GIe, dQNall, total;
+    int64_t GI, GH, GIp, GHp, dGIg, dGHg, dGIp, dGHp, dGIe, dGHe, dXA, dCT, dG, dQa, dQb, dEa, dEb, dQsel, dQSp, dQSg, dhdir, dhdirG, dQN, GIe, dQNall, total;
 };
 static DrnnWs drnn_ws(const ganffn_drnn_cfg* c) {
     DrnnWs w;
     const int64_t T = (int64_t)c->S * c->B, T1 = (int64_t)(c->S + 1) * c->B, B = c->B, H = c->H, He = c->He;
     int64_t p = 0;
     auto take = [&](int64_t n) { int64_t r = p; p += (n + 3) & ~int64_t(3); return r; };
-    w.GI = take(B * 3 * H); w.GH = take(B * 3 * H);
+    w.GI = take(B * 3 * H); w.GH = take(B * 3 * H); w.GIp = take(B * 3 * H); w.GHp = take(B * 3 * H);
     w.dGIg = take(T * 3 * H); w.dGHg = take(T * 3 * H); w.dGIp = take(T * 3 * H); w.dGHp = take(T * 3 * H);
     w.dGIe = take(T * 3 * He); w.dGHe = take(T * 3 * He);
     w.dXA = take(T * H); w.dCT = take(B * H); w.dG = take(T1 * H);
     w.dQa = take(B * 2 * H); w.dQb = take(B * 2 * H); w.dEa = take(B * He); w.dEb = take(B * He);
-    w.dQsel = take(B * H); w.dQSp = take(B * H); w.dQSg = take(B * H); w.dhdir = take(B * H); w.dQN = take(B * H);
+    w.dQsel = take(B * H); w.dQSp = take(B * H); w.dQSg = take(B * H); w.dhdir = take(B * H); w.dhdirG = take(B * H); w.dQN = take(B * H);
     w.GIe = take(T * 3 * He); w.dQNall = take(T * H);       // emotion chain: input pre-activations / dQN of all steps
     w.total = p;
     return w;
@@ -754,53 +750,43 @@ extern "C" int ganffn_drnn_fwd(const ganffn_drnn_cfg* c, int ndir, const float* 
     }
     const dim3 gH((B * H + 255) / 256, 1, ndir), gHe((B * He + 255) / 256, 1, ndir);
     const bool echain = He <= EC_MAXHE;          // emotion cell as one chain per dialogue after the main loop
+    // A step is three launches: the context attention over g_0 .. g_{t-1}; the four products of the global and the party
+    // cell (the party cell needs c_t but not g_t, the global cell neither: they are independent within a step); both
+    // cells' gate math.
     for (int t = 0; t < S; ++t) {
         const int64_t r0 = (int64_t)t * B, r1 = (int64_t)(t + 1) * B;
         SkinnyGroup sg;
+        if (t > 0) {
+            AttnArgs at;
+            at.B = B; at.H = H; at.S = S; at.t = t;
+            for (int z = 0; z < ndir; ++z) at.d[z] = AttnDir{saved[z] + so.XA + r0 * H, saved[z] + so.G, saved[z] + so.CT + r0 * H, alpha[z]};
+            hipLaunchKernelGGL(drnn_attn_fwd_kernel, dim3(B, 1, ndir), dim3(DR_AT), 0, st, at);
+            GF_LAUNCH_CHECK();
+        }
         // ---- global cell: GI = XG[t] + QS[t] Wih_g[:, Dm:]^T ; GH = G[t] Whh_g^T + bhh_g
+        // ---- party cell (speaker): GI = XP[t] + CT[t] Wih_p[:, Dm:]^T ; GH = QS[t] Whh_p^T + bhh_p
         for (int z = 0; z < ndir; ++z) {
             float* sv = saved[z]; float* ws = workspace[z];
-            sg.p[2 * z] = SkinnyProb{sv + so.QS + r0 * H, H, prm[z].g_wih + Dm, Dm + H, sv + so.XG + r0 * 3 * H, 3 * H, nullptr, nullptr, ws + wo.GI, 3 * H, B, 3 * H, H};
-            sg.p[2 * z + 1] = SkinnyProb{sv + so.G + r0 * H, H, prm[z].g_whh, H, nullptr, 0, nullptr, prm[z].g_bhh, ws + wo.GH, 3 * H, B, 3 * H, H};
+            sg.p[4 * z] = SkinnyProb{sv + so.QS + r0 * H, H, prm[z].g_wih + Dm, Dm + H, sv + so.XG + r0 * 3 * H, 3 * H, nullptr, nullptr, ws + wo.GI, 3 * H, B, 3 * H, H};
+            sg.p[4 * z + 1] = SkinnyProb{sv + so.G + r0 * H, H, prm[z].g_whh, H, nullptr, 0, nullptr, prm[z].g_bhh, ws + wo.GH, 3 * H, B, 3 * H, H};
+            sg.p[4 * z + 2] = SkinnyProb{sv + so.CT + r0 * H, H, prm[z].p_wih + Dm, Dm + H, sv + so.XP + r0 * 3 * H, 3 * H, nullptr, nullptr, ws + wo.GIp, 3 * H, B, 3 * H, H};
+            sg.p[4 * z + 3] = SkinnyProb{sv + so.QS + r0 * H, H, prm[z].p_whh, H, nullptr, 0, nullptr, prm[z].p_bhh, ws + wo.GHp, 3 * H, B, 3 * H, H};
         }
-        GF_TRY(launch_skinny(sg, 2 * ndir, false, st));
-        GateArgs ga;
+        GF_TRY(launch_skinny(sg, 4 * ndir, false, st));
+        GateArgs ga, gp;
         ga.B = B; ga.H = H; ga.row0 = (int)r0; ga.p = c->p; ga.train = c->train; ga.rng = rng; ga.add = add;
+        gp = ga;
         for (int z = 0; z < ndir; ++z) {
             float* sv = saved[z]; float* ws = workspace[z];
             ga.d[z] = GateDir{ws + wo.GI, ws + wo.GH, sv + so.G + r0 * H, sv + so.Rg + r0 * H, sv + so.Zg + r0 * H, sv + so.Ng + r0 * H,
                               sv + so.HNg + r0 * H, sv + so.G + r1 * H, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                               SITE_DRNN_G + 4u * z};
-        }
-        // ---- ... together with the context attention over g_0 .. g_{t-1} (independent of this step's global cell)
-        if (t > 0) {
-            GateAttnArgs gaa;
-            gaa.g = ga;
-            gaa.at.B = B; gaa.at.H = H; gaa.at.S = S; gaa.at.t = t;
-            for (int z = 0; z < ndir; ++z)
-                gaa.at.d[z] = AttnDir{saved[z] + so.XA + r0 * H, saved[z] + so.G, saved[z] + so.CT + r0 * H, alpha[z]};
-            gaa.gate_blocks = (B * H + DR_AT - 1) / DR_AT;
-            hipLaunchKernelGGL(drnn_gate_attn_fwd_kernel, dim3(gaa.gate_blocks + B, 1, ndir), dim3(DR_AT), 0, st, gaa);
-            GF_LAUNCH_CHECK();
-        } else {
-            hipLaunchKernelGGL(gru_gate_fwd_kernel<0>, gH, dim3(256), 0, st, ga);
-            GF_LAUNCH_CHECK();
-        }
-        // ---- party cell (speaker): GI = XP[t] + CT[t] Wih_p[:, Dm:]^T ; GH = QS[t] Whh_p^T + bhh_p
-        for (int z = 0; z < ndir; ++z) {
-            float* sv = saved[z]; float* ws = workspace[z];
-            sg.p[2 * z] = SkinnyProb{sv + so.CT + r0 * H, H, prm[z].p_wih + Dm, Dm + H, sv + so.XP + r0 * 3 * H, 3 * H, nullptr, nullptr, ws + wo.GI, 3 * H, B, 3 * H, H};
-            sg.p[2 * z + 1] = SkinnyProb{sv + so.QS + r0 * H, H, prm[z].p_whh, H, nullptr, 0, nullptr, prm[z].p_bhh, ws + wo.GH, 3 * H, B, 3 * H, H};
-        }
-        GF_TRY(launch_skinny(sg, 2 * ndir, false, st));
-        for (int z = 0; z < ndir; ++z) {
-            float* sv = saved[z]; float* ws = workspace[z];
-            ga.d[z] = GateDir{ws + wo.GI, ws + wo.GH, sv + so.QS + r0 * H, sv + so.Rp + r0 * H, sv + so.Zp + r0 * H, sv + so.Np + r0 * H,
+            gp.d[z] = GateDir{ws + wo.GIp, ws + wo.GHp, sv + so.QS + r0 * H, sv + so.Rp + r0 * H, sv + so.Zp + r0 * H, sv + so.Np + r0 * H,
                               sv + so.HNp + r0 * H, nullptr, spk[z] + r0, t + 1 < S ? spk[z] + r1 : nullptr, mval[z] + r0,
                               sv + so.Q + r0 * 2 * H, sv + so.Q + r1 * 2 * H, sv + so.QN + r0 * H, sv + so.QS + r1 * H,
                               SITE_DRNN_P + 4u * z};
         }
-        hipLaunchKernelGGL(gru_gate_fwd_kernel<1>, gH, dim3(256), 0, st, ga);
+        hipLaunchKernelGGL(drnn_gates_fwd_kernel, dim3(gH.x, 2, ndir), dim3(256), 0, st, ga, gp);
         GF_LAUNCH_CHECK();
         if (echain) continue;
         // ---- emotion cell: GI = QN[t] Wih_e^T + bih_e ; GH = E[t] Whh_e^T + bhh_e
@@ -910,8 +896,11 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
         }
         GF_TRY(launch_skinny(sg, 2 * ndir, true, st));
         }
-        // ---- party cell: gradient wrt Q[t+1][spk] = dQ[t+1][spk] + dQN (selected inside the gate kernel)
+        // ---- gate gradients of both cells in one launch.  Party cell: gradient wrt Q[t+1][spk] = dQ[t+1][spk] + dQN (selected
+        // inside the kernel).  Global cell: dg_t = dG[t+1] — the attention uses of g_t at later steps and the recurrent path
+        // were all added by the steps already done.
         gb.H = H;
+        GateBwdArgs gg = gb;
         for (int z = 0; z < ndir; ++z) {
             const float* sv = saved[z]; float* ws = workspace[z];
             gb.d[z] = GateBwdDir{ws + dQin, echain ? ws + wo.dQNall + r0 * H : ws + wo.dQN, sv + so.Rp + r0 * H, sv + so.Zp + r0 * H, sv + so.Np + r0 * H, sv + so.HNp + r0 * H,
@@ -923,46 +912,35 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
                 gb.d[z].pg_out = ws + dQin;
                 gb.d[z].pg_dQSp = ws + wo.dQSp; gb.d[z].pg_dQSg = ws + wo.dQSg; gb.d[z].pg_spk = spk[z] + r1;
             }
+            gg.d[z] = GateBwdDir{ws + wo.dG + r1 * H, nullptr, sv + so.Rg + r0 * H, sv + so.Zg + r0 * H, sv + so.Ng + r0 * H, sv + so.HNg + r0 * H,
+                                 sv + so.G + r0 * H, ws + wo.dGIg + r0 * 3 * H, ws + wo.dGHg + r0 * 3 * H, ws + wo.dhdirG, nullptr,
+                                 nullptr, SITE_DRNN_G + 4u * z};
         }
-        hipLaunchKernelGGL(gru_gate_bwd_kernel<1>, gH, dim3(256), 0, st, gb);
+        hipLaunchKernelGGL(drnn_gates_bwd_kernel, dim3(gH.x, 2, ndir), dim3(256), 0, st, gg, gb);
         GF_LAUNCH_CHECK();
+        // ---- the four dgrad products of the step in one launch
         for (int z = 0; z < ndir; ++z) {
             float* ws = workspace[z];
             // dCT[t] = dGI_p Wih_p[:, Dm:] ; dQS_p = dGH_p Whh_p + dhdir
-            sg.p[2 * z] = SkinnyProb{ws + wo.dGIp + r0 * 3 * H, 3 * H, prm[z].p_wih + Dm, Dm + H, nullptr, 0, nullptr, nullptr, ws + wo.dCT, H, B, H, 3 * H};
-            sg.p[2 * z + 1] = SkinnyProb{ws + wo.dGHp + r0 * 3 * H, 3 * H, prm[z].p_whh, H, ws + wo.dhdir, H, nullptr, nullptr, ws + wo.dQSp, H, B, H, 3 * H};
-        }
-        GF_TRY(launch_skinny(sg, 2 * ndir, true, st));
-        // ---- attention backward + global cell gate backward: dg_t = dG[t+1] (attention uses at later steps + the recurrent
-        // path, both already added); one launch, the two touch disjoint data
-        for (int z = 0; z < ndir; ++z) {
-            const float* sv = saved[z]; float* ws = workspace[z];
-            gb.d[z] = GateBwdDir{ws + wo.dG + r1 * H, nullptr, sv + so.Rg + r0 * H, sv + so.Zg + r0 * H, sv + so.Ng + r0 * H, sv + so.HNg + r0 * H,
-                                 sv + so.G + r0 * H, ws + wo.dGIg + r0 * 3 * H, ws + wo.dGHg + r0 * 3 * H, ws + wo.dhdir, nullptr,
-                                 nullptr, SITE_DRNN_G + 4u * z};
-        }
-        if (t > 0) {
-            GateAttnBwdArgs gab;
-            gab.g = gb;
-            gab.at.B = B; gab.at.H = H; gab.at.S = S; gab.at.t = t;
-            for (int z = 0; z < ndir; ++z)
-                gab.at.d[z] = AttnBwdDir{workspace[z] + wo.dCT, saved[z] + so.XA + r0 * H, saved[z] + so.G, alpha[z], workspace[z] + wo.dG,
-                                         workspace[z] + wo.dXA + r0 * H};
-            gab.gate_blocks = (B * H + DR_AT - 1) / DR_AT;
-            hipLaunchKernelGGL(drnn_gate_attn_bwd_kernel, dim3(gab.gate_blocks + B, 1, ndir), dim3(DR_AT), 0, st, gab);
-            GF_LAUNCH_CHECK();
-        } else {
-            hipLaunchKernelGGL(gru_gate_bwd_kernel<0>, gH, dim3(256), 0, st, gb);
-            GF_LAUNCH_CHECK();
-        }
-        for (int z = 0; z < ndir; ++z) {
-            float* ws = workspace[z];
+            sg.p[4 * z] = SkinnyProb{ws + wo.dGIp + r0 * 3 * H, 3 * H, prm[z].p_wih + Dm, Dm + H, nullptr, 0, nullptr, nullptr, ws + wo.dCT, H, B, H, 3 * H};
+            sg.p[4 * z + 1] = SkinnyProb{ws + wo.dGHp + r0 * 3 * H, 3 * H, prm[z].p_whh, H, ws + wo.dhdir, H, nullptr, nullptr, ws + wo.dQSp, H, B, H, 3 * H};
             // dQS_g = dGI_g Wih_g[:, Dm:] ; dG[t] += dGH_g Whh_g + dhdir (in place: second addend = the output block itself)
-            sg.p[2 * z] = SkinnyProb{ws + wo.dGIg + r0 * 3 * H, 3 * H, prm[z].g_wih + Dm, Dm + H, nullptr, 0, nullptr, nullptr, ws + wo.dQSg, H, B, H, 3 * H};
-            sg.p[2 * z + 1] = SkinnyProb{ws + wo.dGHg + r0 * 3 * H, 3 * H, prm[z].g_whh, H, ws + wo.dhdir, H, ws + wo.dG + r0 * H, nullptr,
+            sg.p[4 * z + 2] = SkinnyProb{ws + wo.dGIg + r0 * 3 * H, 3 * H, prm[z].g_wih + Dm, Dm + H, nullptr, 0, nullptr, nullptr, ws + wo.dQSg, H, B, H, 3 * H};
+            sg.p[4 * z + 3] = SkinnyProb{ws + wo.dGHg + r0 * 3 * H, 3 * H, prm[z].g_whh, H, ws + wo.dhdirG, H, ws + wo.dG + r0 * H, nullptr,
                                          ws + wo.dG + r0 * H, H, B, H, 3 * H};
         }
-        GF_TRY(launch_skinny(sg, 2 * ndir, true, st));
+        GF_TRY(launch_skinny(sg, 4 * ndir, true, st));
+        // ---- attention backward of the step: adds into dG rows <= t (after the product above, which adds into row t too),
+        // writes dXA[t]
+        if (t > 0) {
+            AttnBwdArgs ab;
+            ab.B = B; ab.H = H; ab.S = S; ab.t = t;
+            for (int z = 0; z < ndir; ++z)
+                ab.d[z] = AttnBwdDir{workspace[z] + wo.dCT, saved[z] + so.XA + r0 * H, saved[z] + so.G, alpha[z], workspace[z] + wo.dG,
+                                     workspace[z] + wo.dXA + r0 * H};
+            hipLaunchKernelGGL(drnn_attn_bwd_kernel, dim3(B, 1, ndir), dim3(DR_AT), 0, st, ab);
+            GF_LAUNCH_CHECK();
+        }
     }
     // ---- dU and the deferred weight gradients (all steps at once)
     for (int z = 0; z < ndir; ++z) {
