@@ -12,10 +12,11 @@
 // Why not one kernel per dialogue: a step needs every cell's full weight matrix (12.7 MB per direction); one workgroup
 // per dialogue would stream that through ONE CU 94 times.  Instead the dialogues are the N axis (<= 32 per tile) of
 // skinny matrix products that spread a cell's weight rows over ~100-200 workgroups, and the S steps are a chain of small
-// launches (3 per step forward, 3 backward, both directions of BiModel in the same launches; independent pieces of a step
+// launches (2 per step forward, 2 backward, both directions of BiModel in the same launches; independent pieces of a step
 // share a launch: within step t the global and the party cell do not depend on each other — the party cell reads the
-// context over g_0 .. g_{t-1}, not g_t — so their four products are one launch and their gate kernels another; round 2
-// ran them one after the other, 4 + 4 launches per step):
+// context over g_0 .. g_{t-1}, not g_t — so their four products are one launch and their gate kernels another, with the
+// context attention of the next step behind the global cell's gate math in the workgroup that owns the dialogue; round 2
+// ran the cells one after the other, 4 + 4 launches per step):
 //   * everything that depends on U alone is hoisted out of the recurrence into three ordinary GEMMs over all steps
 //     (x-parts of the g / p cells incl. b_ih, and the attention query W_a U_t);
 //   * skinny_nt / skinny_nn: C[B x N] = A[B x K] W^T resp. A W on v_mfma_f32_16x16x4_f32 (exact fp32): a workgroup owns
@@ -249,13 +250,6 @@ template <int PARTY>
 __global__ __launch_bounds__(256) void gru_gate_fwd_kernel(GateArgs a) {
     gru_gate_fwd_body<PARTY>(a, a.d[blockIdx.z], blockIdx.x * 256 + threadIdx.x);
 }
-// both cells of a step in one launch (they are independent: the party cell reads the context of g_0 .. g_{t-1}, not g_t):
-// blockIdx.y = 0 global cell, 1 party cell
-__global__ __launch_bounds__(256) void drnn_gates_fwd_kernel(GateArgs g, GateArgs p) {
-    if (blockIdx.y == 0) gru_gate_fwd_body<0>(g, g.d[blockIdx.z], blockIdx.x * 256 + threadIdx.x);
-    else gru_gate_fwd_body<1>(p, p.d[blockIdx.z], blockIdx.x * 256 + threadIdx.x);
-}
-
 struct GateBwdDir {
     const float* dh;        // [B x H] gradient wrt the cell output AFTER dropout (g / e cells) or wrt Q[t+1][spk] (party cell)
     const float* dh2;       // optional second addend (e cell: upstream dE_out[t])
@@ -320,13 +314,6 @@ template <int PARTY>
 __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(GateBwdArgs a) {
     gru_gate_bwd_body<PARTY>(a, a.d[blockIdx.z], blockIdx.x * 256 + threadIdx.x);
 }
-// both cells' gate gradients of a step in one launch: dG[t+1] is final once step t + 1 is through, so the global cell does
-// not have to wait for this step's party products and attention
-__global__ __launch_bounds__(256) void drnn_gates_bwd_kernel(GateBwdArgs g, GateBwdArgs p) {
-    if (blockIdx.y == 0) gru_gate_bwd_body<0>(g, g.d[blockIdx.z], blockIdx.x * 256 + threadIdx.x);
-    else gru_gate_bwd_body<1>(p, p.d[blockIdx.z], blockIdx.x * 256 + threadIdx.x);
-}
-
 // ------------------------------------------------------------------------------------------
 // "general" context attention of step t over the global history g_0 .. g_{t-1} (model.py:161-164,193)
 // one workgroup per (dialogue, direction); G rows are (S+1) blocks of B: block j+1 = g_j
@@ -418,6 +405,24 @@ __device__ __forceinline__ void drnn_attn_fwd_body(const AttnArgs& a, const Attn
 }
 __global__ __launch_bounds__(DR_AT) void drnn_attn_fwd_kernel(AttnArgs a) { drnn_attn_fwd_body(a, a.d[blockIdx.z], blockIdx.x); }
 
+// Second launch of a forward step: both cells' gate math and, behind the global cell's, the context attention of the NEXT
+// step.  Blocks [0, party_blocks) run the party gate body (1024 elements each); block party_blocks + b owns dialogue b:
+// its first H threads produce g_t[b], then the whole workgroup pools g_0 .. g_t[b] for step t + 1 (the newest history row
+// was written by this very workgroup: a workgroup-scope fence + barrier orders it).
+struct GateAttnArgs { GateArgs g, p; AttnArgs at; int party_blocks, has_attn; };
+__global__ __launch_bounds__(DR_AT) void drnn_gates_attn_fwd_kernel(GateAttnArgs a) {
+    if ((int)blockIdx.x < a.party_blocks) {
+        gru_gate_fwd_body<1>(a.p, a.p.d[blockIdx.z], blockIdx.x * DR_AT + threadIdx.x);
+        return;
+    }
+    const int b = blockIdx.x - a.party_blocks;
+    if ((int)threadIdx.x < a.g.H) gru_gate_fwd_body<0>(a.g, a.g.d[blockIdx.z], b * a.g.H + threadIdx.x);
+    if (!a.has_attn) return;
+    __threadfence_block();
+    __syncthreads();
+    drnn_attn_fwd_body(a.at, a.at.d[blockIdx.z], b);
+}
+
 struct AttnBwdDir {
     const float* dCT;    // [B x H]
     const float* XA;     // [B x H]
@@ -476,6 +481,24 @@ __device__ __forceinline__ void drnn_attn_bwd_body(const AttnBwdArgs& a, const A
     if (!half && k < a.H) d.dXA[(size_t)b * a.H + k] = dx + part[k];
 }
 __global__ __launch_bounds__(DR_AT) void drnn_attn_bwd_kernel(AttnBwdArgs a) { drnn_attn_bwd_body(a, a.d[blockIdx.z], blockIdx.x); }
+
+// First launch of a backward step t: the attention backward of step t + 1 (it completes dG row t + 1 of its dialogue),
+// then the global cell's gate gradient of step t on that row, in the workgroup that owns the dialogue; the party cell's
+// gate gradient (independent of both) in blocks [0, party_blocks).
+struct GateAttnBwdArgs { GateBwdArgs g, p; AttnBwdArgs at; int party_blocks, has_attn; };
+__global__ __launch_bounds__(DR_AT) void drnn_gates_attn_bwd_kernel(GateAttnBwdArgs a) {
+    if ((int)blockIdx.x < a.party_blocks) {
+        gru_gate_bwd_body<1>(a.p, a.p.d[blockIdx.z], blockIdx.x * DR_AT + threadIdx.x);
+        return;
+    }
+    const int b = blockIdx.x - a.party_blocks;
+    if (a.has_attn) {
+        drnn_attn_bwd_body(a.at, a.at.d[blockIdx.z], b);
+        __threadfence_block();
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < a.g.H) gru_gate_bwd_body<0>(a.g, a.g.d[blockIdx.z], b * a.g.H + threadIdx.x);
+}
 
 // ------------------------------------------------------------------------------------------
 // Emotion cell as ONE chain per dialogue (round 2).  e_t = drop(GRU_e(q_t[spk], e_{t-1})) takes q_t from the party cell
@@ -750,19 +773,12 @@ extern "C" int ganffn_drnn_fwd(const ganffn_drnn_cfg* c, int ndir, const float* 
     }
     const dim3 gH((B * H + 255) / 256, 1, ndir), gHe((B * He + 255) / 256, 1, ndir);
     const bool echain = He <= EC_MAXHE;          // emotion cell as one chain per dialogue after the main loop
-    // A step is three launches: the context attention over g_0 .. g_{t-1}; the four products of the global and the party
-    // cell (the party cell needs c_t but not g_t, the global cell neither: they are independent within a step); both
-    // cells' gate math.
+    // A step is two launches: the four products of the global and the party cell (the party cell needs c_t but not g_t, the
+    // global cell neither: they are independent within a step), then both cells' gate math with the context attention of
+    // step t + 1 behind the global cell's (c_0 = 0: step 0 needs none).
     for (int t = 0; t < S; ++t) {
         const int64_t r0 = (int64_t)t * B, r1 = (int64_t)(t + 1) * B;
         SkinnyGroup sg;
-        if (t > 0) {
-            AttnArgs at;
-            at.B = B; at.H = H; at.S = S; at.t = t;
-            for (int z = 0; z < ndir; ++z) at.d[z] = AttnDir{saved[z] + so.XA + r0 * H, saved[z] + so.G, saved[z] + so.CT + r0 * H, alpha[z]};
-            hipLaunchKernelGGL(drnn_attn_fwd_kernel, dim3(B, 1, ndir), dim3(DR_AT), 0, st, at);
-            GF_LAUNCH_CHECK();
-        }
         // ---- global cell: GI = XG[t] + QS[t] Wih_g[:, Dm:]^T ; GH = G[t] Whh_g^T + bhh_g
         // ---- party cell (speaker): GI = XP[t] + CT[t] Wih_p[:, Dm:]^T ; GH = QS[t] Whh_p^T + bhh_p
         for (int z = 0; z < ndir; ++z) {
@@ -786,7 +802,14 @@ extern "C" int ganffn_drnn_fwd(const ganffn_drnn_cfg* c, int ndir, const float* 
                               sv + so.Q + r0 * 2 * H, sv + so.Q + r1 * 2 * H, sv + so.QN + r0 * H, sv + so.QS + r1 * H,
                               SITE_DRNN_P + 4u * z};
         }
-        hipLaunchKernelGGL(drnn_gates_fwd_kernel, dim3(gH.x, 2, ndir), dim3(256), 0, st, ga, gp);
+        GateAttnArgs gaa;
+        gaa.g = ga; gaa.p = gp;
+        gaa.party_blocks = (B * H + DR_AT - 1) / DR_AT;
+        gaa.has_attn = t + 1 < S;
+        gaa.at.B = B; gaa.at.H = H; gaa.at.S = S; gaa.at.t = t + 1;
+        for (int z = 0; z < ndir; ++z)
+            gaa.at.d[z] = AttnDir{saved[z] + so.XA + r1 * H, saved[z] + so.G, saved[z] + so.CT + r1 * H, alpha[z]};
+        hipLaunchKernelGGL(drnn_gates_attn_fwd_kernel, dim3(gaa.party_blocks + B, 1, ndir), dim3(DR_AT), 0, st, gaa);
         GF_LAUNCH_CHECK();
         if (echain) continue;
         // ---- emotion cell: GI = QN[t] Wih_e^T + bih_e ; GH = E[t] Whh_e^T + bhh_e
@@ -916,7 +939,15 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
                                  sv + so.G + r0 * H, ws + wo.dGIg + r0 * 3 * H, ws + wo.dGHg + r0 * 3 * H, ws + wo.dhdirG, nullptr,
                                  nullptr, SITE_DRNN_G + 4u * z};
         }
-        hipLaunchKernelGGL(drnn_gates_bwd_kernel, dim3(gH.x, 2, ndir), dim3(256), 0, st, gg, gb);
+        GateAttnBwdArgs gab;
+        gab.g = gg; gab.p = gb;
+        gab.party_blocks = (B * H + DR_AT - 1) / DR_AT;
+        gab.has_attn = t + 1 < S;             // attention backward of step t + 1: needs its dCT (the products of step t + 1)
+        gab.at.B = B; gab.at.H = H; gab.at.S = S; gab.at.t = t + 1;
+        for (int z = 0; z < ndir; ++z)
+            gab.at.d[z] = AttnBwdDir{workspace[z] + wo.dCT, saved[z] + so.XA + r1 * H, saved[z] + so.G, alpha[z], workspace[z] + wo.dG,
+                                     workspace[z] + wo.dXA + r1 * H};
+        hipLaunchKernelGGL(drnn_gates_attn_bwd_kernel, dim3(gab.party_blocks + B, 1, ndir), dim3(DR_AT), 0, st, gab);
         GF_LAUNCH_CHECK();
         // ---- the four dgrad products of the step in one launch
         for (int z = 0; z < ndir; ++z) {
@@ -930,17 +961,6 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
                                          ws + wo.dG + r0 * H, H, B, H, 3 * H};
         }
         GF_TRY(launch_skinny(sg, 4 * ndir, true, st));
-        // ---- attention backward of the step: adds into dG rows <= t (after the product above, which adds into row t too),
-        // writes dXA[t]
-        if (t > 0) {
-            AttnBwdArgs ab;
-            ab.B = B; ab.H = H; ab.S = S; ab.t = t;
-            for (int z = 0; z < ndir; ++z)
-                ab.d[z] = AttnBwdDir{workspace[z] + wo.dCT, saved[z] + so.XA + r0 * H, saved[z] + so.G, alpha[z], workspace[z] + wo.dG,
-                                     workspace[z] + wo.dXA + r0 * H};
-            hipLaunchKernelGGL(drnn_attn_bwd_kernel, dim3(B, 1, ndir), dim3(DR_AT), 0, st, ab);
-            GF_LAUNCH_CHECK();
-        }
     }
     // ---- dU and the deferred weight gradients (all steps at once)
     for (int z = 0; z < ndir; ++z) {
