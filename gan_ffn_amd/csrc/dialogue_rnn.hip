@@ -53,26 +53,31 @@ struct SkinnyGroup {
     SkinnyProb p[8];      // a step's products of both cells (2 each) in both directions
 };
 
-// NT: C[b][n] = sum_k A[b][k] W[n][k] (+ Cin[b][n] + bias[n]).  Workgroup = 16 weight rows x 32 dialogues, 4 waves split K.
+// NT: C[b][n] = sum_k A[b][k] W[n][k] (+ Cin[b][n] + bias[n]).  Workgroup = 16 weight rows x 32 dialogues, NW waves split K
+// (4 for the K = 500 products of the forward step, 12 for the K = 1500 ones of the backward step: 125 -> 128 k each).
 // MFMA tile D[m = weight row][n' = dialogue]: A-operand = W rows, B-operand = A rows; both are float4 loads along k
 // (k block of 16 per 4 MFMAs: step i contracts k = kb + 4g + i, identically on both operands).
-__global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyGroup grp) {
-    __shared__ __attribute__((aligned(16))) float red[4][2][4][64];
+// A launch is one link of a serial chain, so what counts is its latency: every load of a chunk of SK_NT k-blocks (a
+// wave's whole K range in both uses) is issued before the first MFMA — one memory round trip (10.9 -> 9.9 us in-step).
+constexpr int SK_NT = 8;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_nt_kernel(SkinnyGroup grp) {
+    __shared__ __attribute__((aligned(16))) float red[NW][2][4][64];
     const SkinnyProb& q = grp.p[blockIdx.z];
     const int n0 = blockIdx.x * 16;
     if (n0 >= q.N) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-    const int KQ = (((q.K + 3) / 4) + 15) / 16 * 16;     // k range per wave, multiple of 16
+    const int KQ = (((q.K + NW - 1) / NW) + 15) / 16 * 16;     // k range per wave, multiple of 16
     const int kbeg = w * KQ, kend = min(q.K, kbeg + KQ);
     const float* wrow = q.W + (size_t)min(n0 + c, q.N - 1) * q.ldw;
     const float* a0 = q.A + (size_t)min(c, q.M - 1) * q.lda;
     const float* a1 = q.A + (size_t)min(16 + c, q.M - 1) * q.lda;
     floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    for (int kb = kbeg; kb < kend; kb += 32) {
-        float4 wv[2], x0[2], x1[2];
-        float f[2];
+    for (int kb = kbeg; kb < kend; kb += 16 * SK_NT) {
+        float4 wv[SK_NT], x0[SK_NT], x1[SK_NT];
+        float f[SK_NT];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < SK_NT; ++u) {
             const int k = kb + 16 * u + 4 * g;             // K % 4 == 0: a float4 never straddles the end
             f[u] = k < kend ? 1.f : 0.f;
             const int kc = max(min(k, q.K - 4), 0);
@@ -80,8 +85,9 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyGroup grp) {
             x0[u] = *reinterpret_cast<const float4*>(a0 + kc);
             x1[u] = *reinterpret_cast<const float4*>(a1 + kc);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < SK_NT; ++u) {
             const float wx = wv[u].x * f[u], wy = wv[u].y * f[u], wz = wv[u].z * f[u], ww = wv[u].w * f[u];
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wx, x0[u].x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wx, x1[u].x, acc1, 0, 0, 0);
@@ -99,14 +105,18 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyGroup grp) {
         red[w][1][r][lane] = acc1[r];
     }
     __syncthreads();
-    // thread -> (dialogue tile mt, lane): sums the 4 waves in order; lane holds C[b = 16 mt + c][n0 + 4g .. 4g+3]
+    // thread -> (dialogue tile mt, lane): sums the waves in order; lane holds C[b = 16 mt + c][n0 + 4g .. 4g+3]
     if (threadIdx.x < 128) {
         const int mt = threadIdx.x >> 6;
         const int b = 16 * mt + c, n = n0 + 4 * g;
         if (b < q.M && n < q.N) {
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = ((red[0][mt][r][lane] + red[1][mt][r][lane]) + red[2][mt][r][lane]) + red[3][mt][r][lane];
+            for (int r = 0; r < 4; ++r) {
+                v[r] = red[0][mt][r][lane];
+#pragma unroll
+                for (int ww = 1; ww < NW; ++ww) v[r] += red[ww][mt][r][lane];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (n + r < q.N) {
@@ -118,6 +128,25 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(SkinnyGroup grp) {
                 }
             }
         }
+    }
+}
+
+// out[c][r] = in[r][c] for up to 8 matrices [rows x cols] (leading dimension ld_in) -> [cols x rows]: the recurrent
+// weights in the orientation the backward step's products read row-wise (once per backward call)
+struct TrGroup { const float* in[8]; float* out[8]; int ld_in[8]; int rows, cols; };
+__global__ __launch_bounds__(256) void drnn_transpose_kernel(TrGroup t) {
+    __shared__ float tile[32][33];
+    const int z = blockIdx.z, c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < t.rows && c < t.cols) ? t.in[z][(size_t)r * t.ld_in[z] + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < t.rows && c < t.cols) t.out[z][(size_t)c * t.rows + r] = tile[tx][ty + 8 * i];
     }
 }
 
@@ -180,15 +209,17 @@ __global__ __launch_bounds__(512) void skinny_nn_kernel(SkinnyGroup grp) {
 }
 
 static int launch_skinny(const SkinnyGroup& grp, int nprob, bool nn, hipStream_t st) {
-    int maxN = 0;
+    int maxN = 0, maxK = 0;
     for (int i = 0; i < nprob; ++i) {
         const SkinnyProb& q = grp.p[i];
         GF_CHECK_ARG(q.M >= 1 && q.M <= 32 && (q.K & 3) == 0 && (q.lda & 3) == 0 && aligned16(q.A) && (nn || ((q.ldw & 3) == 0 && aligned16(q.W))),
                      "drnn skinny product: M=%d K=%d lda=%d ldw=%d unsupported", q.M, q.K, q.lda, q.ldw);
         maxN = q.N > maxN ? q.N : maxN;
+        maxK = q.K > maxK ? q.K : maxK;
     }
     if (nn) hipLaunchKernelGGL(skinny_nn_kernel, dim3((maxN + 15) / 16, 1, nprob), dim3(512), 0, st, grp);
-    else hipLaunchKernelGGL(skinny_nt_kernel, dim3((maxN + 15) / 16, 1, nprob), dim3(256), 0, st, grp);
+    else if (maxK > 4 * 16 * SK_NT) hipLaunchKernelGGL(skinny_nt_kernel<12>, dim3((maxN + 15) / 16, 1, nprob), dim3(768), 0, st, grp);
+    else hipLaunchKernelGGL(skinny_nt_kernel<4>, dim3((maxN + 15) / 16, 1, nprob), dim3(256), 0, st, grp);
     GF_LAUNCH_CHECK();
     return 0;
 }
@@ -685,7 +716,7 @@ static DrnnSaved drnn_saved(const ganffn_drnn_cfg* c) {
     return s;
 }
 struct DrnnWs {
-    int64_t GI, GH, GIp, GHp, dGIg, dGHg, dGIp, dGHp, dGIe, dGHe, dXA, dCT, dG, dQa, dQb, dEa, dEb, dQsel, dQSp, dQSg, dhdir, dhdirG, dQN, GIe, dQNall, total;
+    int64_t GI, GH, GIp, GHp, dGIg, dGHg, dGIp, dGHp, dGIe, dGHe, dXA, dCT, dG, dQa, dQb, dEa, dEb, dQsel, dQSp, dQSg, dhdir, dhdirG, dQN, GIe, dQNall, WT, total;
 };
 static DrnnWs drnn_ws(const ganffn_drnn_cfg* c) {
     DrnnWs w;
@@ -699,6 +730,7 @@ static DrnnWs drnn_ws(const ganffn_drnn_cfg* c) {
     w.dQa = take(B * 2 * H); w.dQb = take(B * 2 * H); w.dEa = take(B * He); w.dEb = take(B * He);
     w.dQsel = take(B * H); w.dQSp = take(B * H); w.dQSg = take(B * H); w.dhdir = take(B * H); w.dhdirG = take(B * H); w.dQN = take(B * H);
     w.GIe = take(T * 3 * He); w.dQNall = take(T * H);       // emotion chain: input pre-activations / dQN of all steps
+    w.WT = take(4 * H * 3 * H);                              // transposed recurrent weights (backward): 4 x [H x 3H]
     w.total = p;
     return w;
 }
@@ -725,9 +757,9 @@ static int memset_f(float* p, int64_t n, hipStream_t st) {
 using namespace ganffn;
 
 // test / measurement hook: one skinny product C[M x N] = A[M x K] W^T (nn = 0, W [N x K]) or A W (nn = 1, W [K x N]),
-// replicated `copies` (<= 4) times in one launch like a step of the recurrence (2 directions x 2 products)
+// replicated `copies` (<= 8) times in one launch like a step of the recurrence (2 directions x 2 cells x 2 products)
 extern "C" int ganffn_drnn_skinny(int nn, int copies, const float* A, const float* W, float* C, int M, int N, int K, void* stream) {
-    GF_CHECK_ARG(A && W && C && copies >= 1 && copies <= 4, "drnn_skinny: bad arguments");
+    GF_CHECK_ARG(A && W && C && copies >= 1 && copies <= 8, "drnn_skinny: bad arguments");
     SkinnyGroup sg;
     for (int i = 0; i < copies; ++i)
         sg.p[i] = SkinnyProb{A, K, W + (size_t)i * N * K, nn ? N : K, nullptr, 0, nullptr, nullptr, C + (size_t)i * M * N, N, M, N, K};
@@ -875,6 +907,20 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
     }
     const dim3 gH((B * H + 255) / 256, 1, ndir), gHe((B * He + 255) / 256, 1, ndir);
     const bool echain = He <= EC_MAXHE;
+    {
+        // the step products contract over the 3H gate rows: transposed copies [H x 3H] make them row-wise reads (the NT
+        // kernel, 16.6 -> see DESIGN.md) — order per direction: p_wih[:, Dm:], p_whh, g_wih[:, Dm:], g_whh
+        TrGroup tr;
+        tr.rows = 3 * H; tr.cols = H;
+        for (int z = 0; z < ndir; ++z) {
+            float* wt = workspace[z] + wo.WT;
+            const float* src[4] = {prm[z].p_wih + Dm, prm[z].p_whh, prm[z].g_wih + Dm, prm[z].g_whh};
+            const int ld[4] = {Dm + H, H, Dm + H, H};
+            for (int i = 0; i < 4; ++i) { tr.in[4 * z + i] = src[i]; tr.ld_in[4 * z + i] = ld[i]; tr.out[4 * z + i] = wt + (int64_t)i * H * 3 * H; }
+        }
+        hipLaunchKernelGGL(drnn_transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32, 4 * ndir), dim3(256), 0, st, tr);
+        GF_LAUNCH_CHECK();
+    }
     if (echain) {
         // emotion chain first (it depends on nothing else): gate gradients of all steps, then dQN of all steps in one GEMM
         EchainBwdArgs eb;
@@ -952,15 +998,17 @@ extern "C" int ganffn_drnn_bwd(const ganffn_drnn_cfg* c, int ndir, const float* 
         // ---- the four dgrad products of the step in one launch
         for (int z = 0; z < ndir; ++z) {
             float* ws = workspace[z];
+            const float* wt = ws + wo.WT;
+            const int64_t WM = (int64_t)H * 3 * H;
             // dCT[t] = dGI_p Wih_p[:, Dm:] ; dQS_p = dGH_p Whh_p + dhdir
-            sg.p[4 * z] = SkinnyProb{ws + wo.dGIp + r0 * 3 * H, 3 * H, prm[z].p_wih + Dm, Dm + H, nullptr, 0, nullptr, nullptr, ws + wo.dCT, H, B, H, 3 * H};
-            sg.p[4 * z + 1] = SkinnyProb{ws + wo.dGHp + r0 * 3 * H, 3 * H, prm[z].p_whh, H, ws + wo.dhdir, H, nullptr, nullptr, ws + wo.dQSp, H, B, H, 3 * H};
+            sg.p[4 * z] = SkinnyProb{ws + wo.dGIp + r0 * 3 * H, 3 * H, wt, 3 * H, nullptr, 0, nullptr, nullptr, ws + wo.dCT, H, B, H, 3 * H};
+            sg.p[4 * z + 1] = SkinnyProb{ws + wo.dGHp + r0 * 3 * H, 3 * H, wt + WM, 3 * H, ws + wo.dhdir, H, nullptr, nullptr, ws + wo.dQSp, H, B, H, 3 * H};
             // dQS_g = dGI_g Wih_g[:, Dm:] ; dG[t] += dGH_g Whh_g + dhdir (in place: second addend = the output block itself)
-            sg.p[4 * z + 2] = SkinnyProb{ws + wo.dGIg + r0 * 3 * H, 3 * H, prm[z].g_wih + Dm, Dm + H, nullptr, 0, nullptr, nullptr, ws + wo.dQSg, H, B, H, 3 * H};
-            sg.p[4 * z + 3] = SkinnyProb{ws + wo.dGHg + r0 * 3 * H, 3 * H, prm[z].g_whh, H, ws + wo.dhdirG, H, ws + wo.dG + r0 * H, nullptr,
+            sg.p[4 * z + 2] = SkinnyProb{ws + wo.dGIg + r0 * 3 * H, 3 * H, wt + 2 * WM, 3 * H, nullptr, 0, nullptr, nullptr, ws + wo.dQSg, H, B, H, 3 * H};
+            sg.p[4 * z + 3] = SkinnyProb{ws + wo.dGHg + r0 * 3 * H, 3 * H, wt + 3 * WM, 3 * H, ws + wo.dhdirG, H, ws + wo.dG + r0 * H, nullptr,
                                          ws + wo.dG + r0 * H, H, B, H, 3 * H};
         }
-        GF_TRY(launch_skinny(sg, 4 * ndir, true, st));
+        GF_TRY(launch_skinny(sg, 4 * ndir, false, st));
     }
     // ---- dU and the deferred weight gradients (all steps at once)
     for (int z = 0; z < ndir; ++z) {

@@ -260,7 +260,7 @@ int ganffn_drnn_join_bwd(const float* d_emotions, const int32_t* lens, float* d_
                          void* stream);
 int ganffn_mask_pos_inplace(float* d, const float* aux, float mscale, int64_t n, void* stream);
 
-/* one launch of the recurrence's skinny product, `copies` (<= 4) independent problems sharing A: C_i[M x N] = A[M x K]
+/* one launch of the recurrence's skinny product, `copies` (<= 8) independent problems sharing A: C_i[M x N] = A[M x K]
  * W_i^T (nn = 0, W_i [N x K]) or A W_i (nn = 1, W_i [K x N]); W / C hold the copies back to back; M <= 32 (unit tests and
  * the roofline leg of bench.py --config drnn) */
 int ganffn_drnn_skinny(int nn, int copies, const float* A, const float* W, float* C, int M, int N, int K, void* stream);

@@ -138,18 +138,19 @@ def test_bimodel_uses_the_hip_recurrence_and_matches_its_cpu_self():
 
 
 @pytest.mark.parametrize("nn", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(30, 1500, 500), (32, 300, 100), (3, 500, 1500), (1, 100, 300), (17, 52, 36)])
+@pytest.mark.parametrize("M,N,K", [(30, 1500, 500), (32, 300, 100), (3, 500, 1500), (30, 500, 1500), (1, 100, 300), (17, 52, 36)])
 def test_skinny_products(nn, M, N, K):
-    """the recurrence's skinny MFMA products against fp64 matmul (4 weight copies per launch, like a step)"""
+    """the recurrence's skinny MFMA products against fp64 matmul (8 weight copies per launch, like a step: 2 directions x
+    2 cells x 2 products; K = 1500 with nn = 0 is the backward step on transposed weights, 12 waves per workgroup)"""
     import ctypes as C
     from gan_ffn_amd import _lib, ops
     g = torch.Generator().manual_seed(M * 7 + N + K + nn)
     A = torch.randn(M, K, generator=g)
-    W = torch.randn(4, K, N, generator=g) if nn else torch.randn(4, N, K, generator=g)
+    W = torch.randn(8, K, N, generator=g) if nn else torch.randn(8, N, K, generator=g)
     Ad, Wd = A.cuda(), W.cuda().contiguous()
-    Cd = torch.full((4, M, N), float("nan"), device="cuda")
-    _lib.call("ganffn_drnn_skinny", nn, 4, ops._ptr(Ad), ops._ptr(Wd), ops._ptr(Cd), M, N, K, ops._stream())
-    for i in range(4):
+    Cd = torch.full((8, M, N), float("nan"), device="cuda")
+    _lib.call("ganffn_drnn_skinny", nn, 8, ops._ptr(Ad), ops._ptr(Wd), ops._ptr(Cd), M, N, K, ops._stream())
+    for i in range(8):
         ref = A.double() @ (W[i].double() if nn else W[i].double().T)
         assert float((Cd[i].cpu().double() - ref).abs().max() / ref.abs().max()) < 3e-6 * max(1.0, K ** 0.5)
 
