@@ -309,16 +309,19 @@ def build_workload(config, dev):
     return engine.build_networks(device=dev, seed=3407)       # random init of the reference architecture
 
 
+DRNN_IN_STEP_FILE = "profiles/r03_drnn_by_launch_shape.txt"
+
+
 def time_skinny_kernel(B, reps=20):
-    """the recurrence's skinny product at the party-cell shape of configuration 5 (both directions' W_ih and W_hh
-    products in one launch: 4 problems of [B x 500] x [500 x 1500]), timed with HIP events on the launch stream.
-    Returns (avg seconds per launch, algorithmic bytes per launch)."""
+    """the recurrence's skinny product at the shape of configuration 5's BACKWARD step (both cells' two dgrad products in
+    both directions in one launch: 8 problems of [B x 1500] x [1500 x 500] on the transposed weights, row-wise reads), timed
+    with HIP events on the launch stream.  Returns (avg seconds per launch, algorithmic bytes per launch)."""
     from gan_ffn_amd import _lib, ops
-    M, N, K = B, 1500, 500
+    M, N, K = B, 500, 1500
     A = torch.randn(M, K, device="cuda")
-    W = torch.randn(4, K, N, device="cuda")
-    C = torch.empty(4, M, N, device="cuda")
-    run = lambda: _lib.call("ganffn_drnn_skinny", 1, 4, ops._ptr(A), ops._ptr(W), ops._ptr(C), M, N, K, ops._stream())
+    W = torch.randn(8, N, K, device="cuda")
+    C = torch.empty(8, M, N, device="cuda")
+    run = lambda: _lib.call("ganffn_drnn_skinny", 0, 8, ops._ptr(A), ops._ptr(W), ops._ptr(C), M, N, K, ops._stream())
     run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # launches go to torch's current stream
     torch.cuda.synchronize()
@@ -327,7 +330,20 @@ def time_skinny_kernel(B, reps=20):
         run()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / reps, 4.0 * (4 * K * N + M * K + 4 * M * N)
+    return e0.elapsed_time(e1) * 1e-3 / reps, 4.0 * (8 * K * N + 8 * M * K + 8 * M * N)
+
+
+def drnn_in_step_us(symbol_prefix):
+    """average duration of a kernel inside the configuration-5 step, from the committed rocprofv3 summary (or None)"""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), DRNN_IN_STEP_FILE)
+    try:
+        for line in open(path):
+            f = line.split()
+            if len(f) >= 5 and f[0].endswith("%") and " ".join(f[4:]).startswith(symbol_prefix):
+                return float(f[2])
+    except Exception:
+        pass
+    return None
 
 
 def run_drnn(args, dev, pg, rank, world):
@@ -381,6 +397,7 @@ def run_drnn(args, dev, pg, rank, world):
         dt, utts = float(t), float(u)
     if rank == 0:
         kt, kbytes = time_skinny_kernel(B)
+        in_step = drnn_in_step_us("skinny_nt_kernel<12>")
         print(json.dumps({
             "metric": "utterances/sec per phase-2 train step, IEMOCAP GAN-FFN + DialogueRNN", "value": round(utts * args.steps / dt, 2),
             "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": n_warm,
@@ -392,13 +409,16 @@ def run_drnn(args, dev, pg, rank, world):
                                    "%dxMI355X" % (B, world),
                        "dialogues_per_gpu": B, "seq_len": S, "parallelism": "dp%d" % world, "launch": "eager",
                        "last_loss": round(float(loss.detach()), 4)},
-            "roofline": {"bound": "hbm", "kernel": "skinny_nn_kernel (backward of one recurrence step's gate products, both directions: "
-                                                   "4 x ([B x 500] x [500 x 1500]); the kernel with the largest share of GPU time in "
-                                                   "profiles/r02_drnn_by_launch_shape.txt)",
+            "roofline": {"bound": "hbm", "kernel": "skinny_nt_kernel<12> (the four dgrad products of one backward step of the "
+                                                   "recurrence, both directions: 8 x ([B x 1500] x [1500 x 500]) on transposed "
+                                                   "weights; the skinny products are the kernel family with the largest share of "
+                                                   "GPU time in " + DRNN_IN_STEP_FILE + ")",
                          "achieved": round(kbytes / kt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(kbytes / kt / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": round(kbytes), "avg_kernel_us": round(kt * 1e6, 2),
-                         "how": "HIP events around 20 back-to-back launches on the launch stream; the 12 MB of weights stay "
+                         "in_step_avg_us": in_step, "frac_in_step": round(kbytes / (in_step * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if in_step else None,
+                         "how": "HIP events around 20 back-to-back launches on the launch stream (in_step_avg_us: the same "
+                                "kernel inside the step, from the committed rocprofv3 summary); the 24 MB of weights stay "
                                 "L2 / MALL-resident between launches, so the bound that applies is the L2 -> CU path, priced "
                                 "here against the HBM peak as the contract asks"}}), flush=True)
 

@@ -1,5 +1,5 @@
 # GPU call B of a round (after call A's profiles/r03_bench_streams1_by_launch_shape.txt is in place): HBM-side traffic of
-# the roofline kernel (two --pmc passes), the general2 attention line, then the default bench.py line with its CPU baseline.
+# the roofline kernel (two --pmc passes), the general2 attention line, then the default bench.py line with its CPU baseline and the MELD / configuration-5 lines.
 set -e
 R=$PWD
 O=$R/gpurun_out
@@ -13,3 +13,7 @@ rm -rf $O/prof_g2
 cat $O/r03_general2_line.txt
 timeout -k 10 900 python bench.py > $O/r03_bench_default.json 2> $O/r03_bench_default.err
 cat $O/r03_bench_default.json
+for c in meld drnn; do
+  timeout -k 10 300 python bench.py --config $c --no-cpu-baseline > $O/r03_bench_$c.json 2> $O/r03_bench_$c.err
+  cat $O/r03_bench_$c.json
+done
