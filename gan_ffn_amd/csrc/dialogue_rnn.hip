@@ -72,6 +72,18 @@ __global__ __launch_bounds__(64 * NW) void skinny_nt_kernel(SkinnyGroup grp) {
     const float* wrow = q.W + (size_t)min(n0 + c, q.N - 1) * q.ldw;
     const float* a0 = q.A + (size_t)min(c, q.M - 1) * q.lda;
     const float* a1 = q.A + (size_t)min(16 + c, q.M - 1) * q.lda;
+    // the epilogue's addends (waves 0 and 1 write the tile) are fetched with the operands, not after the reduction
+    float e_cin[4] = {0.f, 0.f, 0.f, 0.f}, e_cin2[4] = {0.f, 0.f, 0.f, 0.f}, e_bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (threadIdx.x < 128) {
+        const int eb = min(16 * (int)(threadIdx.x >> 6) + c, q.M - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int en = min(n0 + 4 * g + r, q.N - 1);
+            if (q.Cin) e_cin[r] = q.Cin[(size_t)eb * q.ldcin + en];
+            if (q.Cin2) e_cin2[r] = q.Cin2[(size_t)eb * q.ldc + en];
+            if (q.bias) e_bias[r] = q.bias[en];
+        }
+    }
     floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     for (int kb = kbeg; kb < kend; kb += 16 * SK_NT) {
         float4 wv[SK_NT], x0[SK_NT], x1[SK_NT];
@@ -121,9 +133,9 @@ __global__ __launch_bounds__(64 * NW) void skinny_nt_kernel(SkinnyGroup grp) {
             for (int r = 0; r < 4; ++r) {
                 if (n + r < q.N) {
                     float o = v[r];
-                    if (q.Cin) o += q.Cin[(size_t)b * q.ldcin + n + r];
-                    if (q.Cin2) o += q.Cin2[(size_t)b * q.ldc + n + r];
-                    if (q.bias) o += q.bias[n + r];
+                    if (q.Cin) o += e_cin[r];
+                    if (q.Cin2) o += e_cin2[r];
+                    if (q.bias) o += e_bias[r];
                     q.C[(size_t)b * q.ldc + n + r] = o;
                 }
             }

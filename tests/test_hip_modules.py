@@ -206,3 +206,26 @@ def test_fused_ffn_modes_agree_with_fixture(mode):
         test_train_mode_matches_oracle_with_same_masks("AcousticDiscriminator", 100, 94, 4)
     finally:
         lib.ganffn_debug_set_ffn_mode(0)
+
+
+@pytest.mark.parametrize("case,d_in", [("TextGenerator", 100), ("VisualGenerator", 512), ("VisualDiscriminator", 512)])
+def test_parameter_gradients_do_not_depend_on_whether_the_input_wants_a_gradient(case, d_in):
+    """ganffn_encoder_bwd2 with need_dx_in = 0 (the input does not require grad: a network trained on data,
+    train_IEMOCAP.py:200-252) skips the bottom layer's in-proj dgrad and the PE-dropout backward — every parameter gradient
+    must keep its bits, in train mode with dropout (same Philox offsets on both runs)"""
+    from gan_ffn_amd import model, ops
+    torch.manual_seed(11)
+    m = getattr(model, case)(100).cuda().train()
+    x = torch.randn(41, 3, d_in, device="cuda")
+    grads = []
+    for want in (True, False):
+        ops.manual_seed(5, "cuda")
+        xi = x.clone().requires_grad_(want)
+        m.zero_grad(set_to_none=True)
+        out = m(xi)
+        out.square().sum().backward()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        assert len(grads[-1]) > 100
+        assert (xi.grad is not None) == want
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
