@@ -191,6 +191,30 @@ SCHEDULE_BIMODAL = [s for s in SCHEDULE if "visual" not in s[1:]]
 STREAM_MAP_BIMODAL = {1: [0, 0, 0, 0], 2: [0, 0, 1, 1]}
 
 
+_STREAMS = {}
+
+
+def _side_streams(dev, prios, tuner=None):
+    """the side streams of a device, chosen once per process and shared by every engine built afterwards.
+
+    Which hardware queue a new HIP stream lands on depends on how many streams the process created and used before
+    (torch's pools, RCCL, other engines), and with it how well kernels of different streams overlap: the same three
+    sub-step chains ran at 34.7, 37.1, 40.5, 43.5 or 54 ms per iteration depending on nothing but that
+    (tools/lab/stream_order.py; 1-workgroup spin kernels overlap on every pair — only real launch mixes tell the pairs
+    apart).  `tuner(candidates_by_priority, prios)` picks the streams by timing a probe workload (GanEngine._tune_streams);
+    without it, or with GANFFN_STREAM_TUNE=0, fresh streams are taken as they come.  Engines join their streams at the end of
+    every step, so sharing them between the engines of one process is safe."""
+    key = (str(dev), tuple(prios))
+    if os.environ.get("GANFFN_STREAM_CACHE", "1") == "1" and key in _STREAMS:
+        return _STREAMS[key]
+    if tuner is not None and len(prios) > 1 and os.environ.get("GANFFN_STREAM_TUNE", "1") == "1":
+        streams = tuner(prios)
+    else:
+        streams = [torch.cuda.Stream(device=dev, priority=p_) for p_ in prios]
+    _STREAMS[key] = streams
+    return streams
+
+
 class _Runner:
     """network-level forward / backward / Adam on preallocated buffers — shared by the GAN step runner and the
     phase-2 (classifier) step runner"""
@@ -329,10 +353,69 @@ class GanEngine(_Runner):
             prio = [int(x) for x in os.environ.get("GANFFN_STREAM_PRIO", default_prio).split(",") if x.strip()]
             prio = (prio + [0] * self.n_streams)[:self.n_streams]
             # main streams, then (early generator forward) one helper stream per main stream
-            self.streams = [torch.cuda.Stream(device=dev, priority=prio[i % self.n_streams])
-                            for i in range(self.n_streams * (2 if self.early_gen else 1))]
+            self.streams = list(_side_streams(dev, prio, self._tune_streams))
+            self._tune_x = (None, None)
+            self._use_scratch(0)
+            if self.early_gen:
+                self.streams += [torch.cuda.Stream(device=dev, priority=p_) for p_ in prio]
         self._res = {}
         self.static_batch = None
+
+    def _tune_slot(self, i):
+        """the probe work of stream slot i for _tune_streams: eval-mode forwards of one generator into its no-save pass
+        buffers with the slot's scratch (nothing else is written: no parameter, gradient or RNG state changes)"""
+        k = self.modalities[i % len(self.modalities)]
+        if getattr(self, "_tune_x", (None, None))[0] != self._shape:
+            S, B = self._shape
+            self._tune_x = (self._shape, {m: torch.zeros(S, B, self.G[m].E, device=self.dev) for m in self.modalities})
+        self._use_scratch(i)
+        for _ in range(1 if self.G[k].E > 256 else 3):                      # (the 512-wide generator is ~3x a 100-wide one)
+            self._net_fwd(self.G[k], self.pass_G_nosave[k], self._tune_x[1][k], train=False, save=False, adds=(0, 1))
+
+    def _tune_streams(self, prios, n_cand=6, reps=2):
+        """choose one stream per entry of `prios` among n_cand fresh candidates per priority by TIMING them on this engine's
+        own kernels: slot i runs _tune_slot(i) beside the slots already chosen; the first two slots are chosen jointly over
+        all candidate pairs, every further slot greedily.  ~0.15 s, once per process and device."""
+        dev = self.dev
+        cands = {p_: [torch.cuda.Stream(device=dev, priority=p_) for _ in range(n_cand)] for p_ in sorted(set(prios))}
+        cur = torch.cuda.current_stream(dev)
+
+        def probe(streams):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            for i, st in enumerate(streams):
+                st.wait_event(e0)
+                with torch.cuda.stream(st):
+                    self._tune_slot(i)
+            for st in streams:
+                cur.wait_stream(st)
+            e1.record(cur)
+            e1.synchronize()
+            return e0.elapsed_time(e1)
+
+        def best(fixed, pool):
+            timed = []
+            for c_ in pool:
+                group = fixed + (list(c_) if isinstance(c_, tuple) else [c_])
+                timed.append((min(probe(group) for _ in range(reps)), c_))
+            return min(timed, key=lambda t_: t_[0])[1]
+
+        torch.cuda.synchronize(dev)
+        saved_add = self._base_add
+        self._base_add = 0
+        try:
+            probe([cands[prios[0]][0]])                                      # warm-up (lazy module / allocator state)
+            if prios[0] == prios[1]:
+                pool = [(a_, b_) for i, a_ in enumerate(cands[prios[0]]) for b_ in cands[prios[0]][i + 1:]]
+            else:
+                pool = [(a_, b_) for a_ in cands[prios[0]] for b_ in cands[prios[1]]]
+            chosen = list(best([], pool))
+            for p_ in prios[2:]:
+                chosen.append(best(chosen, [c_ for c_ in cands[p_] if c_ not in chosen]))
+        finally:
+            self._base_add = saved_add
+            torch.cuda.synchronize(dev)
+        return chosen
 
     def _resize_passes(self, S, B):
         for d in (self.pass_G_nosave, self.pass_G, self.pass_D1):
@@ -873,7 +956,7 @@ class DrnnEngine(GanEngine):
         self.h_step = torch.zeros(1, dtype=torch.int32, device=dev)
         self.class_w = torch.tensor(class_weights, device=dev, dtype=torch.float32) if class_weights is not None else None
         self.n_streams = max(1, min(3, n_streams))
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(3)] if self.n_streams > 1 else None
+        self.streams = None                                  # (n_streams > 1: chosen in _prepare5, once the buffers exist)
         self.loss = torch.zeros(1, device=dev)
         self._shape = None
         self._cap_S = self._cap_B = 0
@@ -920,6 +1003,18 @@ class DrnnEngine(GanEngine):
             p_.resize(S, B)
         self.cfg_train = _lib.DrnnCfg(S, B, self.Dm, self.H, self.He, self.p_rec, 1)
         self.cfg_eval = _lib.DrnnCfg(S, B, self.Dm, self.H, self.He, self.p_rec, 0)
+        if self.n_streams > 1 and self.streams is None:
+            self.streams = list(_side_streams(self.dev, [0, 0, 0], self._tune_streams))
+            self._tune_x = (None, None)
+
+    def _tune_slot(self, i):
+        k = ("acoustic", "visual", "text")[i % 3]
+        if getattr(self, "_tune_x", (None, None))[0] != self._shape:
+            S, B = self._shape
+            self._tune_x = (self._shape, {m: torch.zeros(S, B, self.G[m].E, device=self.dev) for m in self.G})
+        self.ws = self.ws3[k]
+        # (save=True: these pass buffers and their workspace were sized for the saving mode; the next real forward overwrites)
+        self._net_fwd(self.G[k], self.pass_G[k], self._tune_x[1][k], train=False, save=True, adds=(0, 1))
 
     # ------------------------------------------------------------------------------------------
     def _drnn_ptrs(self, grad):
