@@ -353,11 +353,9 @@ class GanEngine(_Runner):
             prio = [int(x) for x in os.environ.get("GANFFN_STREAM_PRIO", default_prio).split(",") if x.strip()]
             prio = (prio + [0] * self.n_streams)[:self.n_streams]
             # main streams, then (early generator forward) one helper stream per main stream
-            self.streams = list(_side_streams(dev, prio, self._tune_streams))
+            self.streams = list(_side_streams(dev, prio + (prio if self.early_gen else []), self._tune_streams))
             self._tune_x = (None, None)
             self._use_scratch(0)
-            if self.early_gen:
-                self.streams += [torch.cuda.Stream(device=dev, priority=p_) for p_ in prio]
         self._res = {}
         self.static_batch = None
 
@@ -644,8 +642,9 @@ class GanEngine(_Runner):
                 # stream, and runs beside this sub-step instead of after it.  (The visual generator's four sub-steps are a
                 # cycle — each needs the parameters the previous one wrote: its two train-mode forwards leave that chain.)
                 # Results do not change: same parameters, same dropout offsets (the multi-stream tests pass bit for bit with
-                # it on).  MEASURED SLOWER and therefore OFF by default (GANFFN_EARLY_GEN=1 enables it): 37.8 against 35.55 ms
-                # per step — the three streams already saturate the chip, more kernels in flight only slow each other down.
+                # it on).  NO GAIN, therefore OFF by default (GANFFN_EARLY_GEN=1 enables it): 35.4 against 35.3 ms per step with
+                # its six streams chosen by _tune_streams (37.8 and 47 ms before that: helper streams that shared a hardware
+                # queue with a main stream).
                 j = i + 1
                 if self.early_gen and j < nsub and self.schedule[j][0] == "G" and smap[j] == smap[i] and \
                         (kind, who) != ("G", self.schedule[j][1]):
