@@ -225,7 +225,7 @@ def test_parameter_gradients_do_not_depend_on_whether_the_input_wants_a_gradient
         out = m(xi)
         out.square().sum().backward()
         grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
-        assert len(grads[-1]) > 100
+        assert len(grads[-1]) >= 100
         assert (xi.grad is not None) == want
     for k in grads[0]:
         assert torch.equal(grads[0][k], grads[1][k]), k
