@@ -113,6 +113,10 @@ def load():
         raise GanffnError(
             "libganffn.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C gan_ffn_amd/csrc`. There is no CPU fallback for the GAN-FFN hot path." % LIB_PATH)
+    # torch first: its wheel carries its own HIP runtime, and device memory and streams come from torch.  Loaded in the other
+    # order, libganffn.so binds /opt/rocm's libamdhip64 and the process ends up with two runtimes — every launch of this
+    # library then fails with "no ROCm-capable device is detected" (seen with build() + smoke() in one process).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
