@@ -194,7 +194,7 @@ STREAM_MAP_BIMODAL = {1: [0, 0, 0, 0], 2: [0, 0, 1, 1]}
 _STREAMS = {}
 
 
-def _side_streams(dev, prios, tuner=None):
+def _side_streams(dev, prios, tuner=None, work=1):
     """the side streams of a device, chosen once per process and shared by every engine built afterwards.
 
     Which hardware queue a new HIP stream lands on depends on how many streams the process created and used before
@@ -202,16 +202,17 @@ def _side_streams(dev, prios, tuner=None):
     sub-step chains ran at 34.7, 37.1, 40.5, 43.5 or 54 ms per iteration depending on nothing but that
     (tools/lab/stream_order.py; 1-workgroup spin kernels overlap on every pair — only real launch mixes tell the pairs
     apart).  `tuner(candidates_by_priority, prios)` picks the streams by timing a probe workload (GanEngine._tune_streams);
-    without it, or with GANFFN_STREAM_TUNE=0, fresh streams are taken as they come.  Engines join their streams at the end of
+    without it, or with GANFFN_STREAM_TUNE=0, fresh streams are taken as they come; `work` = tokens per pass of the engine
+    that asks (the choice is re-timed when a much bigger engine comes along).  Engines join their streams at the end of
     every step, so sharing them between the engines of one process is safe."""
     key = (str(dev), tuple(prios))
-    if os.environ.get("GANFFN_STREAM_CACHE", "1") == "1" and key in _STREAMS:
-        return _STREAMS[key]
+    if os.environ.get("GANFFN_STREAM_CACHE", "1") == "1" and key in _STREAMS and work <= 4 * _STREAMS[key][1]:
+        return _STREAMS[key][0]                 # (a choice timed on a much smaller batch is not trusted for a big one)
     if tuner is not None and len(prios) > 1 and os.environ.get("GANFFN_STREAM_TUNE", "1") == "1":
         streams = tuner(prios)
     else:
         streams = [torch.cuda.Stream(device=dev, priority=p_) for p_ in prios]
-    _STREAMS[key] = streams
+    _STREAMS[key] = (streams, max(1, work))
     return streams
 
 
@@ -353,7 +354,7 @@ class GanEngine(_Runner):
             prio = [int(x) for x in os.environ.get("GANFFN_STREAM_PRIO", default_prio).split(",") if x.strip()]
             prio = (prio + [0] * self.n_streams)[:self.n_streams]
             # main streams, then (early generator forward) one helper stream per main stream
-            self.streams = list(_side_streams(dev, prio + (prio if self.early_gen else []), self._tune_streams))
+            self.streams = list(_side_streams(dev, prio + (prio if self.early_gen else []), self._tune_streams, S * B))
             self._tune_x = (None, None)
             self._use_scratch(0)
         self._res = {}
@@ -1003,7 +1004,7 @@ class DrnnEngine(GanEngine):
         self.cfg_train = _lib.DrnnCfg(S, B, self.Dm, self.H, self.He, self.p_rec, 1)
         self.cfg_eval = _lib.DrnnCfg(S, B, self.Dm, self.H, self.He, self.p_rec, 0)
         if self.n_streams > 1 and self.streams is None:
-            self.streams = list(_side_streams(self.dev, [0, 0, 0], self._tune_streams))
+            self.streams = list(_side_streams(self.dev, [0, 0, 0], self._tune_streams, S * B))
             self._tune_x = (None, None)
 
     def _tune_slot(self, i):

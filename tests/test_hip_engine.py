@@ -297,3 +297,22 @@ def test_short_last_batch_keeps_the_reserved_buffers():
         tol = 5e-5 if i == 0 else 0.15          # later batches: Adam chaos (same bound as GAN_LOSS_TOL[12:])
         for k in want:
             assert abs(want[k] - got[i][k]) < tol, (i, k, want[k], got[i][k])
+
+
+def test_engines_of_one_process_share_their_side_streams():
+    """the side streams are chosen once per process (by timing, engine._tune_streams) and every later engine of comparable
+    size runs on the same ones: on ROCm a second set of streams created later can land on hardware queues that serialise
+    the sub-step chains (DESIGN.md §4 iv).  A much bigger engine re-times the choice."""
+    from gan_ffn_amd import engine
+    handles = []
+    for S, B in ((11, 2), (13, 2), (94, 8)):
+        gens, discs = build_all(zero_dropout=True)
+        eng = engine.GanEngine(gens, discs, n_streams=3)
+        eng.iteration(gan_batch(S=S, B=B))
+        eng.synchronize()
+        torch.cuda.synchronize()
+        assert len(eng.streams) == 3 and len({s.cuda_stream for s in eng.streams}) == 3
+        handles.append([s.cuda_stream for s in eng.streams])
+    assert handles[0] == handles[1]
+    key = (str(eng.dev), (0, 0, -1))
+    assert engine._STREAMS[key][1] >= 94 * 8 or handles[2] == handles[0]
