@@ -201,7 +201,7 @@ def _side_streams(dev, prios, tuner=None, work=1):
     (torch's pools, RCCL, other engines), and with it how well kernels of different streams overlap: the same three
     sub-step chains ran at 34.7, 37.1, 40.5, 43.5 or 54 ms per iteration depending on nothing but that
     (tools/lab/stream_order.py; 1-workgroup spin kernels overlap on every pair — only real launch mixes tell the pairs
-    apart).  `tuner(candidates_by_priority, prios)` picks the streams by timing a probe workload (GanEngine._tune_streams);
+    apart).  `tuner(prios)` picks the streams by timing a probe workload on fresh candidates (GanEngine._tune_streams);
     without it, or with GANFFN_STREAM_TUNE=0, fresh streams are taken as they come; `work` = tokens per pass of the engine
     that asks (the choice is re-timed when a much bigger engine comes along).  Engines join their streams at the end of
     every step, so sharing them between the engines of one process is safe."""
