@@ -376,6 +376,7 @@ class GanEngine(_Runner):
         own kernels: slot i runs _tune_slot(i) beside the slots already chosen; the first two slots are chosen jointly over
         all candidate pairs, every further slot greedily.  ~0.15 s, once per process and device."""
         dev = self.dev
+        n_cand = int(os.environ.get("GANFFN_STREAM_CAND", n_cand))
         cands = {p_: [torch.cuda.Stream(device=dev, priority=p_) for _ in range(n_cand)] for p_ in sorted(set(prios))}
         cur = torch.cuda.current_stream(dev)
 
