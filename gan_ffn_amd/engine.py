@@ -907,7 +907,7 @@ class DrnnEngine(GanEngine):
     """One train / eval step of GAN_FFN_DialogueRNN on the C ABI, no autograd graph: the three generators (n_streams = 3
     runs their forward and backward passes on three HIP streams chosen like GanEngine's; measured NOT faster than one
     stream on this workload — 15.0-16.5 against 14.9-15.0 ms per step: kernels of different streams do not run side by
-    side, only the dead time between launches overlaps, and the generators are 6 of ~1100 launches —
+    side, only the dead time between launches overlaps, and the run-to-run spread grows —
     so one stream is the default), fusion = their sum, BiModel's two
     DialogueRNN directions through one chain of launches (ganffn_drnn_fwd / _bwd), the matching attention
     (ganffn_general2_attention_*), linear + ReLU + dropout, the class head, MaskedNLLLoss with class weights, and Adam
