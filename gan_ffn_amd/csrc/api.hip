@@ -123,8 +123,7 @@ int g_dhead_off = 0;
 int g_pe_off = 0;
 extern int g_n100_force_splits;
 extern int g_tn100_off, g_tn100_force_splits;
-extern unsigned long long* g_n100_stamps;
-extern unsigned long long* g_wres_stamps;
+GF_LAB_ONLY(extern unsigned long long* g_n100_stamps; extern unsigned long long* g_wres_stamps;)
 constexpr int MAX_SPLITS = 16;  // partial-output slabs: fused FFN (16 F splits) / split-K GEMMs (<= 8)
 
 static int64_t a4(int64_t n) { return (n + 3) & ~int64_t(3); }
@@ -656,9 +655,12 @@ extern "C" int ganffn_gemm_n100(const float* A, const float* W, int w_kmajor, co
     *n_slabs = s;
     return 0;
 }
-// lab only, deliberately NOT declared in include/ganffn.h: in-kernel time stamps of gemm_n100 (5 x uint64 per workgroup)
+#ifdef GANFFN_LAB
+// lab builds only (make LAB=1 -> lib/libganffn_lab.so; never in the product library, not declared in include/ganffn.h):
+// in-kernel time stamps of gemm_n100 (5 x uint64 per workgroup) and gemm_wres (4 x uint64)
 extern "C" int ganffn_lab_set_n100_stamps(void* dev_buf) { g_n100_stamps = (unsigned long long*)dev_buf; return 0; }
 extern "C" int ganffn_lab_set_wres_stamps(void* dev_buf) { g_wres_stamps = (unsigned long long*)dev_buf; return 0; }
+#endif
 extern "C" int ganffn_debug_set_ffn_mode(int bits) {
     g_ffn_fused = (bits & 1) ? 1 : 0;
     g_rc_off = (bits & 2) ? 1 : 0;

@@ -7,6 +7,14 @@
 
 #include "../../include/ganffn.h"
 
+// Lab instrumentation (in-kernel time stamps and their setters) exists only in lab builds (`make LAB=1` ->
+// lib/libganffn_lab.so, selected by tools/lab scripts through GANFFN_LIB); the product library compiles none of it.
+#ifdef GANFFN_LAB
+#define GF_LAB_ONLY(...) __VA_ARGS__
+#else
+#define GF_LAB_ONLY(...)
+#endif
+
 namespace ganffn {
 
 // ---------------------------------------------------------------------------------------

@@ -662,10 +662,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmArgs g) {
 // A software-pipelined variant (previous tile's epilogue and this tile's Philox rounds interleaved between the MFMAs,
 // 2 waves per SIMD at 200 VGPRs) was built and measured slower (22.3 / 37.0 us); this is the simple form.
 // Same MFMA (v_mfma_f32_32x32x2_f32, exact fp32) and the same epilogue formulas as gemm_body.
-unsigned long long* g_wres_stamps = nullptr;    // lab only (ganffn_lab_set_wres_stamps): 4 x uint64 per workgroup
+GF_LAB_ONLY(unsigned long long* g_wres_stamps = nullptr;)    // lab builds only (make LAB=1): 4 x uint64 of in-kernel time stamps per workgroup
 
 template <int MODE, int EPI, int KC>
-__global__ __launch_bounds__(256) void gemm_wres_kernel(GemmArgs g, int mtiles, int wg_per_panel, unsigned long long* stamps) {
+__global__ __launch_bounds__(256) void gemm_wres_kernel(GemmArgs g, int mtiles, int wg_per_panel GF_LAB_ONLY(, unsigned long long* stamps)) {
     static_assert(KC % 4 == 0 && KC <= 128, "short K only");
     constexpr int BM = 64, BN = 64;
     constexpr int G8 = (KC + 7) / 8;                              // groups of 8 along k; k >= KC carries zero weights
@@ -677,8 +677,8 @@ __global__ __launch_bounds__(256) void gemm_wres_kernel(GemmArgs g, int mtiles, 
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
     const int panel = blockIdx.x / wg_per_panel, j0 = blockIdx.x - panel * wg_per_panel;
     const int n0 = panel * BN;
-    unsigned long long* const stamp = (stamps && tid == 0) ? stamps + 4 * (size_t)blockIdx.x : nullptr;
-    if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
+    GF_LAB_ONLY(unsigned long long* const stamp = (stamps && tid == 0) ? stamps + 4 * (size_t)blockIdx.x : nullptr;
+                if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();)
 
     // weight fragments: MFMA j of group gq takes k = 8 gq + 4 h + j — the k order of gemm_body, so this kernel's results
     // are bit-identical to the generic kernel's (a K tail is zero weights against clamped, finite token values)
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void gemm_wres_kernel(GemmArgs g, int mtiles, 
     GF_WRES_SSTORE(0)
     __syncthreads();
     int buf = 0;
-    if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
+    GF_LAB_ONLY(if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();)
 
     // One tile's 4 * G8 MFMAs with their LDS fragment reads.
 #define GF_WRES_MFMA(ACC, BUF)                                                                              \
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256) void gemm_wres_kernel(GemmArgs g, int mtiles, 
         }
         __syncthreads();
     }
-    if (stamp) { stamp[2] = __builtin_amdgcn_s_memtime(); stamp[3] = (unsigned long long)((mtiles - j0 + wg_per_panel - 1) / wg_per_panel); }
+    GF_LAB_ONLY(if (stamp) { stamp[2] = __builtin_amdgcn_s_memtime(); stamp[3] = (unsigned long long)((mtiles - j0 + wg_per_panel - 1) / wg_per_panel); })
 #undef GF_WRES_MFMA
 #undef GF_WRES_GLOAD
 #undef GF_WRES_SSTORE
@@ -794,7 +794,7 @@ static int launch_wres(const GemmArgs& g, hipStream_t st) {
     int per = res / panels;
     if (per < 1) per = 1;
     if (per > mtiles) per = mtiles;
-    hipLaunchKernelGGL((gemm_wres_kernel<MODE, EPI, KC>), dim3(panels * per), dim3(256), lds, st, g, mtiles, per, g_wres_stamps);
+    hipLaunchKernelGGL((gemm_wres_kernel<MODE, EPI, KC>), dim3(panels * per), dim3(256), lds, st, g, mtiles, per GF_LAB_ONLY(, g_wres_stamps));
     GF_LAUNCH_CHECK();
     return 0;
 }

@@ -38,8 +38,8 @@ struct N100Args {
     const float* bias;             // [100] or null; added by chunk 0
     float* C; long slab_stride;    // C + z * slab_stride: [T x 100] partial product of K chunk z
     int T, K, kchunk;
-    unsigned long long* stamps;    // lab only (null in the product): per workgroup {realtime at entry, cycles at entry, after the
-                                   // prologue, after the K loop, at exit}
+    GF_LAB_ONLY(unsigned long long* stamps;)   // lab builds only (make LAB=1): per workgroup {realtime at entry, cycles at entry,
+                                               // after the prologue, after the K loop, at exit}
 };
 
 template <bool WKMAJOR>
@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void gemm_n100_kernel(N100Args a) {
     const int m0 = blockIdx.x * NBM, z = blockIdx.y;
     const int kbeg = z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
     const int nt = (kend - kbeg) / NBK;                           // K, kchunk multiples of 32
-    unsigned long long* const stamp = (a.stamps && tid == 0) ? a.stamps + 5 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
-    if (stamp) { stamp[0] = __builtin_amdgcn_s_memrealtime(); stamp[1] = __builtin_amdgcn_s_memtime(); }
+    GF_LAB_ONLY(unsigned long long* const stamp = (a.stamps && tid == 0) ? a.stamps + 5 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
+                if (stamp) { stamp[0] = __builtin_amdgcn_s_memrealtime(); stamp[1] = __builtin_amdgcn_s_memtime(); })
 
     // loader geometry (loop-invariant element offsets, clamped rows).  Activations: 64 rows x 8 slots = 512 float4, 2 per
     // thread.  Weights: NT 112 rows x 8 slots = 896 float4 (rows >= 100 clamped: they feed discarded features), NN 32 k rows
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm_n100_kernel(N100Args a) {
     GF_N100_GLOAD(B, 1)
     GF_N100_SSTORE(A, 0)
     __syncthreads();
-    if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
+    GF_LAB_ONLY(if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();)
 
     // steps in pairs: even tiles live in register set A / LDS stage 0, odd tiles in set B / stage 1.  The sched_barriers
     // keep the global loads ahead of the MFMAs of the step they are issued in (hipcc sinks them to their use otherwise).
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void gemm_n100_kernel(N100Args a) {
 #undef GF_N100_AIDX
 #undef GF_N100_WIDX
 
-    if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
+    GF_LAB_ONLY(if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();)
     // epilogue: lane (c, g) holds token m0 + 16 wave + c, features 16 m + 4 g .. + 3
     const int tok = m0 + wave * 16 + c;
     if (tok < a.T) {
@@ -185,13 +185,13 @@ __global__ __launch_bounds__(256) void gemm_n100_kernel(N100Args a) {
             }
         }
     }
-    if (stamp) stamp[4] = __builtin_amdgcn_s_memtime();
+    GF_LAB_ONLY(if (stamp) stamp[4] = __builtin_amdgcn_s_memtime();)
 }
 
 }  // namespace
 
 int g_n100_force_splits = 0;      // lab knob (ganffn_debug_set_ffn_mode bits 8..15): 0 = choose
-unsigned long long* g_n100_stamps = nullptr;   // lab knob (ganffn_lab_set_n100_stamps): device buffer for in-kernel time stamps
+GF_LAB_ONLY(unsigned long long* g_n100_stamps = nullptr;)   // lab builds only: device buffer for in-kernel time stamps
 
 bool n100_supported(int N, int K) { return N == NE && K >= 256 && (K % NBK) == 0; }
 
@@ -233,7 +233,7 @@ int launch_gemm_n100(const float* A, int lda, const float* W, int ldw, int w_kma
     const int per = (ksteps + s - 1) / s;
     s = (ksteps + per - 1) / per;
     *splits_io = s;
-    N100Args a{A, lda, W, ldw, bias, C, slab_stride, T, K, per * NBK, g_n100_stamps};
+    N100Args a{A, lda, W, ldw, bias, C, slab_stride, T, K, per * NBK GF_LAB_ONLY(, g_n100_stamps)};
     const dim3 grid((T + NBM - 1) / NBM, s), blk(256);
     if (w_kmajor) hipLaunchKernelGGL((gemm_n100_kernel<true>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((gemm_n100_kernel<false>), grid, blk, 0, st, a);

@@ -294,7 +294,7 @@ int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* par
         splits = (int)((1700 + tiles - 1) / tiles);
         if (splits > WMAXSPLIT) splits = WMAXSPLIT;
         if (splits > kmax / 256) splits = kmax / 256;
-        if (g_tn100_force_splits > 0) splits = g_tn100_force_splits;
+        if (g_tn100_force_splits > 0) splits = g_tn100_force_splits < WMAXSPLIT ? g_tn100_force_splits : WMAXSPLIT;
         if ((long)splits * per_split > part_floats) splits = (int)(part_floats / per_split);
         if (splits < 2) splits = 1;
     }

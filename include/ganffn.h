@@ -19,8 +19,11 @@
  *    affect results — the thread-local last-error string and, per (kernel, device, host thread),
  *    the facts that hipFuncSetAttribute has opted a kernel in to > 48 KiB of LDS and how many
  *    workgroups of the persistent short-K GEMM the device holds at once — and ONE debug switch,
- *    ganffn_debug_set_ffn_mode (default 0; its bits select the older launch sequences of three
- *    d_model-100 sub-chains for A/B measurement — same results to rounding).
+ *    ganffn_debug_set_ffn_mode (default 0; bits 0..6 select the older launch sequences of the
+ *    d_model-100 sub-chains for A/B measurement, bits 8..19 force the chunk counts of two kernels
+ *    — same results to rounding; documented at its declaration).  The library exports nothing
+ *    that is not declared here: in-kernel time stamps and their ganffn_lab_* setters exist only in
+ *    the lab build (`make LAB=1`, a different .so), and the library reads no environment variable.
  *  - Results are bit-reproducible: no kernel accumulates with floating-point atomics (weight
  *    gradients, bias gradients, LayerNorm gradients and loss sums are owner-computed or reduced
  *    in a fixed order), so two runs from the same state and RNG offset give identical bits.
@@ -342,7 +345,8 @@ int ganffn_gemm_n100(const float* A, const float* W, int w_kmajor, const float* 
  *   bit 5: run the discriminator head as separate GELU / GEMM / tail launches instead of csrc/disc_head.hip;
  *   bit 6: run the head of a d_model-100 encoder stack (positional encoding + dropout, layer 0's in-proj) as two launches
  *          instead of one (csrc/rowchain.hip);
- *   bits 8..19: lab knobs (forced chunk counts of the two kernels above; 0 = choose).
+ *   bits 8..15: forced K-chunk count of csrc/gemm_n100.hip (0 = choose; clamped to the caller's slab capacity);
+ *   bits 16..19: forced token-chunk count of csrc/gemm_tn100.hip (0 = choose; clamped to 8 and to the workspace).
  * Every combination is parity-tested; results agree to rounding. */
 int ganffn_debug_set_ffn_mode(int bits);
 

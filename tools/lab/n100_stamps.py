@@ -2,6 +2,8 @@
 import ctypes as C, os, sys, torch
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
+import os
+os.environ.setdefault("GANFFN_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "gan_ffn_amd", "lib", "libganffn_lab.so"))  # make -C gan_ffn_amd/csrc LAB=1
 from gan_ffn_amd import _lib, ops
 lib = _lib.load()
 raw = C.CDLL(_lib.LIB_PATH)
