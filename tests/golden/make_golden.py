@@ -361,12 +361,92 @@ def dialogue_rnn_big():
     return out
 
 
+HEAD_S, HEAD_B = 94, 32      # the headline configuration: BASELINE.json configs[1] (batch 32, train_IEMOCAP.py:603; S = 94, model.py:1437)
+BIG_CASES = (("AcousticGenerator", 100), ("TextGenerator", 100), ("VisualGenerator", 512), ("AcousticDiscriminator", 100),
+             ("TextDiscriminator", 100), ("VisualDiscriminator", 512), ("VisualDiscriminator", 100))
+
+
+def modules_big():
+    """the six reference modules (seven input cases) at the HEADLINE size (94, 32), eval mode, formula weights: summaries
+    (strided samples + sum + l2) of the output, the input gradient and the SELECTED parameter gradients — the same
+    quantities as module_cases(), so the GPU tests compare the HIP path with the reference directly at this size"""
+    out = {}
+    S, B = HEAD_S, HEAD_B
+    for cls_name, din in BIG_CASES:
+        m = build(cls_name).eval()
+        tag = "%s.%d.%dx%d" % (cls_name, din, S, B)
+        x = torch.from_numpy(F_.formula_input(tag, S, B, din, pad_from=61)).requires_grad_(True)
+        for p in m.parameters():
+            p.grad = None
+        y = m(x)
+        g = torch.from_numpy(F_.formula_input("grad." + tag, S, B, y.shape[-1])) - 0.5
+        (y * g).sum().backward()
+        put(out, tag + "/out", y)
+        put(out, tag + "/dx", x.grad)
+        sd = dict(m.named_parameters())
+        for k in SELECTED:
+            if k in sd and sd[k].grad is not None:
+                put(out, tag + "/grad/" + k, sd[k].grad)
+        print("module_big", tag, tuple(y.shape), float(y.abs().mean()))
+    return out
+
+
+def gan_steps_big():
+    """ONE full 12-sub-step iteration at the headline size (94, 32) through the reference's own train_disc / train_gen
+    (dropout p -> 0 on the instances): the 12 losses and every network's first-update parameter deltas"""
+    import train_IEMOCAP as T
+    out = {}
+    S, B = HEAD_S, HEAD_B
+    gens = {k: build(v) for k, v in GEN.items()}
+    discs = {k: build(v) for k, v in DISC.items()}
+    for m in list(gens.values()) + list(discs.values()):
+        zero_dropout(m)
+    lr, b1, b2 = 1e-4, 0.5, 0.6
+    A = torch.optim.Adam
+    opt = {("G", "acoustic"): A(gens["acoustic"].parameters(), lr=lr, betas=(b1, b2)),
+           ("D", "acoustic"): A(discs["acoustic"].parameters(), lr=lr / 2, betas=(b1, b2)),
+           ("G", "visual"): A(gens["visual"].parameters(), lr=lr, betas=(b1, b2)),
+           ("D", "visual"): A(discs["visual"].parameters(), lr=lr / 2, betas=(b1, b2)),
+           ("G", "text"): A(gens["text"].parameters(), lr=lr * 1.1, betas=(b1, b2)),
+           ("D", "text"): A(discs["text"].parameters(), lr=lr / 2, betas=(b1, b2))}
+    bce = nn.BCELoss()
+    batch = {k: torch.from_numpy(F_.formula_input("ganbig." + k, S, B, DIN[k], pad_from=61)) for k in DIN}
+    valid, fake = torch.ones(S, B, 1), torch.zeros(S, B, 1)
+    sched = [("D", "visual", "acoustic"), ("G", "acoustic", "visual"), ("D", "visual", "text"),
+             ("G", "text", "visual"), ("D", "text", "acoustic"), ("G", "acoustic", "text"),
+             ("D", "acoustic", "text"), ("G", "text", "acoustic"), ("D", "text", "visual"),
+             ("G", "visual", "text"), ("D", "acoustic", "visual"), ("G", "visual", "acoustic")]
+    losses, seen = [], set()
+    for kind, who, partner in sched:
+        if kind == "D":
+            v = T.train_disc(discs[who], batch[who], gens[partner], batch[partner], opt[("D", who)], bce, valid, fake)
+        else:
+            v = T.train_gen(gens[who], batch[who], discs[partner], opt[("G", who)], bce, valid, fake)
+        losses.append(float(v))
+        print("gan_big %s %s|%s loss %.7f" % (kind, who, partner, float(v)), flush=True)
+        if (kind, who) not in seen:
+            seen.add((kind, who))
+            sd = dict((discs if kind == "D" else gens)[who].named_parameters())
+            for k in SELECTED:
+                if k in sd:
+                    w0 = F_.formula_tensor(k, tuple(sd[k].shape))
+                    put(out, "gan/%s_%s/delta1/%s" % (kind, who, k), sd[k].detach().numpy() - w0)
+    out["gan/losses"] = np.array(losses, dtype=np.float64)
+    return out
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dialogue_rnn":
         np.savez_compressed(os.path.join(HERE, "dialogue_rnn.npz"), **dialogue_rnn())
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "dialogue_rnn_big":
         np.savez_compressed(os.path.join(HERE, "dialogue_rnn_big.npz"), **dialogue_rnn_big())
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "modules_big":
+        np.savez_compressed(os.path.join(HERE, "modules_big.npz"), **modules_big())
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "gan_steps_big":
+        np.savez_compressed(os.path.join(HERE, "gan_steps_big.npz"), **gan_steps_big())
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "artifacts":
         np.savez_compressed(os.path.join(HERE, "artifacts.npz"), **artifacts())
@@ -378,4 +458,6 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "artifacts.npz"), **artifacts())
     np.savez_compressed(os.path.join(HERE, "dialogue_rnn.npz"), **dialogue_rnn())
     np.savez_compressed(os.path.join(HERE, "dialogue_rnn_big.npz"), **dialogue_rnn_big())
+    np.savez_compressed(os.path.join(HERE, "modules_big.npz"), **modules_big())
+    np.savez_compressed(os.path.join(HERE, "gan_steps_big.npz"), **gan_steps_big())
     print("golden fixtures written to", HERE)
