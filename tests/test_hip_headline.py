@@ -65,7 +65,7 @@ def test_engine_reproduces_reference_iteration_at_headline_size(n_streams):
             if (kind, who) not in seen:
                 seen.add((kind, who))
                 sd = dict((discs if kind == "D" else gens)[who].named_parameters())
-                check_first_update(g, kind, who, lambda k: sd[k].detach().cpu().numpy(), outlier_frac=HEAD_DELTA_OUTLIERS)
+                check_first_update(g, kind, who, lambda k: sd[k].detach().cpu().numpy(), outlier_frac=HEAD_DELTA_OUTLIERS, l2_rtol=2e-2)
     else:
         eng.iteration(batch)
         eng.synchronize()
