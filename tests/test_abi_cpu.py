@@ -114,3 +114,22 @@ def test_same_seed_same_init_as_stock_construction_order():
     assert set(sa) == set(sb)
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+def test_model_shim_binds_every_name_the_trainers_import():
+    """gan_ffn_amd/shims/model.py under the module name `model` serves the import lists of
+    /root/reference/train_IEMOCAP.py:18-29 and train_IEMOCAP_DialogueRNN.py:18-30"""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gan_ffn_amd", "shims", "model.py")
+    spec = importlib.util.spec_from_file_location("model", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from gan_ffn_amd import model as pkg
+    for name in ("MaskedNLLLoss", "FocalLoss", "LSTMModel2", "AcousticGenerator", "AcousticDiscriminator", "TextGenerator",
+                 "TextDiscriminator", "VisualGenerator", "VisualDiscriminator", "GAN_FFN", "GAN_FFN_DialogueRNN"):
+        assert hasattr(mod, name), name
+        if name not in ("FocalLoss", "LSTMModel2"):
+            assert getattr(mod, name) is getattr(pkg, name)
+    with pytest.raises(NotImplementedError):
+        mod.LSTMModel2()
