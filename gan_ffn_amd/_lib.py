@@ -79,6 +79,9 @@ SIGNATURES = {
     "ganffn_gemm_tn_grouped": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "ganffn_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),
     "ganffn_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),
+    "ganffn_attention_keep_words": (_L, [_I, _I]),
+    "ganffn_attention_fwd_keep": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),
+    "ganffn_attention_bwd_keep": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),
     "ganffn_add_dropout_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U32, _P, _U64, _P]),
     "ganffn_add_dropout_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U32, _P, _U64, _P]),
     "ganffn_general2_attention_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -119,6 +122,8 @@ def load():
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("GANFFN_LIB") and not hasattr(lib, name):
+            continue             # a lab / older build named through GANFFN_LIB may lack newer entry points (A/B measurement only)
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args

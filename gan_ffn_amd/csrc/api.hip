@@ -67,10 +67,10 @@ static LayerOff layer_off(int E, int F) {
 // ------------------------------------------------------------------------------------------
 // saved-for-backward layout of one encoder stack
 //   X[0..L]      (L+1) * T*E     X[0] = PE output, X[l+1] = output of layer l
-//   per layer:   qkv 3TE | attn_o TE | x1 TE | xhat1 TE | xhat2 TE | h TF | rstd1 T4 | rstd2 T4 | lse (T H)4
+//   per layer:   qkv 3TE | attn_o TE | x1 TE | xhat1 TE | xhat2 TE | h TF | rstd1 T4 | rstd2 T4 | lse (T H)4 | keep B H 448
 // ------------------------------------------------------------------------------------------
 struct SavedOff {
-    int64_t X, layers, per_layer, qkv, attn_o, x1, xhat1, xhat2, h, rstd1, rstd2, lse, total;
+    int64_t X, layers, per_layer, qkv, attn_o, x1, xhat1, xhat2, h, rstd1, rstd2, lse, keep, total;
 };
 static SavedOff saved_off(const ganffn_enc_cfg* c) {
     SavedOff s;
@@ -87,6 +87,7 @@ static SavedOff saved_off(const ganffn_enc_cfg* c) {
     s.rstd1 = p; p += T4;
     s.rstd2 = p; p += T4;
     s.lse = p; p += (T * c->H + 3) & ~int64_t(3);     // attention log-sum-exp [B*H x S]
+    s.keep = p; p += (int64_t)c->B * c->H * ATTN_KEEP_WORDS;   // attention-dropout keep words (uint32) of a train-mode pass
     s.per_layer = p;
     s.total = s.layers + (int64_t)c->L * s.per_layer;
     return s;
@@ -121,7 +122,7 @@ int g_n100_off = 0;
 int g_dhead_off = 0;
 // bit 6: positional encoding + dropout and layer 0's in-proj as two launches instead of rowchain.hip's one
 int g_pe_off = 0;
-extern int g_n100_force_splits;
+extern int g_n100_force_splits, g_n100_force_kw;
 extern int g_tn100_off, g_tn100_force_splits;
 GF_LAB_ONLY(extern unsigned long long* g_n100_stamps; extern unsigned long long* g_wres_stamps;)
 constexpr int MAX_SPLITS = 16;  // partial-output slabs: fused FFN (16 F splits) / split-K GEMMs (<= 8)
@@ -253,7 +254,9 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
         ea.bias = P + lo.in_b;
         if (!rc) GF_TRY(launch_gemm_nt(Xcur, E, P + lo.in_w, E, sv + so.qkv, 3 * E, T, 3 * E, E, EPI_NONE, ea, st));
         // attention core
-        GF_TRY(launch_attention_fwd(sv + so.qkv, sv + so.attn_o, sv + so.lse, S, B, E, H, c->p_enc, site + 0, rng, add, train, st));
+        // (keep words only when a backward will follow: saved != null)
+        GF_TRY(launch_attention_fwd(sv + so.qkv, sv + so.attn_o, sv + so.lse, saved ? reinterpret_cast<uint32_t*>(sv + so.keep) : nullptr, S, B, E,
+                                    H, c->p_enc, site + 0, rng, add, train, st));
         // out-proj, residual + dropout + LN1
         if (rc) {
             GF_TRY(launch_rc_outproj_ln_fwd(sv + so.attn_o, P + lo.out_w, P + lo.out_b, Xcur, P + lo.n1w, P + lo.n1b, sv + so.x1,
@@ -431,8 +434,8 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
         if (G) tn[ntn++] = TnDesc{dyB, E, sv + so.attn_o, E, G + lo.out_w, E, G + lo.out_b, E, E, T};
         if (!rc) GF_TRY(launch_gemm_nn(dyB, E, P + lo.out_w, E, d_attn, E, T, E, E, EPI_NONE, none, st));
         // attention core backward
-        GF_TRY(launch_attention_bwd(sv + so.qkv, sv + so.attn_o, sv + so.lse, d_attn, d_qkv, S, B, E, H, c->p_enc, site + 0, rng,
-                                    add, train, st));
+        GF_TRY(launch_attention_bwd(sv + so.qkv, sv + so.attn_o, sv + so.lse, d_attn, reinterpret_cast<const uint32_t*>(sv + so.keep), d_qkv, S, B, E,
+                                    H, c->p_enc, site + 0, rng, add, train, st));
         // in-proj wgrad + dgrad; dX[l] = d_qkv W_in + dz1
         if (G) tn[ntn++] = TnDesc{d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T};
         if (ntn == 40 || (l == layer_lo && ntn > 0)) {
@@ -670,6 +673,8 @@ extern "C" int ganffn_debug_set_ffn_mode(int bits) {
     g_tn100_off = (bits & 8) ? 1 : 0;
     g_tn100_force_splits = (bits >> 16) & 0xF;      // lab: force the token-chunk count of the d_model-100 grouped wgrad (0 = choose)
     g_n100_force_splits = (bits >> 8) & 0xFF;       // lab: force the K-chunk count of gemm_n100 (0 = choose)
+    g_n100_force_kw = (bits >> 20) & 0x3;           // lab: force 4 (1) or 8 (2) waves per gemm_n100 workgroup (0 = choose; 3 -> 2)
+    if (g_n100_force_kw == 3) g_n100_force_kw = 2;
     return 0;
 }
 extern "C" int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h,
@@ -703,10 +708,20 @@ extern "C" int ganffn_gemm_tn_grouped(int n, const float* const* At, const float
 }
 extern "C" int ganffn_attention_fwd(const float* qkv, float* o, float* lse, int S, int B, int E, int H, float p, uint32_t site,
                                     const uint64_t* rng, uint64_t add, void* stream) {
-    return launch_attention_fwd(qkv, o, lse, S, B, E, H, p, site, rng, add, 1, (hipStream_t)stream);
+    return launch_attention_fwd(qkv, o, lse, nullptr, S, B, E, H, p, site, rng, add, 1, (hipStream_t)stream);
+}
+extern "C" int64_t ganffn_attention_keep_words(int B, int H) { return (int64_t)B * H * ATTN_KEEP_WORDS; }
+extern "C" int ganffn_attention_fwd_keep(const float* qkv, float* o, float* lse, uint32_t* keep, int S, int B, int E, int H, float p,
+                                         uint32_t site, const uint64_t* rng, uint64_t add, void* stream) {
+    return launch_attention_fwd(qkv, o, lse, keep, S, B, E, H, p, site, rng, add, 1, (hipStream_t)stream);
+}
+extern "C" int ganffn_attention_bwd_keep(const float* qkv, const float* o, const float* lse, const float* d_o, const uint32_t* keep,
+                                         float* d_qkv, int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng,
+                                         uint64_t add, void* stream) {
+    return launch_attention_bwd(qkv, o, lse, d_o, keep, d_qkv, S, B, E, H, p, site, rng, add, 1, (hipStream_t)stream);
 }
 extern "C" int ganffn_attention_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv, int S,
                                     int B, int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add,
                                     void* stream) {
-    return launch_attention_bwd(qkv, o, lse, d_o, d_qkv, S, B, E, H, p, site, rng, add, 1, (hipStream_t)stream);
+    return launch_attention_bwd(qkv, o, lse, d_o, nullptr, d_qkv, S, B, E, H, p, site, rng, add, 1, (hipStream_t)stream);
 }

@@ -574,12 +574,12 @@ static int launch_bwd_t(const float* qkv, const float* d_o, float* d_qkv, const 
         default: return FN<HD, 4>(__VA_ARGS__);                 \
     }
 
-int launch_attention_fwd(const float* qkv, float* o, float* lse, int S, int B, int E, int H, float p, uint32_t site,
+int launch_attention_fwd(const float* qkv, float* o, float* lse, uint32_t* keep, int S, int B, int E, int H, float p, uint32_t site,
                          const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
     GF_TRY(check_attn(S, B, E, H));
     GF_CHECK_ARG(qkv && o, "attention_fwd: null pointer");
     GF_CHECK_ARG(!(train && p > 0.f) || rng, "attention_fwd: rng required when dropout is active");
-    if (attn16_supported(E, H, S)) return launch_attn16_fwd(qkv, o, lse, S, B, E, H, p, site, rng, add, train, st);
+    if (attn16_supported(E, H, S)) return launch_attn16_fwd(qkv, o, lse, keep, S, B, E, H, p, site, rng, add, train, st);
     const AttnGeom g = make_geom(S, B, E, H);
     const size_t lds = 3 * hd_mat_floats(g) * sizeof(float);
     GF_CHECK_ARG(lds <= 160 * 1024, "attention_fwd: LDS need %zu > 160 KiB", lds);
@@ -588,12 +588,13 @@ int launch_attention_fwd(const float* qkv, float* o, float* lse, int S, int B, i
     NT_SWITCH(launch_fwd_t, 0, qkv, o, g, lds, p, site, rng, add, train, st)
 }
 
-int launch_attention_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv, int S, int B,
-                         int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
+int launch_attention_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, const uint32_t* keep, float* d_qkv,
+                         int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
+                         hipStream_t st) {
     GF_TRY(check_attn(S, B, E, H));
     GF_CHECK_ARG(qkv && d_o && d_qkv, "attention_bwd: null pointer");
     GF_CHECK_ARG(!(train && p > 0.f) || rng, "attention_bwd: rng required when dropout is active");
-    if (attn16_supported(E, H, S)) return launch_attn16_bwd(qkv, o, lse, d_o, d_qkv, S, B, E, H, p, site, rng, add, train, st);
+    if (attn16_supported(E, H, S)) return launch_attn16_bwd(qkv, o, lse, d_o, keep, d_qkv, S, B, E, H, p, site, rng, add, train, st);
     const AttnGeom g = make_geom(S, B, E, H);
     const int hdt = (g.hd == 60 || g.hd == 64) ? g.hd : 0;      // kernel template head_dim (0 = generic)
     const bool alias = hdt == 0 || hdt * g.NT > 192;            // == attention_bwd_kernel::ALIAS

@@ -51,8 +51,13 @@ struct HeadSrc16 {
 };
 
 // Stage NM [S x HD] head slices into LDS images [16 NT rows][LD] (rows >= S and columns >= HD zero), in two phases so that
-// the caller can put data-independent work (the Philox calls) between issuing the global loads and waiting for them:
-// every global load of all matrices is issued (clamped addresses, masked by a select) before the first LDS write.
+// the caller can put data-independent work (the Philox calls) between issuing the global loads and waiting for them.
+// load(): every global load of all matrices, UNCONDITIONAL, from clamped addresses, nothing else — no use of a loaded
+// value before store().  (Round 4: the first version wrote `ok ? q * scale : 0` in load(); hipcc turned each such select
+// into a load under an exec-mask branch and, where the scale multiply followed, put an `s_waitcnt vmcnt(0)` right behind
+// it: the forward of a d_model-100 pass paid FIVE dependent global round trips before its first LDS write, the backward
+// three.  Out-of-range elements are now zeroed by a 0 / scale FACTOR at store time — a multiply cannot be folded into
+// "do not load" — and a sched_barrier keeps the loads together.)
 template <int HD, int NT, int NM, int NW = NT>   // NW: waves of the workgroup doing the staging
 struct HeadStage {
     static constexpr int LD = A16<HD>::LD, PR = LD / 2, ROWS = 16 * NT, PER = ROWS * PR, NTH = 64 * NW;
@@ -60,30 +65,33 @@ struct HeadStage {
     float2 v[NM][U];
     __device__ __forceinline__ void load(const HeadSrc16 (&m)[NM], int S, int B, int b, int tid) {
 #pragma unroll
-        for (int mi = 0; mi < NM; ++mi) {
+        for (int u = 0; u < U; ++u) {
+            const int i = min(tid + u * NTH, PER - 1);
+            const int s = i / PR, j = i - s * PR;
+            const size_t row = (size_t)(min(s, S - 1) * B + b);
+            const int col = min(2 * j, HD - 2);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = min(tid + u * NTH, PER - 1);
-                const int s = i / PR, j = i - s * PR;
-                const bool ok = s < S && 2 * j < HD;
-                const float2 q = *reinterpret_cast<const float2*>(m[mi].src + (size_t)(min(s, S - 1) * B + b) * m[mi].ld_src + min(2 * j, HD - 2));
-                v[mi][u] = ok ? make_float2(q.x * m[mi].scale, q.y * m[mi].scale) : make_float2(0.f, 0.f);
-            }
+            for (int mi = 0; mi < NM; ++mi) v[mi][u] = *reinterpret_cast<const float2*>(m[mi].src + row * m[mi].ld_src + col);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    __device__ __forceinline__ void store(const HeadSrc16 (&m)[NM], int tid) const {
+    __device__ __forceinline__ void store(const HeadSrc16 (&m)[NM], int S, int tid) const {
 #pragma unroll
-        for (int mi = 0; mi < NM; ++mi) {
+        for (int u = 0; u < U; ++u) {
+            const int i = tid + u * NTH;
+            if (PER % NTH == 0 || i < PER) {
+                const int s = i / PR, j = i - s * PR;
+                const float in = (s < S && 2 * j < HD) ? 1.f : 0.f;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = tid + u * NTH;
-                if (PER % NTH == 0 || i < PER) {
-                    const int s = i / PR, j = i - s * PR;
-                    *reinterpret_cast<float2*>(m[mi].dst + s * LD + 2 * j) = v[mi][u];
+                for (int mi = 0; mi < NM; ++mi) {
+                    const float f = in * m[mi].scale;
+                    *reinterpret_cast<float2*>(m[mi].dst + s * LD + 2 * j) = make_float2(v[mi][u].x * f, v[mi][u].y * f);
                 }
             }
-            if (tid < A16<HD>::TAIL) m[mi].dst[ROWS * LD + tid] = 0.f;
         }
+#pragma unroll
+        for (int mi = 0; mi < NM; ++mi)
+            if (tid < A16<HD>::TAIL) m[mi].dst[ROWS * LD + tid] = 0.f;
     }
 };
 
@@ -168,9 +176,9 @@ __device__ __forceinline__ void store4(float* __restrict__ row, int d0, const fl
 // ------------------------------------------------------------------------------------------
 template <int HD, int NT, int WPB>
 __global__ __launch_bounds__(64 * WPB) void attn16_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o,
-                                                             float* __restrict__ lse, int S, int B, int E, int H, float p,
-                                                             uint32_t site, const uint64_t* __restrict__ rng, uint64_t add,
-                                                             int train) {
+                                                             float* __restrict__ lse, uint32_t* __restrict__ keepw, int S, int B,
+                                                             int E, int H, float p, uint32_t site,
+                                                             const uint64_t* __restrict__ rng, uint64_t add, int train) {
     constexpr int LD = A16<HD>::LD, NTD = A16<HD>::NTD, MAT = 16 * NT * LD + A16<HD>::TAIL;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(NT % WPB == 0, "query tiles per workgroup must divide the tile count");
@@ -202,8 +210,12 @@ __global__ __launch_bounds__(64 * WPB) void attn16_fwd_kernel(const float* __res
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) mine |= (wd[qq] >= dc.thr ? 1u : 0u) << (4 * t + qq);
             }
+            // keep words for the backward (A16_KEEP_WORDS per (dialogue, head)): word [query group Q = 4w + c/4][4g + ql],
+            // nibble t = the four queries of the group at key 16t + 4g + ql — one coalesced dword store per lane; the
+            // backward then needs no Philox call at all (its lane (key 16w' + c', group g') reads word [4t + g'][c'])
+            if (keepw != nullptr) keepw[(size_t)rowgroup * 16 + 4 * g + ql] = mine;
         }
-        stg.store(m3, tid);
+        stg.store(m3, S, tid);
     }
     __syncthreads();
 
@@ -268,12 +280,14 @@ __global__ __launch_bounds__(64 * WPB) void attn16_fwd_kernel(const float* __res
 // ------------------------------------------------------------------------------------------
 // backward: wave w owns keys 16w .. 16w+15 (dK, dV) and, after the dS hand-over, queries 16w .. 16w+15 (dQ)
 // ------------------------------------------------------------------------------------------
-template <int HD, int NT>
+// SAVED: the dropout keep bits come from the words the forward stored (keepw) instead of Philox calls — the same bits, so
+// both forms give identical results (tests/test_hip_ops.py::test_attention_fwd_bwd compares them with torch.equal)
+template <int HD, int NT, bool SAVED>
 __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                              const float* __restrict__ lse, const float* __restrict__ d_o,
-                                                             float* __restrict__ d_qkv, int S, int B, int E, int H, float p,
-                                                             uint32_t site, const uint64_t* __restrict__ rng, uint64_t add,
-                                                             int train) {
+                                                             const uint32_t* __restrict__ keepw, float* __restrict__ d_qkv,
+                                                             int S, int B, int E, int H, float p, uint32_t site,
+                                                             const uint64_t* __restrict__ rng, uint64_t add, int train) {
     constexpr int LD = A16<HD>::LD, NTD = A16<HD>::NTD, KS = A16<HD>::KS, ROWS = 16 * NT, MAT = ROWS * LD + A16<HD>::TAIL;
     constexpr int LDS_S = ROWS + 4;                      // dS image [query][key]: rows 4 apart sit 16 banks apart
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -291,9 +305,12 @@ __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __rest
     const int ld3 = 3 * E;
     const float scale = rsqrtf((float)HD);
     const DropCtx dc = make_drop(rng, add, site, p, train);
-    uint32_t wdt[NT][4];
+    uint32_t wdt[SAVED ? 1 : NT][4];     // Philox words of this lane's (key, 4-query group) pairs     (recomputed masks)
+    uint32_t kw[SAVED ? NT : 1];         // keep words [4t + g][c]; this wave's nibble is bits 4w .. 4w+3    (saved masks)
+    if (!SAVED) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wdt[t][0] = wdt[t][1] = wdt[t][2] = wdt[t][3] = 0xFFFFFFFFu;
+        for (int t = 0; t < NT; ++t) wdt[t][0] = wdt[t][1] = wdt[t][2] = wdt[t][3] = 0xFFFFFFFFu;
+    }
     {
         const HeadSrc16 m4[4] = {{Qs, qkv + head * HD, ld3, scale}, {Ks, qkv + E + head * HD, ld3, 1.f},
                                  {Vs, qkv + 2 * E + head * HD, ld3, 1.f}, {Os, d_o + head * HD, E, 1.f}};
@@ -309,16 +326,20 @@ __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __rest
             dv[kk] = d_o[rowo + d];
         }
         const float lv = lse[(size_t)bh * S + min(qi, S - 1)];
+        if (SAVED) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) kw[t] = keepw[((size_t)bh * 28 + 4 * t + g) * 16 + c];
+        }
         HeadStage<HD, NT, 4> stg;
         stg.load(m4, S, B, b, tid);
-        if (dc.on) {
+        if (!SAVED && dc.on) {
             // the keep words of this lane's (key, 4-query group) pairs: exactly one Philox call per accumulator tile, and
             // data-independent — evaluated while the global loads are in flight
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 philox4((uint32_t)(bh * 28 + 4 * t + g) * 128u + (uint32_t)(16 * w + c), dc.site, dc.o0, dc.o1, dc.k0, dc.k1, wdt[t]);
         }
-        stg.store(m4, tid);
+        stg.store(m4, S, tid);
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) part += (4 * kk + g < HD && qi < S) ? ov[kk] * dv[kk] : 0.f;
         part += __shfl_xor(part, 16, 64);
@@ -350,7 +371,7 @@ __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float pv = keyok ? __expf(ps[t][r]) : 0.f;             // probability (pre-dropout)
-            const bool keep = !dc.on || wdt[t][r] >= dc.thr;
+            const bool keep = SAVED ? (((kw[t] >> (4 * w + r)) & 1u) != 0u) : (!dc.on || wdt[t][r] >= dc.thr);
             const float dpk = keep ? dp[t][r] * dc.scale : 0.f;          // dP = keep * scale * dP~
             ps[t][r] = keep ? pv * dc.scale : 0.f;                       // P~
             dp[t][r] = pv * (dpk - dd[r]);                               // dS
@@ -448,7 +469,7 @@ static size_t bwd_lds(int nt) {
 }
 
 template <int HD, int NT>
-static int launch16_fwd(const float* qkv, float* o, float* lse, int S, int B, int E, int H, float p, uint32_t site,
+static int launch16_fwd(const float* qkv, float* o, float* lse, uint32_t* keepw, int S, int B, int E, int H, float p, uint32_t site,
                         const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
     const size_t lds = fwd_lds<HD>(NT);
     // query tiles per workgroup: measured at hd = 10, S = 94 (tools/lab/attn_wpb.py, lab build): 320 problems 11.1 us as
@@ -457,8 +478,8 @@ static int launch16_fwd(const float* qkv, float* o, float* lse, int S, int B, in
 #define GF_A16_FWD(W)                                                                                               \
     {                                                                                                               \
         GF_TRY((lds_optin<attn16_fwd_kernel<HD, NT, W>>(lds, "attention_fwd")));                                    \
-        hipLaunchKernelGGL((attn16_fwd_kernel<HD, NT, W>), dim3(B * H * (NT / W)), dim3(64 * W), lds, st, qkv, o, lse, S, B, E, \
-                           H, p, site, rng, add, train);                                                            \
+        hipLaunchKernelGGL((attn16_fwd_kernel<HD, NT, W>), dim3(B * H * (NT / W)), dim3(64 * W), lds, st, qkv, o, lse, keepw, S, \
+                           B, E, H, p, site, rng, add, train);                                                          \
     }
     if ((long)B * H < 512 && NT % 2 == 0 && NT > 2) GF_A16_FWD((NT % 2 == 0 ? 2 : NT))
     else GF_A16_FWD(NT)
@@ -467,12 +488,19 @@ static int launch16_fwd(const float* qkv, float* o, float* lse, int S, int B, in
     return 0;
 }
 template <int HD, int NT>
-static int launch16_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv, int S, int B, int E,
-                        int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
+static int launch16_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, const uint32_t* keepw, float* d_qkv,
+                        int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
+                        hipStream_t st) {
     const size_t lds = bwd_lds<HD>(NT);
-    GF_TRY((lds_optin<attn16_bwd_kernel<HD, NT>>(lds, "attention_bwd")));
-    hipLaunchKernelGGL((attn16_bwd_kernel<HD, NT>), dim3(B * H), dim3(64 * NT), lds, st, qkv, o, lse, d_o, d_qkv, S, B, E, H, p,
-                       site, rng, add, train);
+    if (keepw != nullptr && train && p > 0.f) {          // the forward of this pass stored its keep words
+        GF_TRY((lds_optin<attn16_bwd_kernel<HD, NT, true>>(lds, "attention_bwd")));
+        hipLaunchKernelGGL((attn16_bwd_kernel<HD, NT, true>), dim3(B * H), dim3(64 * NT), lds, st, qkv, o, lse, d_o, keepw, d_qkv, S,
+                           B, E, H, p, site, rng, add, train);
+    } else {
+        GF_TRY((lds_optin<attn16_bwd_kernel<HD, NT, false>>(lds, "attention_bwd")));
+        hipLaunchKernelGGL((attn16_bwd_kernel<HD, NT, false>), dim3(B * H), dim3(64 * NT), lds, st, qkv, o, lse, d_o, keepw, d_qkv, S,
+                           B, E, H, p, site, rng, add, train);
+    }
     GF_LAUNCH_CHECK();
     return 0;
 }
@@ -494,25 +522,26 @@ static int launch16_bwd(const float* qkv, const float* o, const float* lse, cons
         default: return FN<HD, 7>(__VA_ARGS__);             \
     }
 
-int launch_attn16_fwd(const float* qkv, float* o, float* lse, int S, int B, int E, int H, float p, uint32_t site,
+int launch_attn16_fwd(const float* qkv, float* o, float* lse, uint32_t* keepw, int S, int B, int E, int H, float p, uint32_t site,
                       const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
     GF_CHECK_ARG(attn16_supported(E, H, S) && S >= 1 && S <= GANFFN_MAX_SEQ, "attn16_fwd: unsupported E=%d H=%d S=%d", E, H, S);
     GF_CHECK_ARG((long)B * H * 28 * 128 < (1l << 32), "attention: B*H too large for the Philox counter");
-    if (E / H == 64) { NT16_SWITCH3(launch16_fwd, 64, qkv, o, lse, S, B, E, H, p, site, rng, add, train, st) }
-    if (E / H == 60) { NT16_SWITCH3(launch16_fwd, 60, qkv, o, lse, S, B, E, H, p, site, rng, add, train, st) }
-    if (E / H == 10) { NT16_SWITCH(launch16_fwd, 10, qkv, o, lse, S, B, E, H, p, site, rng, add, train, st) }
-    NT16_SWITCH(launch16_fwd, 30, qkv, o, lse, S, B, E, H, p, site, rng, add, train, st)
+    if (E / H == 64) { NT16_SWITCH3(launch16_fwd, 64, qkv, o, lse, keepw, S, B, E, H, p, site, rng, add, train, st) }
+    if (E / H == 60) { NT16_SWITCH3(launch16_fwd, 60, qkv, o, lse, keepw, S, B, E, H, p, site, rng, add, train, st) }
+    if (E / H == 10) { NT16_SWITCH(launch16_fwd, 10, qkv, o, lse, keepw, S, B, E, H, p, site, rng, add, train, st) }
+    NT16_SWITCH(launch16_fwd, 30, qkv, o, lse, keepw, S, B, E, H, p, site, rng, add, train, st)
 }
 
-int launch_attn16_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv, int S, int B, int E,
-                      int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
+int launch_attn16_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, const uint32_t* keepw, float* d_qkv,
+                      int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
+                      hipStream_t st) {
     GF_CHECK_ARG(attn16_supported(E, H, S) && S >= 1 && S <= GANFFN_MAX_SEQ, "attn16_bwd: unsupported E=%d H=%d S=%d", E, H, S);
     GF_CHECK_ARG(o && lse, "attention_bwd: head_dim %d needs the forward's output and log-sum-exp", E / H);
     GF_CHECK_ARG((long)B * H * 28 * 128 < (1l << 32), "attention: B*H too large for the Philox counter");
-    if (E / H == 64) { NT16_SWITCH3(launch16_bwd, 64, qkv, o, lse, d_o, d_qkv, S, B, E, H, p, site, rng, add, train, st) }
-    if (E / H == 60) { NT16_SWITCH3(launch16_bwd, 60, qkv, o, lse, d_o, d_qkv, S, B, E, H, p, site, rng, add, train, st) }
-    if (E / H == 10) { NT16_SWITCH(launch16_bwd, 10, qkv, o, lse, d_o, d_qkv, S, B, E, H, p, site, rng, add, train, st) }
-    NT16_SWITCH(launch16_bwd, 30, qkv, o, lse, d_o, d_qkv, S, B, E, H, p, site, rng, add, train, st)
+    if (E / H == 64) { NT16_SWITCH3(launch16_bwd, 64, qkv, o, lse, d_o, keepw, d_qkv, S, B, E, H, p, site, rng, add, train, st) }
+    if (E / H == 60) { NT16_SWITCH3(launch16_bwd, 60, qkv, o, lse, d_o, keepw, d_qkv, S, B, E, H, p, site, rng, add, train, st) }
+    if (E / H == 10) { NT16_SWITCH(launch16_bwd, 10, qkv, o, lse, d_o, keepw, d_qkv, S, B, E, H, p, site, rng, add, train, st) }
+    NT16_SWITCH(launch16_bwd, 30, qkv, o, lse, d_o, keepw, d_qkv, S, B, E, H, p, site, rng, add, train, st)
 }
 
 }  // namespace ganffn

@@ -255,15 +255,21 @@ long gemm_tn_grouped_part_floats();
 // lse [B*H x S]: log-sum-exp of every score row, written by the forward (may be NULL: not kept) and, together with the
 // forward's output o, read by the backward of the small-head kernels (attention16.hip); the head_dim 60/64 kernels
 // (attention.hip) recompute the softmax statistics and ignore both.
-int launch_attention_fwd(const float* qkv, float* o, float* lse, int S, int B, int E, int H, float p, uint32_t site,
+// keep [B*H x ATTN_KEEP_WORDS] (or NULL): the dropout keep bits of the probability matrix, written by a train-mode
+// small-head forward and read back by its backward instead of recomputing the Philox calls (attention16.hip; the
+// head_dim 60/64 kernels ignore it).  Same bits either way.
+constexpr int ATTN_KEEP_WORDS = 28 * 16;
+int launch_attention_fwd(const float* qkv, float* o, float* lse, uint32_t* keep, int S, int B, int E, int H, float p, uint32_t site,
                          const uint64_t* rng, uint64_t add, int train, hipStream_t st);
-int launch_attention_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv, int S, int B,
-                         int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+int launch_attention_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, const uint32_t* keep, float* d_qkv,
+                         int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
+                         hipStream_t st);
 bool attn16_supported(int E, int H, int S);
-int launch_attn16_fwd(const float* qkv, float* o, float* lse, int S, int B, int E, int H, float p, uint32_t site,
+int launch_attn16_fwd(const float* qkv, float* o, float* lse, uint32_t* keepw, int S, int B, int E, int H, float p, uint32_t site,
                       const uint64_t* rng, uint64_t add, int train, hipStream_t st);
-int launch_attn16_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv, int S, int B, int E,
-                      int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st);
+int launch_attn16_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, const uint32_t* keepw, float* d_qkv,
+                      int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
+                      hipStream_t st);
 
 int launch_pe_dropout(const float* x, const float* pe, float* out, int S, int B, int E, float p,
                       const uint64_t* rng, uint64_t add, int train, hipStream_t st);

@@ -18,6 +18,10 @@
 //    ds_read_b32) — no transposed copy is made.
 // k order inside a 16-wide group: lane group g takes k = 16 q + 4 g + j at the j-th MFMA, identically for both operands and
 // for every token (a dialogue's bits do not depend on its batch position).
+// Round 4: KW = 2 — EIGHT waves per workgroup: two waves per 16-token group, each taking one 16-wide half of every 32-wide K
+// tile (q = its half), so a SIMD holds two waves of ONE workgroup and one's LDS reads / waits run under the other's MFMAs
+// without a second output slab (more K chunks buy the same co-residency with more slab traffic and more prologues).  The
+// two halves are added through LDS in fixed order (half 0 + half 1) by the half-0 waves.
 #include "common.h"
 
 namespace ganffn {
@@ -42,13 +46,17 @@ struct N100Args {
                                                // after the prologue, after the K loop, at exit}
 };
 
-template <bool WKMAJOR>
-__global__ __launch_bounds__(256) void gemm_n100_kernel(N100Args a) {
+template <bool WKMAJOR, int KW>
+__global__ __launch_bounds__(256 * KW) void gemm_n100_kernel(N100Args a) {
+    static_assert(KW == 1 || KW == 2, "one or two waves per token group along K");
+    constexpr int NTHR = 256 * KW;
     constexpr int WT = WKMAJOR ? NBK * LDWK : 112 * NBK;          // weight tile floats
     constexpr int STAGE = WT + NBM * NBK;
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 4];          // + a dump slot for the loaders' surplus vectors
     constexpr int DUMP = 2 * STAGE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    static_assert(KW == 1 || 2 * STAGE >= NBM * 116, "the K-half exchange image [64 tokens][116] re-uses the stage buffers");
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int wave = (tid >> 6) & 3, khalf = tid >> 8;             // token group of 16; which 16-wide half of a K tile (KW == 2)
     const int m0 = blockIdx.x * NBM, z = blockIdx.y;
     const int kbeg = z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
     const int nt = (kend - kbeg) / NBK;                           // K, kchunk multiples of 32
@@ -61,12 +69,12 @@ __global__ __launch_bounds__(256) void gemm_n100_kernel(N100Args a) {
     // stored to the dump slot, so no load or LDS store sits under a condition.  Everything is a NAMED scalar / vector: hipcc
     // keeps small arrays that live across the K loop in scratch memory.
 #define GF_N100_AIDX(J)                                                                                             \
-    const int ia##J = tid + 256 * J, rowa##J = ia##J >> 3, sla##J = ia##J & 7;                                      \
+    const int ia##J = min(tid + NTHR * J, NBM * 8 - 1), rowa##J = ia##J >> 3, sla##J = ia##J & 7;                  \
     const uint32_t offa##J = (uint32_t)min(m0 + rowa##J, a.T - 1) * (uint32_t)a.lda + (uint32_t)(sla##J << 2);      \
     const int ldsa##J = WT + sw32(rowa##J, sla##J);
     GF_N100_AIDX(0) GF_N100_AIDX(1)
 #define GF_N100_WIDX(J)                                                                                             \
-    const int iw##J = tid + 256 * J;                                                                                \
+    const int iw##J = tid + NTHR * J;                                                                               \
     const bool okw##J = iw##J < (WKMAJOR ? NBK * 25 : 112 * 8);                                                     \
     const int icw##J = min(iw##J, (WKMAJOR ? NBK * 25 : 112 * 8) - 1);                                              \
     const int rw##J = WKMAJOR ? icw##J / 25 : icw##J >> 3;                                                          \
@@ -84,18 +92,24 @@ __global__ __launch_bounds__(256) void gemm_n100_kernel(N100Args a) {
         const int k0 = kbeg + min((TT), nt - 1) * NBK; /* (a prefetch beyond the last tile re-reads it: never consumed) */ \
         const float* Ak = a.A + k0;                                                                                 \
         const float* Wk = WKMAJOR ? a.W + (size_t)k0 * a.ldw : a.W + k0;                                            \
-        qa##R##0 = *reinterpret_cast<const float4*>(Ak + offa0); qa##R##1 = *reinterpret_cast<const float4*>(Ak + offa1); \
+        qa##R##0 = *reinterpret_cast<const float4*>(Ak + offa0);                                                    \
         qw##R##0 = *reinterpret_cast<const float4*>(Wk + offw0); qw##R##1 = *reinterpret_cast<const float4*>(Wk + offw1); \
-        qw##R##2 = *reinterpret_cast<const float4*>(Wk + offw2); qw##R##3 = *reinterpret_cast<const float4*>(Wk + offw3); \
+        if constexpr (KW == 1) {        /* 256 threads: 2 activation and 4 weight vectors each; 512 threads: 1 and 2 */ \
+            qa##R##1 = *reinterpret_cast<const float4*>(Ak + offa1);                                                \
+            qw##R##2 = *reinterpret_cast<const float4*>(Wk + offw2); qw##R##3 = *reinterpret_cast<const float4*>(Wk + offw3); \
+        }                                                                                                           \
     }
 #define GF_N100_SSTORE(R, BUF)                                                                                      \
     {                                                                                                               \
         float* const sdst = smem + (BUF) * STAGE;                                                                   \
-        *reinterpret_cast<float4*>(sdst + ldsa0) = qa##R##0; *reinterpret_cast<float4*>(sdst + ldsa1) = qa##R##1;   \
+        *reinterpret_cast<float4*>(sdst + ldsa0) = qa##R##0;                                                        \
         *reinterpret_cast<float4*>(smem + ((BUF) ? ldsw1_0 : ldsw0_0)) = qw##R##0;                                  \
         *reinterpret_cast<float4*>(smem + ((BUF) ? ldsw1_1 : ldsw0_1)) = qw##R##1;                                  \
-        *reinterpret_cast<float4*>(smem + ((BUF) ? ldsw1_2 : ldsw0_2)) = qw##R##2;                                  \
-        *reinterpret_cast<float4*>(smem + ((BUF) ? ldsw1_3 : ldsw0_3)) = qw##R##3;                                  \
+        if constexpr (KW == 1) {                                                                                    \
+            *reinterpret_cast<float4*>(sdst + ldsa1) = qa##R##1;                                                    \
+            *reinterpret_cast<float4*>(smem + ((BUF) ? ldsw1_2 : ldsw0_2)) = qw##R##2;                              \
+            *reinterpret_cast<float4*>(smem + ((BUF) ? ldsw1_3 : ldsw0_3)) = qw##R##3;                              \
+        }                                                                                                           \
     }
 
     floatx4 acc[NT7];
@@ -104,38 +118,44 @@ __global__ __launch_bounds__(256) void gemm_n100_kernel(N100Args a) {
 
     if (WKMAJOR) {
         // columns 100 .. 111 of the K-major weight tile are never written by the loader: zero them once (both stages)
-        for (int i = tid; i < 2 * NBK * 12; i += 256) {
+        for (int i = tid; i < 2 * NBK * 12; i += NTHR) {
             const int st = i / (NBK * 12), r = (i / 12) % NBK, cc = i % 12;
             smem[st * STAGE + r * LDWK + NE + cc] = 0.f;
         }
     }
-    // one K tile from LDS stage BUF: all fragment reads, then its 56 MFMAs
+    // one K tile from LDS stage BUF: all fragment reads, then its 56 MFMAs (KW == 2: this wave's 16-wide half, 28 MFMAs)
+    constexpr int NQ = 2 / KW;
     auto compute = [&](const int buf) __attribute__((always_inline)) {
         const float* s = smem + buf * STAGE;
         const float* sa = s + WT;
-        float4 bx[2];
+        float4 bx[NQ];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) bx[q] = *reinterpret_cast<const float4*>(sa + sw32(wave * 16 + c, 4 * q + g));
-        float wv[2][NT7][4];
+        for (int qi = 0; qi < NQ; ++qi) {
+            const int q = KW == 2 ? khalf : qi;
+            bx[qi] = *reinterpret_cast<const float4*>(sa + sw32(wave * 16 + c, 4 * q + g));
+        }
+        float wv[NQ][NT7][4];
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int qi = 0; qi < NQ; ++qi) {
+            const int q = KW == 2 ? khalf : qi;
 #pragma unroll
             for (int m = 0; m < NT7; ++m) {
                 if (WKMAJOR) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) wv[q][m][j] = s[(16 * q + 4 * g + j) * LDWK + 16 * m + c];
+                    for (int j = 0; j < 4; ++j) wv[qi][m][j] = s[(16 * q + 4 * g + j) * LDWK + 16 * m + c];
                 } else {
                     const float4 v = *reinterpret_cast<const float4*>(s + sw32(16 * m + c, 4 * q + g));
-                    wv[q][m][0] = v.x; wv[q][m][1] = v.y; wv[q][m][2] = v.z; wv[q][m][3] = v.w;
+                    wv[qi][m][0] = v.x; wv[qi][m][1] = v.y; wv[qi][m][2] = v.z; wv[qi][m][3] = v.w;
                 }
             }
+        }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float bq[4] = {bx[q].x, bx[q].y, bx[q].z, bx[q].w};
+        for (int qi = 0; qi < NQ; ++qi) {
+            const float bq[4] = {bx[qi].x, bx[qi].y, bx[qi].z, bx[qi].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int m = 0; m < NT7; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][m][j], bq[j], acc[m], 0, 0, 0);
+                for (int m = 0; m < NT7; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[qi][m][j], bq[j], acc[m], 0, 0, 0);
         }
     };
     GF_N100_GLOAD(A, 0)
@@ -169,6 +189,22 @@ __global__ __launch_bounds__(256) void gemm_n100_kernel(N100Args a) {
 
     GF_LAB_ONLY(if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();)
     // epilogue: lane (c, g) holds token m0 + 16 wave + c, features 16 m + 4 g .. + 3
+    if constexpr (KW == 2) {
+        // the K halves meet in LDS (the stage buffers are dead: the loop ended on a barrier): half 1 writes its tile image
+        // [64 tokens][116], half 0 adds it to its own accumulators — always (half 0) + (half 1)
+        float* xrow = smem + (wave * 16 + c) * 116 + 4 * g;
+        if (khalf == 1) {
+#pragma unroll
+            for (int m = 0; m < NT7; ++m) *reinterpret_cast<float4*>(xrow + 16 * m) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+        }
+        __syncthreads();
+        if (khalf == 1) return;
+#pragma unroll
+        for (int m = 0; m < NT7; ++m) {
+            const float4 o = *reinterpret_cast<const float4*>(xrow + 16 * m);
+            acc[m][0] += o.x; acc[m][1] += o.y; acc[m][2] += o.z; acc[m][3] += o.w;
+        }
+    }
     const int tok = m0 + wave * 16 + c;
     if (tok < a.T) {
         float* crow = a.C + (size_t)z * a.slab_stride + (size_t)tok * NE;
@@ -191,19 +227,22 @@ __global__ __launch_bounds__(256) void gemm_n100_kernel(N100Args a) {
 }  // namespace
 
 int g_n100_force_splits = 0;      // lab knob (ganffn_debug_set_ffn_mode bits 8..15): 0 = choose
+int g_n100_force_kw = 0;          // lab knob (bits 20..21): 0 = choose, 1 = four waves per workgroup, 2 = eight (two per K tile)
 GF_LAB_ONLY(unsigned long long* g_n100_stamps = nullptr;)   // lab builds only: device buffer for in-kernel time stamps
 
 bool n100_supported(int N, int K) { return N == NE && K >= 256 && (K % NBK) == 0; }
 
-// K chunks (= output slabs, <= max_splits).  Measured on MI355X (tools/lab/n100_lab.py, n100_stamps.py; K = 2048):
-//  * the K loop runs at 69 % MFMA utilisation with one workgroup per CU, 85 % with two, 94 % with three (in-kernel stamps),
-//    but every co-resident workgroup adds its prologue, and every slab is read again by the consumer;
-//  * rows-of-K weights: T = 3008: 5 / 10 / 16 chunks 18.7 / 18.9 / 19.0 us (flat: take the fewest slabs); T = 6016: 5 / 8 / 16
-//    chunks 30.0 / 29.8 / 32.9 us;
-//  * K-major weights (58 LDS reads per tile instead of 16): T = 3008: 5 / 10 / 16 chunks 22.7 / 20.1 / 18.3 us — co-residency
-//    pays; T = 6016: 5 / 8 / 16 chunks 32.3 / 30.6 / 33.2 us.
-// Rule: rows-of-K: the launch's waves (4 per 64 tokens and chunk) fill the 1024 SIMDs in whole rounds, a round costs the
-// chunk's K tiles; K-major: the same with rounds of 3 workgroups per CU (768 workgroups); plus the slab traffic.
+// K chunks (= output slabs, <= max_splits) and waves per workgroup.  Measured on MI355X (tools/lab/n100_lab.py, K = 2048,
+// gpurun_out/r4_n100_lab.txt; round 3's 4-wave numbers in brackets):
+//  * 8 waves (two per 16-token group, one 16-wide half of every K tile each): rows-of-K weights T = 3008: 4 / 5 / 8 / 10 / 16
+//    chunks 20.8 / 18.1 / 20.1 / 19.2 / 22.9 us [22.0 / 19.1 / 20.4 / 19.0 / 19.0]; T = 6016: 4 / 5 / 6 / 8 chunks
+//    34.0 / 29.2 / 41.2 / 36.1 us [35.4 / 30.5 / 35.1 / 29.9];
+//  * K-major weights (58 LDS reads per tile instead of 16): T = 3008: 5 / 8 / 16 chunks 19.3 / 20.3 / 18.1 us
+//    [22.9 / 21.6 / 18.5]; T = 6016: 5 / 6 / 8 chunks 29.9 / 34.0 / 29.1 us [32.4 / 35.0 / 29.9] — with the second wave per
+//    SIMD inside the workgroup the K-major layout no longer needs the extra chunks (and their slabs) for co-residency.
+// Rule (8 waves): a CU runs its workgroups' MFMA work back to back, so the launch costs ceil(workgroups / 256 CUs) x the
+// chunk's K tiles, plus the slab traffic: every slab is written here and read again by the LayerNorm-side consumer
+// (~0.8 tile-times per slab at T = 3008; the consumer at T = 6016 with 8 slabs is bandwidth-bound on them: 19 MB).
 int n100_splits(int T, int K, int max_splits, int w_kmajor) {
     if (g_n100_force_splits > 0) return g_n100_force_splits < max_splits ? g_n100_force_splits : max_splits;
     const int tiles_m = (T + NBM - 1) / NBM, ksteps = K / NBK;
@@ -213,13 +252,19 @@ int n100_splits(int T, int K, int max_splits, int w_kmajor) {
         const int per = (ksteps + s - 1) / s;
         if ((s - 1) * per >= ksteps) continue;                       // an empty last chunk
         const long wgs = (long)tiles_m * s;
-        const long rounds = w_kmajor ? (wgs + 767) / 768 : (wgs * 4 + 1023) / 1024;
-        // every slab is written here and read again by the LayerNorm-side consumer: 2 x T x 400 bytes of HBM traffic,
-        // ~0.8 tile-times per slab at T = 3008 (the consumer at T = 6016 with 8 slabs is bandwidth-bound on them: 19 MB)
+        const long rounds = (wgs + 255) / 256;
         const double cost = (double)rounds * per + 0.8 * ((double)T / 3008.0) * s;
         if (cost < best_cost) { best_cost = cost; best = s; }
     }
+    (void)w_kmajor;
     return best;
+}
+
+// waves per 16-token group along K: two (8-wave workgroups) — faster at every chunk count the rule above picks; the 4-wave
+// form stays behind the lab knob for A/B
+static int n100_kw(int T, int splits) {
+    (void)T; (void)splits;
+    return 2;
 }
 
 // C slabs = A[T x K] . W^T (w_kmajor == 0: W [100 x K]) or A . W (w_kmajor == 1: W [K x 100]); *splits_io: in = cap, out = slabs written
@@ -234,9 +279,15 @@ int launch_gemm_n100(const float* A, int lda, const float* W, int ldw, int w_kma
     s = (ksteps + per - 1) / per;
     *splits_io = s;
     N100Args a{A, lda, W, ldw, bias, C, slab_stride, T, K, per * NBK GF_LAB_ONLY(, g_n100_stamps)};
-    const dim3 grid((T + NBM - 1) / NBM, s), blk(256);
-    if (w_kmajor) hipLaunchKernelGGL((gemm_n100_kernel<true>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((gemm_n100_kernel<false>), grid, blk, 0, st, a);
+    const dim3 grid((T + NBM - 1) / NBM, s);
+    const int kw = g_n100_force_kw ? g_n100_force_kw : n100_kw(T, s);
+    if (kw == 2) {
+        if (w_kmajor) hipLaunchKernelGGL((gemm_n100_kernel<true, 2>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((gemm_n100_kernel<false, 2>), grid, dim3(512), 0, st, a);
+    } else {
+        if (w_kmajor) hipLaunchKernelGGL((gemm_n100_kernel<true, 1>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_n100_kernel<false, 1>), grid, dim3(256), 0, st, a);
+    }
     GF_LAUNCH_CHECK();
     return 0;
 }

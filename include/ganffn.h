@@ -313,6 +313,16 @@ int ganffn_attention_fwd(const float* qkv, float* o, float* lse, int S, int B, i
 int ganffn_attention_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv,
                          int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng,
                          uint64_t rng_offset_add, void* stream);
+/* The same pair with the attention-dropout keep bits handed from the forward to the backward (what the encoder stack does
+ * inside its saved-for-backward block): keep = ganffn_attention_keep_words(B, H) uint32, written by a forward with p > 0
+ * and read by the backward INSTEAD of re-evaluating the Philox calls (head_dim <= 32; larger heads ignore it).  The
+ * bits are the same, so both pairs give identical results; keep = NULL is exactly the pair above. */
+int64_t ganffn_attention_keep_words(int B, int H);
+int ganffn_attention_fwd_keep(const float* qkv, float* o, float* lse, uint32_t* keep, int S, int B, int E, int H,
+                              float p, uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, void* stream);
+int ganffn_attention_bwd_keep(const float* qkv, const float* o, const float* lse, const float* d_o,
+                              const uint32_t* keep, float* d_qkv, int S, int B, int E, int H, float p, uint32_t site,
+                              const uint64_t* rng, uint64_t rng_offset_add, void* stream);
 /* z = x + drop(y); xhat = (z-mean)*rstd; out = xhat*w + b   (norm1/norm2 of the encoder layer) */
 int ganffn_add_dropout_layernorm_fwd(const float* x, const float* y, const float* w, const float* b,
                                      float* out, float* xhat, float* rstd, int T, int E, float eps,
@@ -346,7 +356,8 @@ int ganffn_gemm_n100(const float* A, const float* W, int w_kmajor, const float* 
  *   bit 6: run the head of a d_model-100 encoder stack (positional encoding + dropout, layer 0's in-proj) as two launches
  *          instead of one (csrc/rowchain.hip);
  *   bits 8..15: forced K-chunk count of csrc/gemm_n100.hip (0 = choose; clamped to the caller's slab capacity);
- *   bits 16..19: forced token-chunk count of csrc/gemm_tn100.hip (0 = choose; clamped to 8 and to the workspace).
+ *   bits 16..19: forced token-chunk count of csrc/gemm_tn100.hip (0 = choose; clamped to 8 and to the workspace);
+ *   bits 20..21: csrc/gemm_n100.hip with 4 (value 1) or 8 (value 2) waves per workgroup (0 = choose).
  * Every combination is parity-tested; results agree to rounding. */
 int ganffn_debug_set_ffn_mode(int bits);
 

@@ -197,6 +197,21 @@ def test_attention_fwd_bwd(lib, S, B, E, H, p):
     lib.call("ganffn_attention_bwd", ptr(qd), ptr(od), ptr(lse), ptr(dod), ptr(dq), S, B, E, H, C.c_float(p),
              C.c_uint32(site), ptr(rng), C.c_uint64(add), stream())
     assert rel_err(dq, q64.grad) < 5e-5
+    # the pair that hands the dropout keep bits from the forward to the backward (what the encoder stack runs): the
+    # same bits, so output, log-sum-exp and gradient are IDENTICAL to the Philox-recomputing pair above
+    nk = int(lib.load().ganffn_attention_keep_words(B, H))
+    keep = torch.zeros(nk, dtype=torch.int32, device="cuda")
+    od2, lse2 = torch.full_like(od, float("nan")), torch.full_like(lse, float("nan"))
+    lib.call("ganffn_attention_fwd_keep", ptr(qd), ptr(od2), ptr(lse2), ptr(keep), S, B, E, H, C.c_float(p), C.c_uint32(site),
+             ptr(rng), C.c_uint64(add), stream())
+    dq2 = torch.full_like(dq, float("nan"))
+    lib.call("ganffn_attention_bwd_keep", ptr(qd), ptr(od2), ptr(lse2), ptr(dod), ptr(keep), ptr(dq2), S, B, E, H, C.c_float(p),
+             C.c_uint32(site), ptr(rng), C.c_uint64(add), stream())
+    assert torch.equal(od2, od) and torch.equal(dq2, dq)
+    if E // H <= 32:
+        assert torch.equal(lse2, lse)
+        if p > 0:
+            assert int((keep != 0).sum()) > 0        # the forward did store its keep words
 
 
 @pytest.mark.parametrize("T,E", [(3008, 100), (3008, 512), (14, 100), (5, 512), (331, 100)])
@@ -306,10 +321,20 @@ def test_logsoftmax_nll_matches_reference_fixture(lib):
 
 @pytest.mark.parametrize("T,K,kmajor,cap", [(3008, 2048, 0, 16), (6016, 2048, 1, 16), (6016, 2048, 0, 8), (3008, 2048, 1, 5),
                                             (21, 256, 0, 16), (70, 2048, 1, 1), (1, 320, 1, 16), (2112, 2048, 0, 16)])
-def test_gemm_n100_slabs_sum_to_the_product(lib, T, K, kmajor, cap):
+@pytest.mark.parametrize("kw", [0, 1, 2])
+def test_gemm_n100_slabs_sum_to_the_product(lib, T, K, kmajor, cap, kw):
     """[T x K] x [K x 100] on the 112-wide 16x16x4 kernel (csrc/gemm_n100.hip): the sum of its K-chunk slabs against fp64
     torch, both weight layouts (rows of K = linear2's W2; K-major = linear1's W1 in the dgrad), bias on chunk 0; ragged T,
-    a single chunk, chunk counts that do not divide K / 32"""
+    a single chunk, chunk counts that do not divide K / 32; kw: the launch heuristic's choice (0), four waves per
+    workgroup (1), eight = two waves per K tile whose halves are added through LDS in fixed order (2)"""
+    lib.load().ganffn_debug_set_ffn_mode(kw << 20)
+    try:
+        _n100_case(lib, T, K, kmajor, cap)
+    finally:
+        lib.load().ganffn_debug_set_ffn_mode(0)
+
+
+def _n100_case(lib, T, K, kmajor, cap):
     g = torch.Generator().manual_seed(T * 7 + K + kmajor)
     A = torch.randn(T, K, generator=g)
     W = (torch.randn(K, 100, generator=g) if kmajor else torch.randn(100, K, generator=g)) / (K ** 0.5)

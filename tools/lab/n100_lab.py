@@ -33,11 +33,12 @@ for T in (3008, 6016):
     t_nt = timeit(lambda: _lib.call("ganffn_gemm_nt", P(A), P(Wn), P(b), P(y), T, 100, K, st))
     t_nn = timeit(lambda: _lib.call("ganffn_gemm_nn", P(A), P(Wk), P(y), T, 100, K, st))
     print("T=%d generic (unsplit) NT %.1f us, NN %.1f us" % (T, t_nt, t_nn), flush=True)
-    for s in (0, 4, 5, 8, 10, 11, 16):
-        lib.ganffn_debug_set_ffn_mode(s << 8)
-        r = []
-        for km, W in ((0, Wn), (1, Wk)):
-            r.append(timeit(lambda: _lib.call("ganffn_gemm_n100", P(A), P(W), km, P(b), P(slabs), C.c_int64(T * 100), T, K, 16, C.byref(n), st)))
-        print("T=%d forced chunks %2d -> %2d slabs: rows-of-K %.1f us, K-major %.1f us  (%.1f / %.1f TFLOP/s useful)" % (
-            T, s, n.value, r[0], r[1], 2e-6 * T * 100 * K / r[0], 2e-6 * T * 100 * K / r[1]), flush=True)
+    for s in (0, 3, 4, 5, 6, 8, 10, 16):
+        for kw in (1, 2):                     # waves per 16-token group along K (bits 20..21): 4- or 8-wave workgroups
+            lib.ganffn_debug_set_ffn_mode((s << 8) | (kw << 20))
+            r = []
+            for km, W in ((0, Wn), (1, Wk)):
+                r.append(timeit(lambda: _lib.call("ganffn_gemm_n100", P(A), P(W), km, P(b), P(slabs), C.c_int64(T * 100), T, K, 16, C.byref(n), st)))
+            print("T=%d forced chunks %2d -> %2d slabs, %d waves: rows-of-K %.1f us, K-major %.1f us  (%.1f / %.1f TFLOP/s useful)" % (
+                T, s, n.value, 4 * kw, r[0], r[1], 2e-6 * T * 100 * K / r[0], 2e-6 * T * 100 * K / r[1]), flush=True)
 lib.ganffn_debug_set_ffn_mode(0)
