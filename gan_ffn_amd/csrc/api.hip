@@ -123,7 +123,7 @@ int g_dhead_off = 0;
 // bit 6: positional encoding + dropout and layer 0's in-proj as two launches instead of rowchain.hip's one
 int g_pe_off = 0;
 extern int g_n100_force_splits, g_n100_force_kw;
-extern int g_tn100_off, g_tn100_force_splits;
+extern int g_tn100_off, g_tn100_force_splits, g_tn100_in_kernel_sum;
 GF_LAB_ONLY(extern unsigned long long* g_n100_stamps; extern unsigned long long* g_wres_stamps;)
 constexpr int MAX_SPLITS = 16;  // partial-output slabs: fused FFN (16 F splits) / split-K GEMMs (<= 8)
 
@@ -671,6 +671,7 @@ extern "C" int ganffn_debug_set_ffn_mode(int bits) {
     g_dhead_off = (bits & 32) ? 1 : 0;
     g_pe_off = (bits & 64) ? 1 : 0;
     g_tn100_off = (bits & 8) ? 1 : 0;
+    g_tn100_in_kernel_sum = (bits & 16) ? 1 : 0;
     g_tn100_force_splits = (bits >> 16) & 0xF;      // lab: force the token-chunk count of the d_model-100 grouped wgrad (0 = choose)
     g_n100_force_splits = (bits >> 8) & 0xFF;       // lab: force the K-chunk count of gemm_n100 (0 = choose)
     g_n100_force_kw = (bits >> 20) & 0x3;           // lab: force 4 (1) or 8 (2) waves per gemm_n100 workgroup (0 = choose; 3 -> 2)

@@ -298,19 +298,18 @@ __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __rest
     float* Ks = smem;
     float* Ls = Ks + MAT;        // [ROWS] log-sum-exp per query (+big for padded rows)
     float* Ds = Ls + ROWS;       // [ROWS] D_i = sum_d dO_id O_id
-    float* Qs = Ds + ROWS;       // scaled q
+    uint32_t* Wk = reinterpret_cast<uint32_t*>(Ds + ROWS);    // [NT][64] keep words (saved-mask form)
+    float* Qs = Ds + ROWS + 64 * NT;       // scaled q
     float* Vs = Qs + MAT;
     float* Os = Vs + MAT;        // dO
     float* SS = Qs;              // [ROWS][LDS_S] dS, over q / V / dO
     const int ld3 = 3 * E;
     const float scale = rsqrtf((float)HD);
     const DropCtx dc = make_drop(rng, add, site, p, train);
-    uint32_t wdt[SAVED ? 1 : NT][4];     // Philox words of this lane's (key, 4-query group) pairs     (recomputed masks)
-    uint32_t kw[SAVED ? NT : 1];         // keep words [4t + g][c]; this wave's nibble is bits 4w .. 4w+3    (saved masks)
-    if (!SAVED) {
+    uint32_t wdt[NT][4];                 // Philox words of this lane's (key, 4-query group) pairs (saved masks: all-ones / zero)
+    uint32_t kw1 = 0;                    // saved masks: keep word [4w + g][c] — wave w fetches word row w for the whole workgroup
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wdt[t][0] = wdt[t][1] = wdt[t][2] = wdt[t][3] = 0xFFFFFFFFu;
-    }
+    for (int t = 0; t < NT; ++t) wdt[t][0] = wdt[t][1] = wdt[t][2] = wdt[t][3] = 0xFFFFFFFFu;
     {
         const HeadSrc16 m4[4] = {{Qs, qkv + head * HD, ld3, scale}, {Ks, qkv + E + head * HD, ld3, 1.f},
                                  {Vs, qkv + 2 * E + head * HD, ld3, 1.f}, {Os, d_o + head * HD, E, 1.f}};
@@ -326,12 +325,15 @@ __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __rest
             dv[kk] = d_o[rowo + d];
         }
         const float lv = lse[(size_t)bh * S + min(qi, S - 1)];
-        if (SAVED) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) kw[t] = keepw[((size_t)bh * 28 + 4 * t + g) * 16 + c];
-        }
         HeadStage<HD, NT, 4> stg;
         stg.load(m4, S, B, b, tid);
+        if (SAVED) {
+            // every wave needs a nibble of ALL 4 NT keep words of its (c, g) column: each wave fetches one word row (one
+            // coalesced dword per lane) and the rows meet in LDS (all six words per lane straight from memory measured
+            // slower than the Philox calls at 640 problems: 25.9 against 23.9 us)
+            kw1 = keepw[((size_t)bh * 28 + 4 * w + g) * 16 + c];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (!SAVED && dc.on) {
             // the keep words of this lane's (key, 4-query group) pairs: exactly one Philox call per accumulator tile, and
             // data-independent — evaluated while the global loads are in flight
@@ -340,6 +342,7 @@ __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __rest
                 philox4((uint32_t)(bh * 28 + 4 * t + g) * 128u + (uint32_t)(16 * w + c), dc.site, dc.o0, dc.o1, dc.k0, dc.k1, wdt[t]);
         }
         stg.store(m4, S, tid);
+        if (SAVED) Wk[tid] = kw1;
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) part += (4 * kk + g < HD && qi < S) ? ov[kk] * dv[kk] : 0.f;
         part += __shfl_xor(part, 16, 64);
@@ -350,6 +353,16 @@ __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __rest
         }
     }
     __syncthreads();
+    if (SAVED) {
+        // the same registers the Philox form fills: all-ones (kept) or zero (dropped: 0 < thr) — the rest of the kernel is
+        // one code path (a separate bit-test path compiled to 82 VGPRs and ran SLOWER than the Philox calls at 640 problems)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const uint32_t nib = Wk[64 * t + lane] >> (4 * w);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wdt[t][r] = ((nib >> r) & 1u) ? 0xFFFFFFFFu : 0u;
+        }
+    }
 
     const int kj = 16 * w + c;                     // this lane's key
     floatx4 ps[NT], dp[NT];
@@ -371,7 +384,7 @@ __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float pv = keyok ? __expf(ps[t][r]) : 0.f;             // probability (pre-dropout)
-            const bool keep = SAVED ? (((kw[t] >> (4 * w + r)) & 1u) != 0u) : (!dc.on || wdt[t][r] >= dc.thr);
+            const bool keep = !dc.on || wdt[t][r] >= dc.thr;
             const float dpk = keep ? dp[t][r] * dc.scale : 0.f;          // dP = keep * scale * dP~
             ps[t][r] = keep ? pv * dc.scale : 0.f;                       // P~
             dp[t][r] = pv * (dpk - dd[r]);                               // dS
@@ -460,18 +473,25 @@ bool attn16_supported(int E, int H, int S) {
     return (hd == 60 || hd == 64) && S <= 48;
 }
 
+// Hand the dropout keep bits from the forward to the backward (instead of re-evaluating the Philox calls there) only while
+// the launch leaves most CUs with ONE backward workgroup: measured (tools/lab/attn_ab.py, S = 94, head_dim 10, p = 0.1)
+// 16.7 -> 15.2 us at 320 problems, but 24.0 -> 25.1 us at 640 — there the Philox calls run in the shadow of the staging
+// loads, while unpacking the saved words sits behind the barrier on the critical path of co-resident workgroups.
+static bool attn16_use_keep(int B, int H) { return (long)B * H <= 384; }
+
 template <int HD>
 static size_t fwd_lds(int nt) { return (size_t)3 * (16 * nt * A16<HD>::LD + A16<HD>::TAIL) * sizeof(float); }
 template <int HD>
 static size_t bwd_lds(int nt) {
     const size_t mat = (size_t)16 * nt * A16<HD>::LD + A16<HD>::TAIL, img = (size_t)16 * nt * (16 * nt + 4);
-    return (mat + 2 * 16 * nt + (img > 3 * mat ? img : 3 * mat)) * sizeof(float);
+    return (mat + 2 * 16 * nt + 64 * nt + (img > 3 * mat ? img : 3 * mat)) * sizeof(float);
 }
 
 template <int HD, int NT>
 static int launch16_fwd(const float* qkv, float* o, float* lse, uint32_t* keepw, int S, int B, int E, int H, float p, uint32_t site,
                         const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
     const size_t lds = fwd_lds<HD>(NT);
+    if (!attn16_use_keep(B, H)) keepw = nullptr;
     // query tiles per workgroup: measured at hd = 10, S = 94 (tools/lab/attn_wpb.py, lab build): 320 problems 11.1 us as
     // whole workgroups, 10.1 / 9.9 / 11.5 us cut in 2 / 3 / 6; 640 problems 15.0 us whole, 16.4 / 17.9 / 21.5 us cut —
     // the cut pays while the problems do not fill the chip, then the repeated K / V staging costs more than the balance gains
@@ -492,7 +512,7 @@ static int launch16_bwd(const float* qkv, const float* o, const float* lse, cons
                         int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
                         hipStream_t st) {
     const size_t lds = bwd_lds<HD>(NT);
-    if (keepw != nullptr && train && p > 0.f) {          // the forward of this pass stored its keep words
+    if (keepw != nullptr && train && p > 0.f && attn16_use_keep(B, H)) {          // the forward of this pass stored its keep words
         GF_TRY((lds_optin<attn16_bwd_kernel<HD, NT, true>>(lds, "attention_bwd")));
         hipLaunchKernelGGL((attn16_bwd_kernel<HD, NT, true>), dim3(B * H), dim3(64 * NT), lds, st, qkv, o, lse, d_o, keepw, d_qkv, S,
                            B, E, H, p, site, rng, add, train);

@@ -12,7 +12,12 @@
 //  * the token range is cut into 2..8 chunks so that the launch has several times 768 workgroups (3 resident per CU: the
 //    K loop then runs at > 90 % MFMA utilisation, gemm_n100.hip) and the CUs finish within one short workgroup of each
 //    other; chunk z writes its partial tile to slab z and one ordered reduce launch adds the slabs to the gradient —
-//    no atomics, bit-reproducible;
+//    no atomics, bit-reproducible.  (Round 4 built the alternative — the LAST workgroup of a tile to arrive, decided by an
+//    integer ticket, adds the slabs in chunk order inside tn100_kernel: same bits, tests/test_hip_ops.py — and measured it
+//    SLOWER: 731 against 490 us at T = 6016, 535 against 264 us at T = 3008 (gpurun_out/r4_tn100_lab.txt).  The
+//    device-scope release / acquire fences it needs — a partial slab may sit in another XCD's L2 — write back and invalidate
+//    the whole L2 once per workgroup, 1704 times per launch; the 21 us reduce launch is the cheaper way to cross the XCDs.
+//    It stays behind ganffn_debug_set_ffn_mode bit 4.)
 //  * bias gradients (column sums of dY over the tokens) are accumulated from the operand registers the MFMAs read anyway;
 //  * workgroup ids are remapped so that one XCD (one L2) gets a contiguous range of the (problem, chunk, tile) list: the
 //    tiles of a problem share its 100-wide operand panel ([T x 100], 2.4 MB at T = 6016) through that L2, the wide operand
@@ -38,11 +43,13 @@ struct W100Problem {
     int ntiles, block0;                        // 64-wide tiles over Nn; first workgroup of this problem
     int M, N;                                  // the gradient's shape (partial-slab layout: [M x N] dense, then [M] column sums)
     long part_off;
+    int ctr0;                                  // first arrival counter of this problem (one per 64-wide tile)
 };
 struct W100Group {
     W100Problem p[WMAXP];
     int n, splits;
     float* part; long part_stride;
+    int* counters;                             // per (problem, tile) arrival tickets, zero at launch; null: separate reduce launch
 };
 
 __global__ __launch_bounds__(256) void tn100_kernel(W100Group grp) {
@@ -226,6 +233,68 @@ __global__ __launch_bounds__(256) void tn100_kernel(W100Group grp) {
             }
         }
     }
+    if (slab == nullptr || grp.counters == nullptr) return;
+
+    // ---------------- the last chunk of this tile to arrive adds the tile's slabs to the gradient, in chunk order ----------------
+    // release: this workgroup's slab stores are visible device-wide before its ticket is; acquire on the other side.  The
+    // ticket decides only WHO adds — every slab is read back from memory and summed z = 0, 1, ... exactly as
+    // tn100_reduce_kernel does, so the result does not depend on the arrival order (and equals round 3's bits).
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&grp.counters[q.ctr0 + tile], 1) == grp.splits - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const float* const part = grp.part + q.part_off;
+    const int ns = grp.splits;
+    if (q.side == 0) {
+#pragma unroll
+        for (int m = 0; m < WT7; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mm = 16 * m + 4 * g + r;
+                if (mm < WE && nok) {
+                    const size_t e = (size_t)mm * q.N + n;
+                    float sacc = part[e];
+                    for (int zz = 1; zz < ns; ++zz) sacc += part[(size_t)zz * grp.part_stride + e];
+                    q.C[(size_t)mm * q.ldc + n] += sacc;
+                }
+            }
+    } else if (nok) {
+#pragma unroll
+        for (int m = 0; m < WT7; ++m) {
+            const int mm = 16 * m + 4 * g;
+            if (mm < WE) {
+                const size_t e = (size_t)n * q.N + mm;
+                float4 sacc = *reinterpret_cast<const float4*>(part + e);
+                for (int zz = 1; zz < ns; ++zz) {
+                    const float4 v = *reinterpret_cast<const float4*>(part + (size_t)zz * grp.part_stride + e);
+                    sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
+                }
+                float* dst = q.C + (size_t)n * q.ldc + mm;
+                const float4 o = *reinterpret_cast<const float4*>(dst);
+                *reinterpret_cast<float4*>(dst) = make_float4(o.x + sacc.x, o.y + sacc.y, o.z + sacc.z, o.w + sacc.w);
+            }
+        }
+    }
+    const size_t nC = (size_t)q.M * q.N;
+    if (cs_v && g == 0 && nok) {
+        float sacc = part[nC + n];
+        for (int zz = 1; zz < ns; ++zz) sacc += part[(size_t)zz * grp.part_stride + nC + n];
+        q.colsum[n] += sacc;
+    }
+    if (cs_u && g == 0) {
+#pragma unroll
+        for (int m = 0; m < WT7; ++m) {
+            const int mm = 16 * m + c;
+            if (mm < WE) {
+                float sacc = part[nC + mm];
+                for (int zz = 1; zz < ns; ++zz) sacc += part[(size_t)zz * grp.part_stride + nC + mm];
+                q.colsum[mm] += sacc;
+            }
+        }
+    }
 }
 
 // C_i += sum_z part[z][i], colsum_i += sum_z part[z][M N + i], slabs in chunk order; blockIdx.y = problem
@@ -258,6 +327,8 @@ __global__ __launch_bounds__(256) void tn100_reduce_kernel(W100Group grp) {
 }  // namespace
 
 int g_tn100_force_splits = 0;     // lab knob (ganffn_debug_set_ffn_mode bits 16..19): 0 = choose
+int g_tn100_in_kernel_sum = 0;    // lab knob (bit 4): add the partial slabs in the last-arriving workgroup of a tile (measured slower)
+constexpr long TN100_COUNTERS = 4096;      // ints reserved at the end of the partial-slab workspace for the arrival tickets
 
 // every problem has a 100-wide dimension, 16-byte aligned dense operands
 bool tn100_supported(const TnDesc* d, int n) {
@@ -290,6 +361,11 @@ int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* par
     // chunks of the token range: aim at ~6.6 workgroups per CU (1700 for a whole 8-layer pass = 568 tiles x 3: the CUs then
     // finish within 5 % of each other), at least 256 tokens per workgroup, within the workspace
     int splits = 1;
+    int* counters = nullptr;
+    if (part_ws != nullptr && aligned16(part_ws) && g_tn100_in_kernel_sum && tiles <= TN100_COUNTERS && part_floats > 2 * TN100_COUNTERS) {
+        part_floats -= TN100_COUNTERS;
+        counters = reinterpret_cast<int*>(part_ws + part_floats);
+    }
     if (part_ws != nullptr && aligned16(part_ws)) {
         splits = (int)((1700 + tiles - 1) / tiles);
         if (splits > WMAXSPLIT) splits = WMAXSPLIT;
@@ -301,7 +377,8 @@ int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* par
     grp.splits = splits;
     grp.part = splits > 1 ? part_ws : nullptr;
     grp.part_stride = per_split;
-    int total = 0;
+    grp.counters = splits > 1 ? counters : nullptr;
+    int total = 0, ctr = 0;
     long off = 0;
     for (int i = 0; i < n; ++i) {
         W100Problem& q = grp.p[i];
@@ -317,12 +394,15 @@ int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* par
         q.ntiles = (q.Nn + WBN - 1) / WBN;
         q.block0 = total;
         q.part_off = off;
+        q.ctr0 = ctr;
+        ctr += q.ntiles;
         off += (((long)d[i].M * d[i].N + d[i].M) + 3) & ~3L;
         total += q.ntiles * splits;
     }
+    if (grp.counters != nullptr) GF_HIP(hipMemsetAsync(grp.counters, 0, (size_t)ctr * sizeof(int), st));
     hipLaunchKernelGGL(tn100_kernel, dim3(total), dim3(256), 0, st, grp);
     GF_LAUNCH_CHECK();
-    if (splits > 1) {
+    if (splits > 1 && grp.counters == nullptr) {
         hipLaunchKernelGGL(tn100_reduce_kernel, dim3(64, n), dim3(256), 0, st, grp);
         GF_LAUNCH_CHECK();
     }

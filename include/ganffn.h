@@ -352,6 +352,8 @@ int ganffn_gemm_n100(const float* A, const float* W, int w_kmajor, const float* 
  *   bit 2: run the [T x 2048] x [2048 x 100] products on the generic 64 x 64 tiles instead of csrc/gemm_n100.hip;
  *   bit 3: run the grouped weight-gradient launch of a d_model-100 pass on the generic 64 x 64 tiles instead of
  *          csrc/gemm_tn100.hip;
+ *   bit 4: csrc/gemm_tn100.hip adds its partial slabs in the kernel's last-arriving workgroup per tile instead of in a second
+ *          launch (same bits; measured slower: the device-scope fences cost more than the launch);
  *   bit 5: run the discriminator head as separate GELU / GEMM / tail launches instead of csrc/disc_head.hip;
  *   bit 6: run the head of a d_model-100 encoder stack (positional encoding + dropout, layer 0's in-proj) as two launches
  *          instead of one (csrc/rowchain.hip);

@@ -20,7 +20,8 @@ for T in (6016, 3008):
     A_, B_, C_, S_ = arr([bufs[p][0] for p in probs]), arr([bufs[p][1] for p in probs]), arr(Cd), arr(Sd)
     Ms, Ns, Ks = (C.c_int * n)(*[p[0] for p in probs]), (C.c_int * n)(*[p[1] for p in probs]), (C.c_int * n)(*[T] * n)
     flop = sum(2.0 * m * nn * T for (m, nn) in probs)
-    for bits, name in ((8, "generic 64x64 tiles"), (0, "tn100 auto"), (2 << 16, "tn100 2 chunks"), (3 << 16, "tn100 3 chunks"), (1 << 16, "tn100 1 chunk (owner)")):
+    for bits, name in ((8, "generic 64x64 tiles"), (0, "tn100 auto + reduce launch"), (16, "tn100 auto, in-kernel sum"), (2 << 16, "tn100 2 chunks"),
+                       ((2 << 16) | 16, "tn100 2 chunks, in-kernel sum"), (3 << 16, "tn100 3 chunks"), (4 << 16, "tn100 4 chunks"), (1 << 16, "tn100 1 chunk (owner)")):
         lib.ganffn_debug_set_ffn_mode(bits)
         call = lambda: _lib.call("ganffn_gemm_tn_grouped", n, A_, B_, C_, S_, Ms, Ns, Ks, P(ws), nws, st)
         for _ in range(3):
@@ -31,5 +32,5 @@ for T in (6016, 3008):
             call()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
-        print("T=%d %-24s %7.1f us  %.1f TFLOP/s useful (%.0f %% of 157.3)" % (T, name, us, flop / us / 1e6, flop / us / 1e6 / 1.573), flush=True)
+        print("T=%d %-28s %7.1f us  %.1f TFLOP/s useful (%.0f %% of 157.3)" % (T, name, us, flop / us / 1e6, flop / us / 1e6 / 1.573), flush=True)
 lib.ganffn_debug_set_ffn_mode(0)
