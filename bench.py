@@ -73,7 +73,8 @@ def wgrad_groups(S, B, config="iemocap"):
             (2, [(m, n, T1) for _ in range(8) for (m, n) in e512])]
 
 
-TRAFFIC_FILE = "profiles/r03_wgrad_traffic.json"
+TRAFFIC_FILE = "profiles/r04_wgrad_traffic.json"
+GEMM_TRAFFIC_FILE = "profiles/r04_gemm_traffic.json"
 
 
 def wgrad_algorithmic_bytes(S, B, config="iemocap"):
@@ -86,10 +87,10 @@ def wgrad_algorithmic_bytes(S, B, config="iemocap"):
     return tot / n
 
 
-def committed_traffic(S, B):
-    """HBM-side bytes per launch of the roofline kernel from the committed PMC passes (tools/traffic_pmc.sh), or None
+def committed_traffic(S, B, which=None):
+    """HBM-side bytes per launch of a kernel family from the committed PMC passes (tools/traffic_pmc.sh), or None
     when the file is absent or was taken at another problem size"""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), TRAFFIC_FILE)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), which or TRAFFIC_FILE)
     try:
         d = json.load(open(path))
         if d.get("seq_len") == S and d.get("dialogues_per_gpu") == B:
@@ -214,7 +215,102 @@ def time_n100_kernel(S, B, reps=3):
     return e0.elapsed_time(e1) * 1e-3 / (reps * nl), flops, nl
 
 
-IN_STEP_FILE = "profiles/r03_bench_streams1_by_launch_shape.txt"
+def _time_mix(calls, reps=3):
+    """HIP-event timing (events recorded on the launch stream = torch's current stream) of `reps` replays of one
+    iteration's launch mix: calls = [(count, fn, algorithmic work per launch)].  -> (avg s per launch, avg work per launch, launches)"""
+    def one_iteration():
+        for cnt, fn, _ in calls:
+            for _i in range(cnt):
+                fn()
+    one_iteration()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        one_iteration()
+    e1.record()
+    torch.cuda.synchronize()
+    n = sum(c[0] for c in calls)
+    return e0.elapsed_time(e1) * 1e-3 / (reps * n), sum(c[0] * c[2] for c in calls) / n, n
+
+
+def time_generic_gemm(S, B, reps=3):
+    """Live timing of the generic 64 x 64-tile GEMM family (`gemm_kernel<NT|NN, ...>`): one iteration's launch mix of the
+    d_model-512 generator — 4 forward stack passes (in-proj, out-proj, linear1 with bias + ReLU + dropout on the two
+    train-mode passes, linear2 as split-K slabs) and 2 backward passes (linear2 dgrad with the ReLU/dropout mask, linear1 and
+    in-proj dgrad as split-K slabs, out-proj dgrad), 8 layers each — through the measurement hook ganffn_gemm_hook, which
+    launches the kernel exactly as the encoder stack does.  (The generator heads and `object`, ~3 % of the family's
+    FLOPs, are not replayed.)"""
+    from gan_ffn_amd import _lib, ops
+    st, P = ops._stream(), ops._ptr
+    T, E, F = S * B, 512, 2048
+    rng = torch.tensor([3407, 0], dtype=torch.int64, device="cuda")
+    r = lambda *sh: torch.rand(*sh, device="cuda") - 0.5
+    x, xq, xf = r(T, E), r(T, 3 * E), r(T, F)
+    hsave = torch.relu(r(T, F))
+    w_in, w_out, w1, w2 = r(3 * E, E) * 0.1, r(E, E) * 0.1, r(F, E) * 0.1, r(E, F) * 0.1
+    b3, b1, bE, bF = torch.zeros(3 * E, device="cuda"), torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda"), torch.zeros(F, device="cuda")
+    o3, oE, oF, slabs = torch.empty(T, 3 * E, device="cuda"), torch.empty(T, E, device="cuda"), torch.empty(T, F, device="cuda"), torch.empty(8, T, E, device="cuda")
+    n = C.c_int(0)
+
+    def hook(mode, epi, A, W, bias, aux, out, M, N, K, train, max_slabs):
+        return lambda: _lib.call("ganffn_gemm_hook", mode, epi, P(A), P(W), P(bias) if bias is not None else None,
+                                 P(aux) if aux is not None else None, P(out), C.c_int64(M * N), M, N, K, C.c_float(0.1), C.c_uint32(18),
+                                 P(rng), C.c_uint64(0), train, max_slabs, C.byref(n), st)
+    fl = lambda M, N, K: 2.0 * M * N * K
+    calls = [
+        (32, hook(0, 0, x, w_in, b3, None, o3, T, 3 * E, E, 0, 1), fl(T, 3 * E, E)),        # in-proj
+        (32, hook(0, 0, x, w_out, b1, None, oE, T, E, E, 0, 1), fl(T, E, E)),              # out-proj
+        (16, hook(0, 1, x, w1, bF, None, oF, T, F, E, 1, 1), fl(T, F, E)),                 # linear1, train mode
+        (16, hook(0, 1, x, w1, bF, None, oF, T, F, E, 0, 1), fl(T, F, E)),                 # linear1, eval mode
+        (32, hook(0, 0, xf, w2, bE, None, slabs, T, E, F, 0, 8), fl(T, E, F)),             # linear2 (split-K slabs)
+        (16, hook(1, 3, x, w2, None, hsave, oF, T, F, E, 1, 1), fl(T, F, E)),              # linear2 dgrad: [T x 512] x [512 x 2048], masked
+        (16, hook(1, 0, xf, w1, None, None, slabs, T, E, F, 0, 8), fl(T, E, F)),           # linear1 dgrad: [T x 2048] x [2048 x 512]
+        (14, hook(1, 0, xq, w_in, None, None, slabs, T, E, 3 * E, 0, 8), fl(T, E, 3 * E)),  # in-proj dgrad: [T x 1536] x [1536 x 512]
+        (16, hook(1, 0, x, w_out, None, None, oE, T, E, E, 0, 1), fl(T, E, E)),            # out-proj dgrad
+    ]
+    return _time_mix(calls, reps)
+
+
+def time_attention(S, B, reps=3):
+    """Live timing of the attention family: one iteration's launch mix — head_dim 10 (d_model 100, 10 heads): forward 112
+    launches over B dialogues (32 of them train mode) and 48 over 2B (train), backward 80 over B (32 train) and 48 over 2B
+    (train); head_dim 64 (d_model 512, 8 heads): forward 32 (16 train), backward 16 (train) — through the C ABI pair that hands
+    the dropout keep words from forward to backward, as the encoder stack does.  -> (avg s, avg algorithmic flops, launches)"""
+    from gan_ffn_amd import _lib, ops
+    st, P = ops._stream(), ops._ptr
+    rng = torch.tensor([3407, 0], dtype=torch.int64, device="cuda")
+    lib = _lib.load()
+    calls = []
+    for (Bx, E, H, nf_tr, nf_ev, nb_tr, nb_ev) in ((B, 100, 10, 32, 80, 32, 48), (2 * B, 100, 10, 48, 0, 48, 0), (B, 512, 8, 16, 16, 16, 0)):
+        qkv, do = torch.randn(S, Bx, 3 * E, device="cuda"), torch.randn(S, Bx, E, device="cuda")
+        o, lse, dq = torch.empty(S, Bx, E, device="cuda"), torch.zeros(Bx * H, S, device="cuda"), torch.empty(S, Bx, 3 * E, device="cuda")
+        keep = torch.zeros(int(lib.ganffn_attention_keep_words(Bx, H)), dtype=torch.int32, device="cuda")
+        ffl = 4.0 * S * E * S * Bx
+        def fwd(p, qkv=qkv, o=o, lse=lse, keep=keep, Bx=Bx, E=E, H=H):
+            return lambda: _lib.call("ganffn_attention_fwd_keep", P(qkv), P(o), P(lse), P(keep), S, Bx, E, H, C.c_float(p), C.c_uint32(16), P(rng), C.c_uint64(0), st)
+        def bwd(p, qkv=qkv, o=o, lse=lse, keep=keep, do=do, dq=dq, Bx=Bx, E=E, H=H):
+            return lambda: _lib.call("ganffn_attention_bwd_keep", P(qkv), P(o), P(lse), P(do), P(keep), P(dq), S, Bx, E, H, C.c_float(p), C.c_uint32(16), P(rng), C.c_uint64(0), st)
+        fwd(0.1)()                      # (the backward reads the forward's output, log-sum-exp and keep words)
+        for cnt, fn, w in ((nf_tr, fwd(0.1), ffl), (nf_ev, fwd(0.0), ffl), (nb_tr, bwd(0.1), 2.5 * ffl), (nb_ev, bwd(0.0), 2.5 * ffl)):
+            if cnt:
+                calls.append((cnt, fn, w))
+    return _time_mix(calls, reps)
+
+
+IN_STEP_FILE = "profiles/r04_bench_streams1_by_launch_shape.txt"
+
+
+def profile_is_current(rel_path):
+    """does the committed rocprofv3 summary carry the hash of the kernel sources now in the tree?  (an in-step
+    figure taken on older kernels must not be mixed with live numerators)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import roofline_model as RM
+    path = os.path.join(ROOT, rel_path)
+    try:
+        return RM.summary_sha(path) == RM.csrc_sha16()
+    except Exception:
+        return False
 
 
 def in_step_kernel_us(symbol_prefix, grid=None):
@@ -309,7 +405,7 @@ def build_workload(config, dev):
     return engine.build_networks(device=dev, seed=3407)       # random init of the reference architecture
 
 
-DRNN_IN_STEP_FILE = "profiles/r03_drnn_by_launch_shape.txt"
+DRNN_IN_STEP_FILE = "profiles/r04_drnn_by_launch_shape.txt"
 
 
 def time_skinny_kernel(B, reps=20):
@@ -334,16 +430,21 @@ def time_skinny_kernel(B, reps=20):
 
 
 def drnn_in_step_us(symbol_prefix):
-    """average duration of a kernel inside the configuration-5 step, from the committed rocprofv3 summary (or None)"""
+    """launch-weighted average duration of a kernel inside the configuration-5 step, from the committed rocprofv3 summary (or
+    None; None too when that summary was taken on other kernel sources than the ones in the tree)"""
+    if not profile_is_current(DRNN_IN_STEP_FILE):
+        return None
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), DRNN_IN_STEP_FILE)
+    tot, n = 0.0, 0
     try:
         for line in open(path):
             f = line.split()
             if len(f) >= 5 and f[0].endswith("%") and " ".join(f[4:]).startswith(symbol_prefix):
-                return float(f[2])
+                tot += float(f[2]) * int(f[1])
+                n += int(f[1])
     except Exception:
         pass
-    return None
+    return round(tot / n, 2) if n else None
 
 
 def run_drnn(args, dev, pg, rank, world):
@@ -464,9 +565,9 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="HIP streams running independent sub-steps concurrently")
     ap.add_argument("--cpu-sample-batch", type=int, default=None,
                     help="dialogues of the CPU-baseline sample (default: the whole batch, BASELINE.md §3)")
-    ap.add_argument("--replay-dominant-only", action="store_true",
-                    help="only replay the roofline kernel's launch mix once (the command tools/traffic_pmc.sh profiles "
-                         "with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass)")
+    ap.add_argument("--replay-family", choices=["wgrad", "gemm_generic", "attention"], default=None,
+                    help="only replay one kernel family's launch mix (warm-up pass + one timed pass): the command "
+                         "tools/traffic_pmc.sh / tools/attention_pmc.sh profile with rocprofv3 --pmc, one counter set per pass")
     args = ap.parse_args()
     if args.seq is None:
         args.seq = 33 if args.config == "meld" else 94
@@ -501,9 +602,12 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    if args.replay_dominant_only:
-        kt, kflop, klaunch = time_dominant_kernel(args.seq, args.batch, reps=1, config=cfgname)
-        print(json.dumps({"avg_kernel_us": kt * 1e6, "launches": klaunch}), flush=True)
+    if args.replay_family:
+        _lib.load()
+        fn = {"wgrad": lambda S_, B_, reps: time_dominant_kernel(S_, B_, reps=reps, config=cfgname), "gemm_generic": time_generic_gemm,
+              "attention": time_attention}[args.replay_family]
+        kt, kwork, klaunch = fn(args.seq, args.batch, reps=1)
+        print(json.dumps({"family": args.replay_family, "avg_kernel_us": kt * 1e6, "launches": klaunch}), flush=True)
         return
     from gan_ffn_amd import data as D
     _lib.load()
@@ -561,8 +665,8 @@ def main():
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                           "config": {"workload": cfgname, "streams": eng.n_streams}}), flush=True)
     elif rank == 0:
-        kt, kflop, klaunch = time_dominant_kernel(S, B, config=cfgname)
-        traffic = committed_traffic(S, B) if cfgname == "iemocap" else None
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import roofline_model as RM
         fpt = flops_per_token(S, cfgname)
         step_tflops = fpt * S * B * world * args.steps / dt / 1e12
         out = {
@@ -584,51 +688,79 @@ def main():
                        "step_tflops_reference_equivalent": round(step_tflops, 2),
                        "step_frac_of_fp32_mfma_peak": round(step_tflops * 1e12 / (FP32_MFMA_PEAK * world), 4),
                        "last_losses": {k: round(v, 4) for k, v in losses.items()}},
-            "roofline": {"bound": "mfma", "kernel": "the grouped weight-gradient launch = all 32 weight-gradient GEMMs (+ bias gradients) of one "
-                                                     "encoder backward pass: tn100_kernel + its ordered slab reduce for the d_model-100 "
-                                                     "networks (112-wide 16x16x4 tiles, csrc/gemm_tn100.hip), gemm_tn_grouped_kernel<false,128> "
-                                                     "for the d_model-512 generator; no atomics; %d launches per iteration; the kernel "
-                                                     "family with the largest share of GPU time in the single-stream profile" % klaunch,
-                         "achieved": round(kflop / kt / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": round(kflop / kt / FP32_MFMA_PEAK, 4), "traffic": traffic,
-                         "traffic_unit": "bytes per launch (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE, separate "
-                                         "rocprofv3 --pmc passes: " + TRAFFIC_FILE + ")" if traffic is not None else None,
-                         "algorithmic_bytes_per_launch": round(wgrad_algorithmic_bytes(S, B, cfgname)),
-                         "avg_kernel_us": round(kt * 1e6, 2), "avg_gflop_per_launch": round(kflop / 1e9, 4),
-                         "how": "HIP events around one iteration's launch mix of this launch replayed in isolation on the launch "
-                                "stream; in_step_avg_us = the same launches inside the single-stream step, from the committed "
-                                "rocprofv3 summary " + IN_STEP_FILE,
-                         "in_step_avg_us": in_step_wgrad_us() if (cfgname == "iemocap" and (S, B) == (94, 32)) else None},
         }
-        if cfgname == "iemocap":
-            # heavy kernel FAMILIES (>= 5 % of GPU time in profiles/r03_bench_streams1_*: the K = 100 -> 2048 products of the
-            # d_model-100 feed-forward block, 16.6 %, and the 2048 -> 100 ones, 13.4 %), each timed live; the one that sits
-            # lowest on its roofline is reported as roofline_worst, the other beside it
-            lt, lflop, ln = time_linear1_kernel(S, B)
-            nt_, nflop, nn = time_n100_kernel(S, B)
+        if cfgname != "iemocap":
+            # extension workload: the weight-gradient launch (its heaviest family; no committed single-stream profile of it)
+            kt, kflop, klaunch = time_dominant_kernel(S, B, config=cfgname)
+            out["roofline"] = {"bound": "mfma", "kernel": "the grouped weight-gradient launch (all 32 weight + bias gradients of one encoder "
+                                                          "backward pass in one launch; %d launches per iteration)" % klaunch,
+                               "achieved": round(kflop / kt / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                               "frac": round(kflop / kt / FP32_MFMA_PEAK, 4), "traffic": None,
+                               "algorithmic_bytes_per_launch": round(wgrad_algorithmic_bytes(S, B, cfgname)),
+                               "avg_kernel_us": round(kt * 1e6, 2), "avg_gflop_per_launch": round(kflop / 1e9, 4),
+                               "how": "HIP events around one iteration's launch mix of this launch replayed in isolation on the launch stream"}
+        else:
+            # ---- the bench line FOLLOWS the committed single-stream profile: every kernel family with >= 5 % of the step's
+            # kernel time is listed with its in-step roofline fraction (tools/roofline_model.py: family table + algorithmic
+            # work per iteration), each is also replayed live (HIP events on the launch stream); `roofline` is the family with
+            # the LARGEST share, `roofline_worst` the one with the LOWEST fraction.
             full = (S, B) == (94, 32)
-            cands = [
-                {"kernel": "gemm_wres_kernel<0,1,100> = linear1 of the d_model-100 feed-forward block with fused bias + ReLU + "
-                           "dropout ([T x 100] x [2048 x 100]^T, K = 100; persistent, weight fragments register-resident); "
-                           "%d launches per iteration (T = S*B and 2*S*B)" % ln,
-                 "achieved": round(lflop / lt / 1e12, 2), "frac": round(lflop / lt / FP32_MFMA_PEAK, 4), "avg_kernel_us": round(lt * 1e6, 2),
-                 "avg_gflop_per_launch": round(lflop / 1e9, 4), "in_step_avg_us": in_step_kernel_us("gemm_wres_kernel<0, 1, 100>") if full else None},
-                {"kernel": "gemm_n100_kernel = [T x 2048] x [2048 x 100] on 16x16x4 MFMAs, 112-wide feature tile, K-chunk slabs "
-                           "(linear2 forward and the linear1 dgrad; csrc/gemm_n100.hip); %d launches per iteration" % nn,
-                 "achieved": round(nflop / nt_ / 1e12, 2), "frac": round(nflop / nt_ / FP32_MFMA_PEAK, 4), "avg_kernel_us": round(nt_ * 1e6, 2),
-                 "avg_gflop_per_launch": round(nflop / 1e9, 4), "in_step_avg_us": in_step_kernel_us("gemm_n100_kernel") if full else None},
-            ]
-            for c_ in cands:
-                c_.update({"bound": "mfma", "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "traffic": None})
-                if c_["in_step_avg_us"]:
-                    c_["in_step_frac"] = round(c_["avg_gflop_per_launch"] * 1e9 / (c_["in_step_avg_us"] * 1e-6) / FP32_MFMA_PEAK, 4)
-            cands.sort(key=lambda c_: c_["frac"])
-            out["roofline_worst"] = dict(cands[0])
-            out["roofline_worst"]["how"] = ("HIP events around one iteration's launch mix of this kernel replayed in isolation on the "
-                                            "launch stream; chosen as the lowest roofline fraction among the kernel families with >= 5 % "
-                                            "of GPU time; in_step_* = the same symbol's launch-weighted average inside the single-stream "
-                                            "step, from the committed rocprofv3 summary " + IN_STEP_FILE)
-            out["roofline_worst"]["other_heavy_families"] = cands[1:]
+            prof_path = os.path.join(ROOT, IN_STEP_FILE)
+            current = profile_is_current(IN_STEP_FILE)
+            instep = RM.in_step(prof_path, S, B) if (full and os.path.exists(prof_path)) else None
+            live = {}
+            for key, fn in (("gemm_generic", time_generic_gemm), ("ffn_k100", time_linear1_kernel), ("ffn_n100", time_n100_kernel),
+                            ("wgrad", lambda S_, B_: time_dominant_kernel(S_, B_, config=cfgname)), ("attention", time_attention)):
+                t_, w_, n_ = fn(S, B)
+                live[key] = dict(avg_kernel_us=round(t_ * 1e6, 2), avg_gflop_per_launch=round(w_ / 1e9, 4), launches_replayed=n_,
+                                 achieved=round(w_ / t_ / 1e12, 2), frac=round(w_ / t_ / FP32_MFMA_PEAK, 4))
+            table = {f["key"]: f for f in RM.family_table(S, B)}
+            fams = []
+            order = [d["family"] for d in instep["families"]] if instep else list(live)
+            for key in order:
+                d = dict(next(x for x in instep["families"] if x["family"] == key)) if instep else \
+                    dict(family=key, kernel=table[key]["title"], bound=table[key]["bound"])
+                if instep:
+                    d["in_step_frac"] = d.pop("frac")
+                    d["in_step_achieved"] = d.pop("achieved")
+                    if not current:
+                        d["in_step_stale"] = True        # the committed profile was taken on other kernel sources
+                if key in live:
+                    d.update(live[key])                  # achieved / frac = the LIVE isolated replay
+                    d.update(peak=FP32_MFMA_PEAK / 1e12, unit="TFLOP/s")
+                else:
+                    d.update(achieved=d.get("in_step_achieved"), frac=d.get("in_step_frac"), avg_kernel_us=None,
+                             live="not replayed in isolation (its launches only exist inside an encoder pass): in-step figures only")
+                fams.append(d)
+            dom = fams[0]
+            traffic = committed_traffic(S, B, GEMM_TRAFFIC_FILE if dom["family"] == "gemm_generic" else TRAFFIC_FILE)
+            out["roofline"] = {
+                "bound": dom["bound"], "kernel": dom["kernel"], "family": dom["family"],
+                "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
+                "traffic": traffic,
+                "traffic_unit": ("bytes per launch, averaged over the replayed launch mix (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE, "
+                                 "separate rocprofv3 --pmc passes: " + (GEMM_TRAFFIC_FILE if dom["family"] == "gemm_generic" else TRAFFIC_FILE) + ")")
+                if traffic is not None else None,
+                "avg_kernel_us": dom.get("avg_kernel_us"), "avg_gflop_per_launch": dom.get("avg_gflop_per_launch"),
+                "share_of_step_kernel_time_pct": dom.get("share_pct"), "in_step_frac": dom.get("in_step_frac"),
+                "how": "the kernel family with the largest share of GPU time in the committed single-stream rocprofv3 summary " + IN_STEP_FILE +
+                       " (chosen by tools/roofline_model.py, not by hand); achieved / frac = algorithmic FLOPs per launch / average launch "
+                       "duration of one iteration's launch mix of that family replayed live in isolation, HIP events on the launch stream; "
+                       "in_step_frac = the family's algorithmic FLOPs per iteration / its kernel time per iteration inside the "
+                       "single-stream step, from that summary" + ("" if current else " (STALE: taken on other kernel sources)")}
+            out["roofline_families"] = fams
+            worst = min(fams, key=lambda d: d.get("in_step_frac") if d.get("in_step_frac") is not None else d["frac"])
+            out["roofline_worst"] = dict(worst)
+            out["roofline_worst"]["how"] = ("the lowest in-step roofline fraction among the kernel families with >= 5 % of the step's "
+                                            "kernel time (every such family is listed in roofline_families)")
+            out["profile"] = {"file": IN_STEP_FILE, "matches_kernel_sources": current,
+                              "kernel_time_ms_per_iteration_single_stream": instep["kernel_time_ms_per_iteration"] if instep else None,
+                              "families_cover_pct": round(sum(d.get("share_pct", 0) for d in fams), 1) if instep else None}
+            wtraffic = committed_traffic(S, B, TRAFFIC_FILE)
+            for d in fams:
+                if d["family"] == "wgrad":
+                    d["traffic"] = wtraffic
+                    d["algorithmic_bytes_per_launch"] = round(wgrad_algorithmic_bytes(S, B, cfgname))
         if world == 1 and not args.no_cpu_baseline:
             threads = host_threads()
             print("[bench] cpu_baseline on %d host threads (affinity / cgroup share)" % threads, file=sys.stderr, flush=True)

@@ -649,6 +649,29 @@ extern "C" int ganffn_ffn_linear1_fwd(const float* x, const float* w1, const flo
     e.bias = b1; e.p = p; e.site = site; e.rng = rng; e.rng_add = add; e.train = train;
     return launch_gemm_nt(x, E, w1, E, h, F, T, F, E, EPI_RELU_DROP, e, (hipStream_t)stream);
 }
+// test / measurement hook: the generic 64 x 64 GEMM kernel as the encoder stack launches it (bench.py replays the d_model-512
+// generator's launch mix through this)
+extern "C" int ganffn_gemm_hook(int mode, int epi, const float* A, const float* W, const float* bias, const float* aux, float* C,
+                                int64_t slab_stride, int M, int N, int K, float p, uint32_t site, const uint64_t* rng, uint64_t add,
+                                int train, int max_slabs, int* n_slabs, void* stream) {
+    GF_CHECK_ARG((mode == 0 || mode == 1) && (epi == EPI_NONE || epi == EPI_RELU_DROP || epi == EPI_MASK_POS),
+                 "gemm_hook: mode %d / epilogue %d not offered by the hook", mode, epi);
+    GF_CHECK_ARG(epi != EPI_MASK_POS || aux, "gemm_hook: the mask epilogue needs the saved activation");
+    GF_CHECK_ARG(!(epi == EPI_RELU_DROP && train && p > 0.f) || rng, "gemm_hook: rng required when dropout is active");
+    EpiArgs e;
+    e.bias = bias; e.aux_in = aux; e.mscale = (train && p > 0.f && epi == EPI_MASK_POS) ? 1.f / (1.f - p) : 1.f;
+    e.p = p; e.site = site; e.rng = rng; e.rng_add = add; e.train = train;
+    int splits = 1;
+    if (max_slabs > 1 && epi == EPI_NONE) {
+        splits = gemm_splitk_factor(M, N, K);
+        if (splits > max_slabs) splits = max_slabs;
+    }
+    int* sp = (max_slabs > 1 && epi == EPI_NONE) ? &splits : nullptr;
+    if (mode == 0) GF_TRY(launch_gemm_nt(A, K, W, K, C, N, M, N, K, epi, e, (hipStream_t)stream, sp, (long)slab_stride));
+    else GF_TRY(launch_gemm_nn(A, K, W, N, C, N, M, N, K, epi, e, (hipStream_t)stream, sp, (long)slab_stride));
+    if (n_slabs) *n_slabs = splits;
+    return 0;
+}
 extern "C" int ganffn_gemm_n100(const float* A, const float* W, int w_kmajor, const float* bias, float* slabs, int64_t slab_stride,
                                 int T, int K, int max_slabs, int* n_slabs, void* stream) {
     GF_CHECK_ARG(n_slabs && max_slabs >= 1 && max_slabs <= MAX_SPLITS, "gemm_n100: max_slabs=%d out of [1,%d]", max_slabs, MAX_SPLITS);

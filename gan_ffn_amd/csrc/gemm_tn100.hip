@@ -239,13 +239,24 @@ __global__ __launch_bounds__(256) void tn100_kernel(W100Group grp) {
     // release: this workgroup's slab stores are visible device-wide before its ticket is; acquire on the other side.  The
     // ticket decides only WHO adds — every slab is read back from memory and summed z = 0, 1, ... exactly as
     // tn100_reduce_kernel does, so the result does not depend on the arrival order (and equals round 3's bits).
+    // (cdna_hip_programming.md, in-launch split-K reduction: every wave drains its stores, the workgroup meets, ONE lane
+    // releases at agent scope — a fence per thread, `__threadfence()`, measured 731 against 490 us for this launch — and draws
+    // the ticket; the last arriver's one lane acquires, then the workgroup reads the slabs with plain loads)
     __shared__ int s_last;
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&grp.counters[q.ctr0 + tile], 1) == grp.splits - 1 ? 1 : 0;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(&grp.counters[q.ctr0 + tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == grp.splits - 1 ? 1 : 0;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     const float* const part = grp.part + q.part_off;
     const int ns = grp.splits;
     if (q.side == 0) {

@@ -345,6 +345,16 @@ int ganffn_dropout(const float* x, float* out, int R, int C, float p, uint32_t s
 int ganffn_gemm_n100(const float* A, const float* W, int w_kmajor, const float* bias, float* slabs, int64_t slab_stride,
                      int T, int K, int max_slabs, int* n_slabs, void* stream);
 
+/* Test / measurement hook: the generic 64 x 64-tile GEMM kernel exactly as the encoder stack launches it for the layers that
+ * have no specialised kernel (the d_model-512 generator, nn.Linear call sites model.py:1244-1252 via torch's
+ * TransformerEncoderLayer).  mode 0: C = A[M x K] W[N x K]^T, mode 1: C = A[M x K] W[K x N].  epi 0: + bias; 1: bias + ReLU +
+ * dropout (linear1); 3: C = acc * (aux > 0 ? 1/(1-p) : 0) (dgrad through ReLU + dropout, aux = the saved activation [M x N]).
+ * max_slabs > 1 with epi 0: K is split the way the encoder splits few-tile long-K products, slab z at C + z * slab_stride,
+ * *n_slabs = slabs written (their sum is the product).  bench.py replays one iteration's launch mix through it. */
+int ganffn_gemm_hook(int mode, int epi, const float* A, const float* W, const float* bias, const float* aux, float* C,
+                     int64_t slab_stride, int M, int N, int K, float p, uint32_t site, const uint64_t* rng,
+                     uint64_t rng_offset_add, int train, int max_slabs, int* n_slabs, void* stream);
+
 /* A/B measurement hook (process-wide), a bit mask; 0 = the default path.
  *   bit 0: run the d_model-100 feed-forward block as the fused kernel of ffn.hip instead of two GEMMs (measured slower);
  *   bit 1: run the token-local chains around the LayerNorms of a d_model-100 layer (out-proj + LN1, LN2 + next in-proj and

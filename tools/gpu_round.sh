@@ -17,11 +17,11 @@ cd /tmp && export TMPDIR=/tmp
 prof() {   # name, bench arguments...
   n=$1; shift
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$n -- python3 $R/bench.py --no-cpu-baseline "$@" > $O/prof_$n.log 2>&1 || { tail -20 $O/prof_$n.log; exit 1; }
-  python3 $R/tools/prof_summary.py $(ls $O/prof_$n/*/*kernel_trace.csv | head -1) 80 > $O/r04_${n}_by_launch_shape.txt
+  python3 $R/tools/prof_summary.py $(ls $O/prof_$n/*/*kernel_trace.csv | head -1) 90 ${ITER:-13} > $O/r04_${n}_by_launch_shape.txt
   cp $(ls $O/prof_$n/*/*kernel_stats.csv | head -1) $O/r04_${n}_kernel_stats.csv
   rm -rf $O/prof_$n
 }
 prof bench_streams1 --streams 1 --no-graph --steps 10 --step-only
 prof bench_default --steps 10 --step-only
-prof drnn --config drnn --steps 10
+ITER=70 prof drnn --config drnn --steps 10        # (60 warm-up steps + 10 timed)
 head -40 $O/r04_bench_streams1_by_launch_shape.txt

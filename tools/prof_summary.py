@@ -11,6 +11,12 @@ for r in rows:
     agg[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 tot = sum(sum(v) for v in agg.values())
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+if len(sys.argv) > 3:
+    print("iterations %d" % int(sys.argv[3]))         # step iterations the trace covers (warm-up + timed), for per-iteration figures
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from roofline_model import csrc_sha16
+    print("csrc_sha16 %s" % csrc_sha16())             # the kernel sources this trace was taken on (bench.py flags a stale profile)
 print("share  launches  avg_us  grid(blocks_x,y,z)  kernel")
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:top]:
     print("%5.2f%% %6d %8.1f  (%s,%s,%s)  %s" % (100 * sum(v) / tot, len(v), sum(v) / len(v), k[1], k[2], k[3], k[0]))
