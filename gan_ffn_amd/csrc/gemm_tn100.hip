@@ -14,10 +14,11 @@
 //    other; chunk z writes its partial tile to slab z and one ordered reduce launch adds the slabs to the gradient —
 //    no atomics, bit-reproducible.  (Round 4 built the alternative — the LAST workgroup of a tile to arrive, decided by an
 //    integer ticket, adds the slabs in chunk order inside tn100_kernel: same bits, tests/test_hip_ops.py — and measured it
-//    SLOWER: 731 against 490 us at T = 6016, 535 against 264 us at T = 3008 (gpurun_out/r4_tn100_lab.txt).  The
-//    device-scope release / acquire fences it needs — a partial slab may sit in another XCD's L2 — write back and invalidate
-//    the whole L2 once per workgroup, 1704 times per launch; the 21 us reduce launch is the cheaper way to cross the XCDs.
-//    It stays behind ganffn_debug_set_ffn_mode bit 4.)
+//    SLOWER both ways it can be written: with a `__threadfence()` per thread 731 against 490 us at T = 6016 (every fence
+//    writes back and invalidates an L2); with the one-lane agent-scope release / acquire of cdna_hip_programming.md 515
+//    against 491 us at T = 6016 and 296 against 261 us at T = 3008 (gpurun_out/r4_tn100_lab*.txt): a tile's slabs are
+//    3 x 28 KB, and the last arriver reads them serially at the end of a workgroup's life, which costs more than the 21 us
+//    reduce launch that reads all of them with the whole chip.  It stays behind ganffn_debug_set_ffn_mode bit 4.)
 //  * bias gradients (column sums of dY over the tokens) are accumulated from the operand registers the MFMAs read anyway;
 //  * workgroup ids are remapped so that one XCD (one L2) gets a contiguous range of the (problem, chunk, tile) list: the
 //    tiles of a problem share its 100-wide operand panel ([T x 100], 2.4 MB at T = 6016) through that L2, the wide operand
@@ -240,8 +241,8 @@ __global__ __launch_bounds__(256) void tn100_kernel(W100Group grp) {
     // ticket decides only WHO adds — every slab is read back from memory and summed z = 0, 1, ... exactly as
     // tn100_reduce_kernel does, so the result does not depend on the arrival order (and equals round 3's bits).
     // (cdna_hip_programming.md, in-launch split-K reduction: every wave drains its stores, the workgroup meets, ONE lane
-    // releases at agent scope — a fence per thread, `__threadfence()`, measured 731 against 490 us for this launch — and draws
-    // the ticket; the last arriver's one lane acquires, then the workgroup reads the slabs with plain loads)
+    // releases at agent scope and draws the ticket; the last arriver's one lane acquires, then the workgroup reads the slabs
+    // with plain loads)
     __shared__ int s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
