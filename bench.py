@@ -87,6 +87,16 @@ def wgrad_algorithmic_bytes(S, B, config="iemocap"):
     return tot / n
 
 
+def generic_gemm_algorithmic_bytes(S, B):
+    """average compulsory bytes of one launch of time_generic_gemm's mix: both operands read once, the output written once
+    (the mask epilogue also reads the saved activation)"""
+    T, E, F = S * B, 512, 2048
+    mix = [(32, T, 3 * E, E, 0), (32, T, E, E, 0), (32, T, F, E, 0), (32, T, E, F, 0), (16, T, F, E, 1), (16, T, E, F, 0), (14, T, E, 3 * E, 0),
+           (16, T, E, E, 0)]
+    tot = sum(c * 4.0 * (M * K + N * K + M * N * (1 + aux)) for (c, M, N, K, aux) in mix)
+    return tot / sum(m[0] for m in mix)
+
+
 def committed_traffic(S, B, which=None):
     """HBM-side bytes per launch of a kernel family from the committed PMC passes (tools/traffic_pmc.sh), or None
     when the file is absent or was taken at another problem size"""
@@ -741,6 +751,8 @@ def main():
                 "traffic_unit": ("bytes per launch, averaged over the replayed launch mix (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE, "
                                  "separate rocprofv3 --pmc passes: " + (GEMM_TRAFFIC_FILE if dom["family"] == "gemm_generic" else TRAFFIC_FILE) + ")")
                 if traffic is not None else None,
+                "algorithmic_bytes_per_launch": round(generic_gemm_algorithmic_bytes(S, B)) if dom["family"] == "gemm_generic" else
+                (round(wgrad_algorithmic_bytes(S, B, cfgname)) if dom["family"] == "wgrad" else None),
                 "avg_kernel_us": dom.get("avg_kernel_us"), "avg_gflop_per_launch": dom.get("avg_gflop_per_launch"),
                 "share_of_step_kernel_time_pct": dom.get("share_pct"), "in_step_frac": dom.get("in_step_frac"),
                 "how": "the kernel family with the largest share of GPU time in the committed single-stream rocprofv3 summary " + IN_STEP_FILE +

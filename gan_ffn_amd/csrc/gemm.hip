@@ -637,7 +637,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 // otherwise hide behind the same symbol and grid as the d_model-512 ones); the code is the same.
 template <int MODE, int BM, int BN, int BK, int EPI, int WGM = 2, int WGN = 2, int SHORTK = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmArgs g) {
-    gemm_body<MODE, BM, BN, BK, EPI, WGM, WGN>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+    // XCD-aware tile order (round 4).  The dispatcher deals workgroups round-robin over the 8 XCDs in linear-id order
+    // (x fastest), and every launch of the d_model-512 generator has a tile count along N that is a multiple of 8 (8, 24,
+    // 32): each XCD then owned a few N columns of EVERY row tile, i.e. every XCD pulled the whole activation operand through
+    // its private L2 — rocprofv3 FETCH_SIZE 4.1x the compulsory bytes over the generator's launch mix
+    // (profiles/r04_gemm_traffic.json: 121 MB against 30 MB per launch), worst for the K = 2048 products (24.6 MB of
+    // activations read 8 times).  Bijective remap as in gemm_tn_grouped_kernel: the workgroups of one XCD get a contiguous
+    // range of the logical (k-split, row tile, column tile) list with the column fastest = a band of row tiles with all
+    // their columns: the activation band is read once, only the (smaller) weight is read by all eight.
+    const int gx = gridDim.x, gy = gridDim.y, per = gx * gy, nwg = per * gridDim.z;
+    const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int q8 = nwg >> 3, r8 = nwg & 7, xl = lin & 7;
+    const int b = (xl < r8 ? xl * (q8 + 1) : r8 * (q8 + 1) + (xl - r8) * q8) + (lin >> 3);
+    const int bz = b / per, t = b - bz * per, by = t / gx, bx = t - by * gx;
+    gemm_body<MODE, BM, BN, BK, EPI, WGM, WGN>(g, bx, by, bz);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

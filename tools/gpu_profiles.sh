@@ -1,0 +1,37 @@
+# GPU call B of a round: every artefact that goes under profiles/ (round-4 names), taken on the kernel sources in the tree:
+# rocprofv3 kernel traces of the step alone (single stream, default 3 streams, configuration 5), PMC traffic of the
+# weight-gradient and generic-GEMM launch mixes, SQ counters of the attention kernels, the general2 GB/s line, and the
+# bench lines (default with CPU baseline, MELD dims, configuration 5).  Then copy gpurun_out/r04_* into profiles/ by hand.
+set -o pipefail
+R=$PWD
+O=$R/gpurun_out
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+prof() {   # name, bench arguments...
+  n=$1; shift
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$n -- python3 $R/bench.py --no-cpu-baseline "$@" > $O/prof_$n.log 2>&1 || { tail -20 $O/prof_$n.log; exit 1; }
+  ( cd $R && python3 tools/prof_summary.py $(ls $O/prof_$n/*/*kernel_trace.csv | head -1) 90 ${ITER:-13} > $O/r04_${n}_by_launch_shape.txt )
+  cp $(ls $O/prof_$n/*/*kernel_stats.csv | head -1) $O/r04_${n}_kernel_stats.csv
+  rm -rf $O/prof_$n
+}
+prof bench_streams1 --streams 1 --no-graph --steps 10 --step-only
+prof bench_default --steps 10 --step-only
+ITER=70 prof drnn --config drnn --steps 10        # (60 warm-up steps + 10 timed)
+cd $R
+cp $O/r04_bench_streams1_by_launch_shape.txt $O/r04_drnn_by_launch_shape.txt profiles/    # bench.py reads its in-step figures from profiles/
+bash tools/traffic_pmc.sh wgrad > $O/traffic_wgrad.log 2>&1 || { tail -20 $O/traffic_wgrad.log; exit 1; }
+bash tools/traffic_pmc.sh gemm_generic > $O/traffic_gemm.log 2>&1 || { tail -20 $O/traffic_gemm.log; exit 1; }
+cp $O/r04_wgrad_traffic.json $O/r04_gemm_traffic.json profiles/
+bash tools/attention_pmc.sh > $O/attention_pmc.log 2>&1 || { tail -30 $O/attention_pmc.log; exit 1; }
+python3 tools/general2_line.py > $O/r04_general2_line.txt 2>&1 || tail -5 $O/r04_general2_line.txt
+timeout -k 10 600 python bench.py > $O/r04_bench_default.json 2> $O/r04_bench_default.err || { tail -20 $O/r04_bench_default.err; exit 1; }
+timeout -k 10 300 python bench.py --config meld > $O/r04_bench_meld.json 2> $O/r04_bench_meld.err || { tail -20 $O/r04_bench_meld.err; exit 1; }
+timeout -k 10 300 python bench.py --config drnn > $O/r04_bench_drnn.json 2> $O/r04_bench_drnn.err || { tail -20 $O/r04_bench_drnn.err; exit 1; }
+python3 - <<'PY'
+import json
+d = json.loads([l for l in open("gpurun_out/r04_bench_default.json") if l.startswith("{")][0])
+print("ms/step", d["ms_per_step"], "roofline", d["roofline"]["family"], d["roofline"]["frac"], "traffic", d["roofline"]["traffic"], "alg", d["roofline"]["algorithmic_bytes_per_launch"])
+for f in d["roofline_families"]:
+    print(" ", f["family"], f.get("share_pct"), "in-step", f.get("in_step_frac"), "live", f["frac"], f.get("avg_kernel_us"))
+print("worst", d["roofline_worst"]["family"], "cpu", d.get("cpu_baseline", {}).get("value"))
+PY
