@@ -83,6 +83,20 @@ class NetState:
         return bucket_ranges(self.enc_floats, self.obj_floats, self.total, self.layer_floats, self.L, n_buckets)
 
 
+def dp_mode():
+    """how gradients cross the ranks (GANFFN_DP_MODE):
+    "inline" (default, round 4): ONE all-reduce of the network's whole gradient slab per sub-step, issued as a synchronous
+        collective — torch >= 2.7 runs those on the CURRENT stream, i.e. in-line on the sub-step's own HIP stream, between its
+        backward and its Adam: no internal communication stream, no cross-stream events; the all-reduce of one sub-step runs
+        beside the compute of the sub-steps on the other streams (each stream has its own communicator, so collectives of
+        different streams never share one);
+    "buckets" (rounds 1-3): 4-5 asynchronous all-reduces per sub-step on the process group's internal stream, each issued
+        right after its layer range's backward, Adam per bucket.  Measured with a 1-rank RCCL group on one MI355X
+        (tools/dist1_ab.sh): 40.6-60.6 ms per step against 34.5 ms for the plain engine — the internal stream's event waits
+        share hardware queues with the sub-step streams and hold them up; see DESIGN.md section 7."""
+    return os.environ.get("GANFFN_DP_MODE", "inline")
+
+
 class GradReducer:
     """Bucketed gradient all-reduce for data parallelism over the DIALOGUE axis (one process per GPU).
     Each call sums one contiguous slice of a gradient slab across ranks, asynchronously (on RCCL's own
@@ -203,12 +217,18 @@ def _side_streams(dev, prios, tuner=None, work=1):
     (tools/lab/stream_order.py; 1-workgroup spin kernels overlap on every pair — only real launch mixes tell the pairs
     apart).  `tuner(prios)` picks the streams by timing a probe workload on fresh candidates (GanEngine._tune_streams);
     without it, or with GANFFN_STREAM_TUNE=0, fresh streams are taken as they come; `work` = tokens per pass of the engine
-    that asks (the choice is re-timed when a much bigger engine comes along).  Engines join their streams at the end of
-    every step, so sharing them between the engines of one process is safe."""
+    that asks (the choice is re-timed when a much bigger engine comes along).
+    Sharing the streams between the engines of one process is safe for engines over DIFFERENT networks and buffers (each
+    engine orders its own sub-steps with its own events).  Two engines over the SAME networks see only their own dependency
+    records: DrnnEngine joins its streams at the end of every step, but an eager multi-stream GanEngine does not (consecutive
+    iterations overlap) — call `eng.synchronize()` (or `loss_dict()`) before another engine touches the same networks
+    (tests/test_hip_engine.py::test_two_engines_over_the_same_networks_need_a_synchronize)."""
     key = (str(dev), tuple(prios))
     if os.environ.get("GANFFN_STREAM_CACHE", "1") == "1" and key in _STREAMS and work <= 4 * _STREAMS[key][1]:
         return _STREAMS[key][0]                 # (a choice timed on a much smaller batch is not trusted for a big one)
-    if tuner is not None and len(prios) > 1 and os.environ.get("GANFFN_STREAM_TUNE", "1") == "1":
+    # (no timing probes while the caller is capturing a graph: they synchronise)
+    if tuner is not None and len(prios) > 1 and os.environ.get("GANFFN_STREAM_TUNE", "1") == "1" and \
+            not torch.cuda.is_current_stream_capturing():
         streams = tuner(prios)
     else:
         streams = [torch.cuda.Stream(device=dev, priority=p_) for p_ in prios]
@@ -284,13 +304,13 @@ class GanEngine(_Runner):
         self.streams = None
         self._res = {}
         self._base_add = 0
-        # Optional (GANFFN_COMM_PER_STREAM=1): one communicator per sub-step stream.  A process group runs its collectives
-        # in issue order on ONE internal stream, so with a single group the all-reduces of a sub-step that is still
-        # computing hold back those of sub-steps on the other streams that are already done.  Off by default: collectives
-        # of different communicators in flight at once rely on their kernels being co-resident on every rank, which
-        # could not be exercised on the one-GPU development box.
+        # One communicator per sub-step stream (default in the in-line mode, see dp_mode(); GANFFN_COMM_PER_STREAM overrides).
         self.pgs = [process_group]
-        if process_group is not None and self.n_streams > 1 and os.environ.get("GANFFN_COMM_PER_STREAM", "0") == "1":
+        per_stream = os.environ.get("GANFFN_COMM_PER_STREAM", "1" if dp_mode() == "inline" else "0") == "1"
+        if process_group is not None and self.n_streams > 1 and per_stream:
+            # in-line collectives run on the sub-step streams themselves; two of them may be in flight at once, and one
+            # communicator must never carry two collectives concurrently: one communicator per sub-step stream (every rank
+            # creates them here, in the same order; each stream's collectives are ordered by the stream)
             import torch.distributed as dist
             ranks = list(range(dist.get_world_size(process_group)))
             self.pgs += [dist.new_group(ranks=ranks) for _ in range(self.n_streams - 1)]
@@ -355,7 +375,7 @@ class GanEngine(_Runner):
             prio = (prio + [0] * self.n_streams)[:self.n_streams]
             # main streams, then (early generator forward) one helper stream per main stream
             self.streams = list(_side_streams(dev, prio + (prio if self.early_gen else []), self._tune_streams, S * B))
-            self._tune_x = (None, None)
+            self._tune_x, self._tune_pass = (None, None), {}
             self._use_scratch(0)
         self._res = {}
         self.static_batch = None
@@ -367,9 +387,18 @@ class GanEngine(_Runner):
         if getattr(self, "_tune_x", (None, None))[0] != self._shape:
             S, B = self._shape
             self._tune_x = (self._shape, {m: torch.zeros(S, B, self.G[m].E, device=self.dev) for m in self.modalities})
+            self._tune_pass = {}
+        # slots beyond the modalities (the early-generator helper streams) probe the same networks: every such slot gets pass
+        # buffers of its own, so that concurrent probes never write the same memory
+        if i < len(self.modalities):
+            ps = self.pass_G_nosave[k]
+        else:
+            if i not in self._tune_pass:
+                self._tune_pass[i] = _Pass(self.G[k], self._shape[0], self._shape[1], self.dev, False)
+            ps = self._tune_pass[i]
         self._use_scratch(i)
         for _ in range(1 if self.G[k].E > 256 else 3):                      # (the 512-wide generator is ~3x a 100-wide one)
-            self._net_fwd(self.G[k], self.pass_G_nosave[k], self._tune_x[1][k], train=False, save=False, adds=(0, 1))
+            self._net_fwd(self.G[k], ps, self._tune_x[1][k], train=False, save=False, adds=(0, 1))
 
     def _tune_streams(self, prios, n_cand=6, reps=2):
         """choose one stream per entry of `prios` among n_cand fresh candidates per priority by TIMING them on this engine's
@@ -400,6 +429,17 @@ class GanEngine(_Runner):
                 timed.append((min(probe(group) for _ in range(reps)), c_))
             return min(timed, key=lambda t_: t_[0])[1]
 
+        if self.pg is not None:
+            # RCCL creates its internal stream(s) at the first collective of a communicator; a stream that appears AFTER the
+            # choice below can land on a hardware queue one of the chosen streams uses.  Issue one tiny all-reduce per
+            # communicator first, so that the candidates are timed with RCCL's queue already taken.
+            for g_ in getattr(self, "pgs", [self.pg]):
+                if g_ is not None:
+                    self.dist_warm = torch.zeros(8, device=dev)
+                    import torch.distributed as dist
+                    dist.all_reduce(self.dist_warm, group=g_, async_op=(dp_mode() != "inline"))
+                    if dp_mode() != "inline":
+                        torch.cuda.synchronize(dev)
         torch.cuda.synchronize(dev)
         saved_add = self._base_add
         self._base_add = 0
@@ -535,6 +575,16 @@ class GanEngine(_Runner):
                 self._pre_write(net_key)
                 self._adam(net)
             return None, plain
+        if dp_mode() == "inline":
+            import torch.distributed as dist
+            group = getattr(self, "_cur_pg", None) or self.pg
+
+            def inline(net_key):
+                # on the CURRENT stream (the sub-step's own): sum over ranks, then Adam divides by world (grad_scale)
+                dist.all_reduce(net.grad, op=dist.ReduceOp.SUM, group=group, async_op=False)
+                self._pre_write(net_key)
+                self._adam(net)
+            return None, inline
         red = GradReducer(getattr(self, "_cur_pg", None) or self.pg)
 
         def cb(lo, hi, last):
@@ -882,9 +932,13 @@ class Phase2Engine(GanEngine):
                 self._net_bwd(net, self.pass_G[k], self.d_fusion, True, adds[k], True, cb)
                 finish(("G", k))
             if self.pg is not None:
-                red = GradReducer(self.pg)
-                red.reduce_async(self.fc_grad)
-                red.finish()
+                if dp_mode() == "inline":
+                    import torch.distributed as dist
+                    dist.all_reduce(self.fc_grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=False)
+                else:
+                    red = GradReducer(self.pg)
+                    red.reduce_async(self.fc_grad)
+                    red.finish()
             ops.adam_step_raw(self.fc_slab, self.fc_grad, self.fc_m, self.fc_v, self.fc_step, self.fc_total, self.lr,
                               0.9, 0.999, 1e-8, self.wd, 1.0 / self.world)
         assert self._adds <= 8, self._adds
@@ -957,6 +1011,8 @@ class DrnnEngine(GanEngine):
         self.h_step = torch.zeros(1, dtype=torch.int32, device=dev)
         self.class_w = torch.tensor(class_weights, device=dev, dtype=torch.float32) if class_weights is not None else None
         self.n_streams = max(1, min(3, n_streams))
+        if process_group is not None:
+            self.n_streams = 1           # (one communicator: its in-line collectives must not run on several streams at once)
         self.streams = None                                  # (n_streams > 1: chosen in _prepare5, once the buffers exist)
         self.loss = torch.zeros(1, device=dev)
         self._shape = None
@@ -974,8 +1030,10 @@ class DrnnEngine(GanEngine):
     def _prepare5(self, S, B):
         if self._shape == (S, B):
             return
-        if B > 32:
-            raise ValueError("DrnnEngine: at most 32 dialogues per step (the recurrence's tile); got %d" % B)
+        if B > 32 or S > 112:
+            raise ValueError("DrnnEngine: at most 32 dialogues of at most 112 utterances per step (the recurrence's tile and the "
+                             "attention kernels' sequence limit); got S = %d, B = %d — split the batch, or run the module path "
+                             "(model.GAN_FFN_DialogueRNN under autograd, which chunks by itself)" % (S, B))
         if self._shape is None or S > self._alloc_S or B > self._alloc_B:
             cS = self._cap_S = max(self._cap_S, S)
             cB = self._cap_B = max(self._cap_B, B)
@@ -1043,6 +1101,15 @@ class DrnnEngine(GanEngine):
         a_rec, a_head = self._base_add + 6, self._base_add + 7
         rng = self.rng.state
         umask, qmask = batch["umask"], batch["qmask"]
+        if ops._CHECK_QMASK:
+            # GANFFN_CHECK_QMASK=1 (one host sync per batch): the gate kernels use argmax / max of a qmask row and the lengths
+            # umask.sum(1) — a soft or multi-hot speaker row or a mask with holes would silently differ from the reference
+            row = qmask.sum(2)
+            if not bool((((row == 1) & (qmask.max(2).values == 1)) | (row == 0)).all()):
+                raise ValueError("DrnnEngine: qmask rows must be one-hot (or all zero on padding)")
+            L_ = umask.sum(1).long()
+            if not bool((umask == (torch.arange(S, device=umask.device).unsqueeze(0) < L_.unsqueeze(1)).to(umask.dtype)).all()):
+                raise ValueError("DrnnEngine: umask rows must be prefixes (1 .. 1 0 .. 0)")
         # per-batch index data (tiny): dialogue lengths, speaker index / value per step, in both directions
         lens = umask.sum(1).to(torch.int32)
         spk_f = torch.argmax(qmask, 2).to(torch.int32).contiguous()
@@ -1123,8 +1190,14 @@ class DrnnEngine(GanEngine):
         # ---- head optimizer step (its all-reduce, when data-parallel, runs beside the generators' backward)
         red_h = None
         if self.pg is not None:
-            red_h = GradReducer(self.pg)
-            red_h.reduce_async(self.h_grad)
+            if dp_mode() == "inline":
+                # in-line on this stream (a communicator never carries two collectives at once: the generators' all-reduces
+                # below use the same one)
+                import torch.distributed as dist
+                dist.all_reduce(self.h_grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=False)
+            else:
+                red_h = GradReducer(self.pg)
+                red_h.reduce_async(self.h_grad)
         # ---- three generator backward passes + Adam, concurrently
         if self.streams is not None:
             fork = torch.cuda.Event()

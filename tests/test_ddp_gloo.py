@@ -74,11 +74,27 @@ def _worker(rank, world, port, tmp):
     param = torch.zeros_like(g_local)
     seen = []
 
+    order = []
+
+    class _Waited:
+        """records WHEN a bucket's all-reduce is waited for (the overlap claim: Adam of bucket k is enqueued before bucket
+        k + 1's all-reduce is waited for, so only the last bucket's reduce is exposed)"""
+
+        def __init__(self, work, tag):
+            self.work, self.tag = work, tag
+
+        def wait(self):
+            order.append(("wait", self.tag))
+            return self.work.wait()
+    red.works = [(_Waited(w, (lo, hi)), lo, hi) for (w, lo, hi) in red.works]
+
     def on_bucket(lo, hi):
         seen.append((lo, hi))
+        order.append(("adam", (lo, hi)))
         param[lo:hi] -= 0.1 * g_local[lo:hi] / red.world
     red.finish(on_bucket)
     assert seen == list(ranges) and red.works == []
+    assert order == [step for r_ in ranges for step in (("wait", r_), ("adam", r_))], order
     g_avg = g_local / red.world                       # Adam's grad_scale = 1/world
     assert torch.equal(param, -0.1 * g_avg)           # bucket-wise update == whole-slab update
 

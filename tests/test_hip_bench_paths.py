@@ -57,3 +57,23 @@ def test_bench_other_configs_on_the_rccl_path(config):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "config", "roofline"):
         assert k in d, k
     assert d["value"] > 0 and d["config"]["parallelism"] == "dp1" and 0 < d["roofline"]["frac"] < 1
+
+
+def test_data_parallel_path_costs_nothing_at_one_rank():
+    """the N = 1 point of the scaling curve: the data-parallel code path (1-rank RCCL group: in-line all-reduce of every
+    sub-step's gradient slab on the sub-step's own stream, one communicator per stream) against the plain engine, 3 streams,
+    step only, best of two interleaved runs each: within 3 %.  Rounds 1-3 issued 4-5 asynchronous
+    all-reduces per sub-step on the process group's internal stream: 18-75 % slower at one rank (tools/dist1_ab.sh)."""
+    def run(dist, port):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if dist:
+            env.update(GANFFN_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--step-only", "--steps", "10"],
+                           capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return _last_json(r.stdout)["ms_per_step"]
+    plain, dist1 = [], []
+    for i in range(2):
+        plain.append(run(False, 0))
+        dist1.append(run(True, 29601 + i))
+    assert min(dist1) <= 1.03 * min(plain), (plain, dist1)
