@@ -316,3 +316,29 @@ def test_engines_of_one_process_share_their_side_streams():
     assert handles[0] == handles[1]
     key = (str(eng.dev), (0, 0, -1))
     assert engine._STREAMS[key][1] >= 94 * 8 or handles[2] == handles[0]
+
+
+def test_two_engines_over_the_same_networks_need_a_synchronize():
+    """Two eager 3-stream engines built over the SAME six networks share the process's side streams but each keeps its own
+    dependency records (and its own Adam state: engine._side_streams docstring).  With `synchronize()` between them the
+    hand-over is race-free: the sequence "two iterations by engine A, synchronize, two by engine B" gives the same bits
+    every time it is run from the same state and dropout seed."""
+    from gan_ffn_amd import engine, ops
+    batch = gan_batch(S=11, B=2)
+    out = []
+    for rep in range(2):
+        gens, discs = build_all(zero_dropout=False)
+        ops.manual_seed(4321)
+        a = engine.GanEngine(gens, discs, n_streams=3)
+        b = engine.GanEngine(gens, discs, n_streams=3)
+        for i in range(4):
+            (a if i < 2 else b).iteration(batch)
+            if i == 1:
+                a.synchronize()            # the contract: before another engine touches the same networks
+                torch.cuda.synchronize()
+        b.synchronize()
+        torch.cuda.synchronize()
+        out.append({k: m.slab.detach().cpu().clone() for k, m in list(gens.items()) + [("D" + k, v) for k, v in discs.items()]})
+        assert all(bool(torch.isfinite(v).all()) for v in out[-1].values())
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k

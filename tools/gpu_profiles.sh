@@ -23,10 +23,12 @@ bash tools/traffic_pmc.sh wgrad > $O/traffic_wgrad.log 2>&1 || { tail -20 $O/tra
 bash tools/traffic_pmc.sh gemm_generic > $O/traffic_gemm.log 2>&1 || { tail -20 $O/traffic_gemm.log; exit 1; }
 cp $O/r04_wgrad_traffic.json $O/r04_gemm_traffic.json profiles/
 bash tools/attention_pmc.sh > $O/attention_pmc.log 2>&1 || { tail -30 $O/attention_pmc.log; exit 1; }
-python3 tools/general2_line.py > $O/r04_general2_line.txt 2>&1 || tail -5 $O/r04_general2_line.txt
+( cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_g2 -- python3 $R/tools/lab/general2_prof.py > $O/prof_g2.log 2>&1 )
+python3 tools/general2_line.py $(ls $O/prof_g2/*/*kernel_stats.csv | head -1) > $O/r04_general2_line.txt
+rm -rf $O/prof_g2
 timeout -k 10 600 python bench.py > $O/r04_bench_default.json 2> $O/r04_bench_default.err || { tail -20 $O/r04_bench_default.err; exit 1; }
-timeout -k 10 300 python bench.py --config meld > $O/r04_bench_meld.json 2> $O/r04_bench_meld.err || { tail -20 $O/r04_bench_meld.err; exit 1; }
-timeout -k 10 300 python bench.py --config drnn > $O/r04_bench_drnn.json 2> $O/r04_bench_drnn.err || { tail -20 $O/r04_bench_drnn.err; exit 1; }
+timeout -k 10 300 python bench.py --config meld --no-cpu-baseline > $O/r04_bench_meld.json 2> $O/r04_bench_meld.err || { tail -20 $O/r04_bench_meld.err; exit 1; }
+timeout -k 10 300 python bench.py --config drnn --no-cpu-baseline > $O/r04_bench_drnn.json 2> $O/r04_bench_drnn.err || { tail -20 $O/r04_bench_drnn.err; exit 1; }
 python3 - <<'PY'
 import json
 d = json.loads([l for l in open("gpurun_out/r04_bench_default.json") if l.startswith("{")][0])
@@ -34,4 +36,5 @@ print("ms/step", d["ms_per_step"], "roofline", d["roofline"]["family"], d["roofl
 for f in d["roofline_families"]:
     print(" ", f["family"], f.get("share_pct"), "in-step", f.get("in_step_frac"), "live", f["frac"], f.get("avg_kernel_us"))
 print("worst", d["roofline_worst"]["family"], "cpu", d.get("cpu_baseline", {}).get("value"))
+print(open("gpurun_out/r04_general2_line.txt").read()[-600:])
 PY
