@@ -38,3 +38,18 @@ for f in d["roofline_families"]:
 print("worst", d["roofline_worst"]["family"], "cpu", d.get("cpu_baseline", {}).get("value"))
 print(open("gpurun_out/r04_general2_line.txt").read()[-600:])
 PY
+# training-level statistical parity table (tests/test_hip_train_stats.py asserts on it; this is the record for profiles/)
+python3 tests/golden/make_train_stats.py hip > $O/train_stats_hip.log 2>&1 || { tail -20 $O/train_stats_hip.log; exit 1; }
+python3 - <<'PY' > gpurun_out/r04_train_stats.txt
+import numpy as np
+c, h = np.load("tests/golden/train_stats.npz"), np.load("gpurun_out/train_stats_hip.npz")
+names, cpu, hip = [str(x) for x in c["names"]], c["cpu"], h["hip"]
+n = cpu.shape[0]
+print("training-level statistical parity, %d seeds each: stock PyTorch on the host (tests/golden/train_stats.npz) | HIP engines on the MI355X" % n)
+print("%-34s %10s %8s | %10s %8s | %s" % ("metric", "cpu mean", "std", "hip mean", "std", "|diff| / standard error"))
+for j, k in enumerate(names):
+    se = np.sqrt(cpu[:, j].var(ddof=1) / n + hip[:, j].var(ddof=1) / n)
+    print("%-34s %10.4f %8.4f | %10.4f %8.4f | %.2f" % (k, cpu[:, j].mean(), cpu[:, j].std(ddof=1), hip[:, j].mean(), hip[:, j].std(ddof=1),
+                                                        abs(cpu[:, j].mean() - hip[:, j].mean()) / max(se, 1e-12)))
+PY
+tail -12 gpurun_out/r04_train_stats.txt
