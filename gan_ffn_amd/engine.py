@@ -1090,6 +1090,28 @@ class DrnnEngine(GanEngine):
         Returns (loss tensor, log_prob (S,B,C)).  train=False: forward + loss only (model.eval())."""
         S, B = batch["text"].shape[:2]
         self._prepare5(S, B)
+        if self.streams is None:
+            return self._step(batch, train)
+        # n_streams = 3: the WHOLE step runs on the tuned streams — the visual generator's stream carries the recurrence and
+        # the head as well, the two 100-wide generators run beside it — and the caller's stream only waits at both ends
+        # (round 3 ran the recurrence on the caller's stream, a fourth stream the tuner had not chosen).  Section timing
+        # (tools/lab/drnn_sections.py, gpurun_out/r4_drnn_sections*.txt): the three generators' forward 3.75 -> 3.3 ms and
+        # backward + Adam 5.69 -> 4.9 ms on three streams, but the recurrence + head — a chain of ~400 latency-sized launches —
+        # 5.84 -> 6.3-7.3 ms as soon as the process has several active hardware queues, whichever stream it runs on:
+        # 14.45-15.6 ms against 14.8-15.3 on one stream depending on the box.  One stream stays the default.
+        cur = torch.cuda.current_stream()
+        main = self.streams[1]
+        main.wait_stream(cur)
+        for t_ in batch.values():
+            if torch.is_tensor(t_) and t_.is_cuda:
+                t_.record_stream(main)
+        with torch.cuda.stream(main):
+            out = self._step(batch, train)
+        cur.wait_stream(main)
+        return out
+
+    def _step(self, batch, train=True):
+        S, B = batch["text"].shape[:2]
         self._check_slabs()
         if self._hparams[0].data_ptr() != self.h_slab.data_ptr():
             raise RuntimeError("the DialogueRNN head was re-allocated after the engine was built: build DrnnEngine after the last .to()")
@@ -1129,7 +1151,7 @@ class DrnnEngine(GanEngine):
             fork.record(cur)
         for i, k in enumerate(keys):
             self.ws = self.ws3[k]
-            if self.streams is not None:
+            if self.streams is not None and self.streams[i].cuda_stream != cur.cuda_stream:
                 self.streams[i].wait_event(fork)
                 if batch[k].is_cuda:
                     batch[k].record_stream(self.streams[i])      # the caller may drop the batch while this stream still reads it
@@ -1139,7 +1161,8 @@ class DrnnEngine(GanEngine):
                 adds[k] = self._net_fwd(self.G[k], self.pass_G[k], batch[k], train=train, save=train)
         if self.streams is not None:
             for s_ in self.streams:
-                cur.wait_stream(s_)
+                if s_.cuda_stream != cur.cuda_stream:
+                    cur.wait_stream(s_)
         st = st_()
         _lib.call("ganffn_add3", P(self.pass_G["acoustic"].out), P(self.pass_G["visual"].out), P(self.pass_G["text"].out),
                   P(f["fusion"]), C.c_int64(T * Dm), st)
@@ -1211,7 +1234,7 @@ class DrnnEngine(GanEngine):
                 cb, finish = self._make_reducer(net)
                 self._net_bwd(net, self.pass_G[k], d_fusion, True, adds[k], True, cb)
                 finish(("G", k))
-            if self.streams is not None:
+            if self.streams is not None and self.streams[i].cuda_stream != cur.cuda_stream:
                 self.streams[i].wait_event(fork)
                 with torch.cuda.stream(self.streams[i]):
                     bwd()
@@ -1223,7 +1246,8 @@ class DrnnEngine(GanEngine):
                           self.wd, 1.0 / self.world)
         if self.streams is not None:
             for s_ in self.streams:
-                cur.wait_stream(s_)
+                if s_.cuda_stream != cur.cuda_stream:
+                    cur.wait_stream(s_)
         assert self._adds <= 6, self._adds
         return self.loss, log_prob
 
