@@ -25,6 +25,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+L2_SERVED_GBS = 16800.0         # same guide, "Indexed rows: gather into LDS": rows served from the XCDs' L2s, 16.8-18.8 TB/s chip-wide (lower bound)
 FP32_MFMA_PEAK = 157.3e12      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 # algorithmic FLOPs of one iteration per padded token at S = 94: fwd 409.5 + bwd 544.8 MFLOP
 FLOP_PER_TOKEN_ITER = 954.3e6
@@ -528,10 +529,15 @@ def run_drnn(args, dev, pg, rank, world):
                          "frac": round(kbytes / kt / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": round(kbytes), "avg_kernel_us": round(kt * 1e6, 2),
                          "in_step_avg_us": in_step, "frac_in_step": round(kbytes / (in_step * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if in_step else None,
+                         "l2_served_peak": L2_SERVED_GBS, "frac_of_l2_served_peak": round(kbytes / kt / 1e9 / L2_SERVED_GBS, 4),
+                         "frac_of_l2_served_peak_in_step": round(kbytes / (in_step * 1e-6) / 1e9 / L2_SERVED_GBS, 4) if in_step else None,
                          "how": "HIP events around 20 back-to-back launches on the launch stream (in_step_avg_us: the same "
-                                "kernel inside the step, from the committed rocprofv3 summary); the 24 MB of weights stay "
-                                "L2 / MALL-resident between launches, so the bound that applies is the L2 -> CU path, priced "
-                                "here against the HBM peak as the contract asks"}}), flush=True)
+                                "kernel inside the step, from the committed rocprofv3 summary).  The 24 MB of recurrent weights are "
+                                "re-read every step by the same workgroup ids, i.e. each XCD re-reads its own 3 MB eighth out of its "
+                                "4 MiB L2: the roof that applies is the L2 -> CU path (MI355X_MICROARCH.md 'Indexed rows': 16.8-18.8 "
+                                "TB/s chip-wide for rows served from L2) — frac_of_l2_served_peak; `frac` against the HBM peak is "
+                                "what the contract's bound key offers.  Either way the launch is latency-sized (one link of a "
+                                "serial chain of ~400)"}}), flush=True)
 
 
 def host_threads():
