@@ -915,7 +915,8 @@ static int launch_pick(const GemmArgs& g, int splits, hipStream_t st) {
             return launch_wres<MODE, EPI>(g, st);
     if (g.K <= 128) return launch_cfg<MODE, 64, 64, 16, EPI, 2, 2, 1>(g, splits, st);
     // (64 x 128 tiles for the N = 2048, K = 512 products: 5-9 % faster in isolation, round 2; in the 3-stream step 35.9 against
-    // 35.7 ms with 64 x 64 — fewer, fatter workgroups co-run worse — so they are not used; round 3, tools/lab/mode_ab.py)
+    // 35.7 ms with 64 x 64 — fewer, fatter workgroups co-run worse — so they are not used; round 3, tools/lab/mode_ab.py;
+    // re-measured in round 4 with tuned streams and the XCD-aware tile order: 34.71 against 34.43 ms, three interleaved runs each)
     return launch_cfg<MODE, 64, 64, 16, EPI>(g, splits, st);
 }
 
