@@ -613,6 +613,8 @@ def main():
     from gan_ffn_amd import _lib, engine, ops
     if args.config == "drnn":
         _lib.load()
+        if os.environ.get("GANFFN_FFN_MODE"):
+            _lib.load().ganffn_debug_set_ffn_mode(int(os.environ["GANFFN_FFN_MODE"]))
         run_drnn(args, dev, pg, rank, world)
         if pg is not None:
             dist.barrier()

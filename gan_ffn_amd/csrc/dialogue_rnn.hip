@@ -59,6 +59,9 @@ struct SkinnyGroup {
 // (k block of 16 per 4 MFMAs: step i contracts k = kb + 4g + i, identically on both operands).
 // A launch is one link of a serial chain, so what counts is its latency: every load of a chunk of SK_NT k-blocks (a
 // wave's whole K range in both uses) is issued before the first MFMA — one memory round trip (10.9 -> 9.9 us in-step).
+// (Round 4: two weight tiles per workgroup — 4 loads per 4 MFMA groups instead of 3 per 2, half the workgroups, a third
+// less L2 traffic — measured SLOWER: configuration 5 15.07 against 14.80 ms, three interleaved runs each.  The launch is not
+// L2-bandwidth-sized; fewer, fatter waves lengthen the one round trip it consists of.)
 constexpr int SK_NT = 8;
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void skinny_nt_kernel(SkinnyGroup grp) {
