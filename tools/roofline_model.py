@@ -19,8 +19,17 @@ HBM_PEAK = 8.0e12              # B/s
 L, F = 8, 2048
 
 
+def _code_only(text):
+    """source text without comments and whitespace: the hash below identifies CODE, so that editing a comment does not make
+    a committed profile look stale"""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return re.sub(r"\s+", "", text)
+
+
 def csrc_sha16():
-    """sha256 (first 16 hex digits) over the kernel sources, in name order: identifies what a profile was taken on"""
+    """sha256 (first 16 hex digits) over the kernel sources' code (comments and whitespace stripped), in name order:
+    identifies what a profile was taken on"""
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = os.path.join(root, "gan_ffn_amd", "csrc")
@@ -28,8 +37,8 @@ def csrc_sha16():
     for n in sorted(os.listdir(d)):
         if n.endswith((".hip", ".h")):
             h.update(n.encode())
-            h.update(open(os.path.join(d, n), "rb").read())
-    h.update(open(os.path.join(root, "include", "ganffn.h"), "rb").read())
+            h.update(_code_only(open(os.path.join(d, n)).read()).encode())
+    h.update(_code_only(open(os.path.join(root, "include", "ganffn.h")).read()).encode())
     return h.hexdigest()[:16]
 
 
