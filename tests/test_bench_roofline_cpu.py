@@ -81,3 +81,13 @@ def test_bench_line_fractions_follow_the_committed_profile():
     step = line["config"]["step_frac_of_fp32_mfma_peak"]
     assert 0.3 < step < 1.0
     assert abs(step - 954.3e6 * 94 * 32 / (line["ms_per_step"] * 1e-3) / RM.FP32_MFMA_PEAK) < 5e-3
+
+
+@needs_profiles
+def test_committed_profiles_were_taken_on_the_kernel_code_in_the_tree():
+    """the in-step figures of the bench line come from these summaries; their header carries a hash of the kernel sources'
+    CODE (comments and whitespace stripped) — a kernel change without a fresh profile fails here, and bench.py would flag the
+    in-step fields as stale"""
+    assert RM.summary_sha(SUMMARY) == RM.csrc_sha16()
+    drnn = os.path.join(ROOT, "profiles", "r04_drnn_by_launch_shape.txt")
+    assert RM.summary_sha(drnn) == RM.csrc_sha16()
