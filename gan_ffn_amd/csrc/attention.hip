@@ -101,6 +101,9 @@ __device__ __forceinline__ void load_heads(const HeadSrc (&m)[NM], const AttnGeo
         constexpr int NTH = 64 * NT;
         constexpr int U = (PER + NTH - 1) / NTH;      // items per thread per matrix
         float v[NM][U][VEC];
+        // load phase: every load unconditional, from clamped addresses, and nothing else (round 4: the `ok ? q : 0` selects
+        // written here before were compiled into loads under exec-mask branches with an `s_waitcnt vmcnt(0)` behind many of
+        // them — 7 load phases in the forward of the head_dim-64 kernel, 16 in its backward instead of one round trip)
 #pragma unroll
         for (int mi = 0; mi < NM; ++mi) {
 #pragma unroll
@@ -108,17 +111,18 @@ __device__ __forceinline__ void load_heads(const HeadSrc (&m)[NM], const AttnGeo
                 const int i = min(tid + u * NTH, PER - 1);
                 const int s = i / PR, d = (i - s * PR) * VEC;
                 const float* src = m[mi].src + (size_t)(min(s, g.S - 1) * g.B + b) * m[mi].ld_src + d;
-                const bool ok = s < g.S;
                 if constexpr (VEC == 4) {
                     const float4 q = *reinterpret_cast<const float4*>(src);
-                    v[mi][u][0] = ok ? q.x : 0.f; v[mi][u][1] = ok ? q.y : 0.f;
-                    v[mi][u][2] = ok ? q.z : 0.f; v[mi][u][3] = ok ? q.w : 0.f;
+                    v[mi][u][0] = q.x; v[mi][u][1] = q.y; v[mi][u][2] = q.z; v[mi][u][3] = q.w;
                 } else {
                     const float2 q = *reinterpret_cast<const float2*>(src);
-                    v[mi][u][0] = ok ? q.x : 0.f; v[mi][u][1] = ok ? q.y : 0.f;
+                    v[mi][u][0] = q.x; v[mi][u][1] = q.y;
                 }
             }
         }
+        // fence both ways: the memory clobber keeps every load above, the stores' 0 / scale factor comes out of the asm
+        float one = 1.f;
+        asm volatile("" : "+v"(one) : : "memory");
 #pragma unroll
         for (int mi = 0; mi < NM; ++mi) {
 #pragma unroll
@@ -126,8 +130,9 @@ __device__ __forceinline__ void load_heads(const HeadSrc (&m)[NM], const AttnGeo
                 const int i = tid + u * NTH;
                 if (PER % NTH == 0 || i < PER) {
                     const int s = i / PR, d = (i - s * PR) * VEC;
+                    const float f = (s < g.S ? one : 0.f) * m[mi].scale;      // rows >= S: zero (finite operand x 0)
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) m[mi].dst[s * g.LDH + d + e] = v[mi][u][e] * m[mi].scale;
+                    for (int e = 0; e < VEC; ++e) m[mi].dst[s * g.LDH + d + e] = v[mi][u][e] * f;
                 }
             }
         }

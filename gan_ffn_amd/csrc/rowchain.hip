@@ -399,9 +399,15 @@ __global__ __launch_bounds__(256) void rc_bwd_kernel(RcBwdArgs a) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) v[j][i] = f4(ds + f0c[i]);
             }
+            // (hipcc otherwise sinks the later slabs' loads to their adds — one register set re-used, one global round trip
+            // per slab: the ISA of rc_bwd_kernel<1, true> had four `global_load, s_waitcnt vmcnt(0)` pairs in a row.  The
+            // empty asm is a fence both ways: its memory clobber keeps every load above it, and the adds below take their
+            // 0 / 1 factor from its output, so none of them can move up between the loads.)
+            float one = 1.f;
+            if (NB > 1) asm volatile("" : "+v"(one) : : "memory");
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const float m = (s0 + j < ns) ? 1.f : 0.f;
+                const float m = (s0 + j < ns) ? one : 0.f;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     d4[i].x += m * v[j][i].x; d4[i].y += m * v[j][i].y; d4[i].z += m * v[j][i].z; d4[i].w += m * v[j][i].w;
