@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — utterances/sec per GAN train step (BASELINE.json metric) on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 60 --warmup 30
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -562,8 +562,10 @@ def host_threads():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: 30 untimed + 60 timed iterations (~3 s of GPU time): the clocks of an idle MI355X need a few hundred ms of load
+    # to settle — measured on one box: 3 + 20 iterations 34.39 / 34.55 ms per step, 30 + 60: 34.33 / 34.33, 100 + 100: 34.33 / 34.25
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=32, help="dialogues per GPU (reference hard-codes 32, train_IEMOCAP.py:603)")
     ap.add_argument("--seq", type=int, default=None, help="padded dialogue length S (default 94, model.py:1437; "
                     "--config meld: 33, MELD's longest dialogue [public, not stated by the reference])")

@@ -14,8 +14,8 @@ prof() {   # name, bench arguments...
   cp $(ls $O/prof_$n/*/*kernel_stats.csv | head -1) $O/r04_${n}_kernel_stats.csv
   rm -rf $O/prof_$n
 }
-prof bench_streams1 --streams 1 --no-graph --steps 10 --step-only
-prof bench_default --steps 10 --step-only
+prof bench_streams1 --streams 1 --no-graph --warmup 3 --steps 10 --step-only
+prof bench_default --warmup 3 --steps 10 --step-only
 ITER=70 prof drnn --config drnn --steps 10        # (60 warm-up steps + 10 timed)
 cd $R
 cp $O/r04_bench_streams1_by_launch_shape.txt $O/r04_drnn_by_launch_shape.txt profiles/    # bench.py reads its in-step figures from profiles/
