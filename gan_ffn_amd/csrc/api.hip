@@ -111,6 +111,10 @@ static int check_cfg(const ganffn_enc_cfg* c) {
 // kernel streams 30 KB of packed weights per (32 tokens x 32 hidden units) and is bound by L2 -> CU bandwidth
 // (357 MB per launch at T = 6016), so it stays opt-in.
 int g_ffn_fused = 0;
+// bit 7 of ganffn_debug_set_ffn_mode: the forward feed-forward block of d_model 100 as ffn3.hip's single kernel (opt-in:
+// 34.6 against 43.8 us in isolation, nothing in the three-stream step — the measurement is in ffn3.hip's header)
+int g_ffn3 = 0;
+int g_ffn3_wide = 0;   // bit 22: also at T > 4096 (the 128-token variant)
 // d_model = 100: the token-local chains around the LayerNorms run as single kernels (rowchain.hip); bit 1 of
 // ganffn_debug_set_ffn_mode switches back to the separate GEMM + LayerNorm launches (both paths are parity-tested)
 int g_rc_off = 0;
@@ -122,7 +126,7 @@ int g_n100_off = 0;
 int g_dhead_off = 0;
 // bit 6: positional encoding + dropout and layer 0's in-proj as two launches instead of rowchain.hip's one
 int g_pe_off = 0;
-extern int g_n100_force_splits, g_n100_force_kw;
+extern int g_n100_force_splits, g_n100_force_kw, g_n100_pad7;
 extern int g_tn100_off, g_tn100_force_splits, g_tn100_in_kernel_sum;
 GF_LAB_ONLY(extern unsigned long long* g_n100_stamps; extern unsigned long long* g_wres_stamps;)
 constexpr int MAX_SPLITS = 16;  // partial-output slabs: fused FFN (16 F splits) / split-K GEMMs (<= 8)
@@ -269,7 +273,10 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
         }
         // FFN: h = drop(relu(x1 W1^T + b1)); y = h W2^T + b2
         int splits = 1;
-        if (fused) {
+        if (g_ffn3 && ffn3_supported(E, F) && (T <= 4096 || g_ffn3_wide)) {
+            GF_TRY(launch_ffn3_fwd(sv + so.x1, P + lo.w1, P + lo.b1, P + lo.w2, P + lo.b2, saved ? sv + so.h : nullptr, tmp, TE, T,
+                                   c->p_enc, site + 2, rng, add, train, MAX_SPLITS, &splits, st));
+        } else if (fused) {
             // one kernel; the hidden tile feeds linear2 from registers; h is streamed out only when backward needs it
             GF_TRY(launch_ffn_fused_fwd(sv + so.x1, pack + (int64_t)l * PK, P + lo.b1, P + lo.b2, saved ? sv + so.h : nullptr,
                                         tmp, TE, T, E, F, c->p_enc, site + 2, rng, add, train, &splits, st));
@@ -693,6 +700,9 @@ extern "C" int ganffn_debug_set_ffn_mode(int bits) {
     g_n100_off = (bits & 4) ? 1 : 0;
     g_dhead_off = (bits & 32) ? 1 : 0;
     g_pe_off = (bits & 64) ? 1 : 0;
+    g_ffn3 = (bits & 128) ? 1 : 0;
+    g_ffn3_wide = (bits & (1 << 22)) ? 1 : 0;
+    g_n100_pad7 = (bits & (1 << 23)) ? 1 : 0;
     g_tn100_off = (bits & 8) ? 1 : 0;
     g_tn100_in_kernel_sum = (bits & 16) ? 1 : 0;
     g_tn100_force_splits = (bits >> 16) & 0xF;      // lab: force the token-chunk count of the d_model-100 grouped wgrad (0 = choose)
@@ -719,6 +729,13 @@ extern "C" int ganffn_ffn_fused_bwd(const float* dy, const float* w1, const floa
     int splits = 0;
     GF_TRY(launch_ffn_fused_bwd(dy, pack_ws, h, dh, slabs, (long)T * E, T, E, F, mscale, &splits, st));
     return -1000 - splits;
+}
+extern "C" int ganffn_ffn3_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h, float* slabs,
+                               int64_t slab_stride, int T, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
+                               int max_slabs, int* n_slabs, void* stream) {
+    GF_CHECK_ARG(n_slabs && max_slabs >= 1 && max_slabs <= MAX_SPLITS, "ffn3_fwd: max_slabs=%d out of [1,%d]", max_slabs, MAX_SPLITS);
+    return launch_ffn3_fwd(x, w1, b1, w2, b2, h, slabs, (long)slab_stride, T, p, site, rng, add, train, max_slabs, n_slabs,
+                           (hipStream_t)stream);
 }
 extern "C" int64_t ganffn_ffn_pack_floats(int F) { return ffn_pack_floats(F); }
 extern "C" int64_t ganffn_gemm_tn_grouped_workspace_floats(void) { return gemm_tn_grouped_part_floats(); }

@@ -234,6 +234,14 @@ int launch_ffn_fused_fwd(const float* x, const float* packed, const float* b1, c
 int launch_ffn_fused_bwd(const float* dy, const float* packed, const float* h, float* dh, float* slabs, long slab_stride, int T,
                          int E, int F, float mscale, int* splits_out, hipStream_t st);
 
+// feed-forward block of the d_model-100 networks as one forward kernel (ffn3.hip): 64 tokens x one hidden chunk per
+// workgroup, the hidden tile goes from product 1 to product 2 in registers; partial y per hidden chunk in slabs
+bool ffn3_supported(int E, int F);
+int ffn3_chunks(int T, int max_slabs);
+int launch_ffn3_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h, float* slabs,
+                    long slab_stride, int T, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, int max_slabs,
+                    int* splits_out, hipStream_t st);
+
 // grouped wgrad: n independent TN problems in one launch
 struct TnDesc {
     const float* At; int lda;

@@ -4,8 +4,8 @@
 // Why its own kernel: on the generic 64 x 64 tiles (gemm.hip) a 100-wide output is two column tiles = 128 columns, 22 %
 // of every MFMA is padding, and the shape ran at 36-45 % of the fp32 MFMA peak (profiles/r02_*: 22 us at T = 3008, 35 us at
 // T = 6016 for 7.9 / 15.7 us of arithmetic).  Here:
-//  * v_mfma_f32_16x16x4_f32 (exact fp32) with the output FEATURE on the m axis: 100 features = 7 tiles of 16 = 112
-//    (10.7 % padding instead of 22 %);
+//  * v_mfma_f32_16x16x4_f32 (exact fp32) with the output FEATURE on the m axis: 100 features = 6 tiles of 16 + 4 features on
+//    v_mfma_f32_4x4x1_16B_f32 (round 4, TAIL4 below: no padding; until then a seventh tile, 112 = 10.7 % padding);
 //  * a wave owns ALL 7 feature tiles of 16 tokens: the 7 MFMAs of a k-step share the token operand, 8 operand registers
 //    feed 7 MFMAs (the 32 x 32 single-accumulator wave tile of the generic kernel needs 2 per MFMA);
 //  * a workgroup = 4 waves = 64 tokens; K is cut into 4..16 chunks (one output slab each, summed in slab order by the
@@ -46,7 +46,11 @@ struct N100Args {
                                                // after the prologue, after the K loop, at exit}
 };
 
-template <bool WKMAJOR, int KW>
+// TAIL4: features 96..99 on v_mfma_f32_4x4x1_16B_f32 (16 blocks of 4 x 4, k = 1, 8 cycles) instead of a seventh 16-wide tile
+// that is three quarters padding (32 cycles): block b = 4 g + c / 4 holds (tokens 4 (c / 4) .. + 3) x (features 96 .. 99) for
+// the k values of lane group g — exactly what lane (c, g) already supplies as the token operand — so a 16-wide k group costs
+// 24 x 32 + 4 x 8 = 800 MFMA cycles instead of 896; the four lane groups' partial sums meet in the epilogue (two shuffles).
+template <bool WKMAJOR, int KW, bool TAIL4>
 __global__ __launch_bounds__(256 * KW) void gemm_n100_kernel(N100Args a) {
     static_assert(KW == 1 || KW == 2, "one or two waves per token group along K");
     constexpr int NTHR = 256 * KW;
@@ -140,11 +144,12 @@ __global__ __launch_bounds__(256 * KW) void gemm_n100_kernel(N100Args a) {
             const int q = KW == 2 ? khalf : qi;
 #pragma unroll
             for (int m = 0; m < NT7; ++m) {
+                const int wr = (TAIL4 && m == NT7 - 1) ? 96 + (c & 3) : 16 * m + c;       // weight row (feature) this lane supplies
                 if (WKMAJOR) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) wv[qi][m][j] = s[(16 * q + 4 * g + j) * LDWK + 16 * m + c];
+                    for (int j = 0; j < 4; ++j) wv[qi][m][j] = s[(16 * q + 4 * g + j) * LDWK + wr];
                 } else {
-                    const float4 v = *reinterpret_cast<const float4*>(s + sw32(16 * m + c, 4 * q + g));
+                    const float4 v = *reinterpret_cast<const float4*>(s + sw32(wr, 4 * q + g));
                     wv[qi][m][0] = v.x; wv[qi][m][1] = v.y; wv[qi][m][2] = v.z; wv[qi][m][3] = v.w;
                 }
             }
@@ -155,7 +160,10 @@ __global__ __launch_bounds__(256 * KW) void gemm_n100_kernel(N100Args a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int m = 0; m < NT7; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[qi][m][j], bq[j], acc[m], 0, 0, 0);
+                for (int m = 0; m < NT7; ++m) {
+                    if (TAIL4 && m == NT7 - 1) acc[m] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[qi][m][j], bq[j], acc[m], 0, 0, 0);
+                    else acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[qi][m][j], bq[j], acc[m], 0, 0, 0);
+                }
         }
     };
     GF_N100_GLOAD(A, 0)
@@ -205,6 +213,16 @@ __global__ __launch_bounds__(256 * KW) void gemm_n100_kernel(N100Args a) {
             acc[m][0] += o.x; acc[m][1] += o.y; acc[m][2] += o.z; acc[m][3] += o.w;
         }
     }
+    if constexpr (TAIL4) {
+        // features 96..99: register r of every lane group holds the partial sum over ITS k values of (token c, feature 96 + r)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[NT7 - 1][r];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[NT7 - 1][r] = v;
+        }
+    }
     const int tok = m0 + wave * 16 + c;
     if (tok < a.T) {
         float* crow = a.C + (size_t)z * a.slab_stride + (size_t)tok * NE;
@@ -227,6 +245,7 @@ __global__ __launch_bounds__(256 * KW) void gemm_n100_kernel(N100Args a) {
 }  // namespace
 
 int g_n100_force_splits = 0;      // lab knob (ganffn_debug_set_ffn_mode bits 8..15): 0 = choose
+int g_n100_pad7 = 0;              // lab knob (bit 23): features 96..99 on a padded seventh 16-wide tile (round 3's form)
 int g_n100_force_kw = 0;          // lab knob (bits 20..21): 0 = choose, 1 = four waves per workgroup, 2 = eight (two per K tile)
 GF_LAB_ONLY(unsigned long long* g_n100_stamps = nullptr;)   // lab builds only: device buffer for in-kernel time stamps
 
@@ -281,12 +300,15 @@ int launch_gemm_n100(const float* A, int lda, const float* W, int ldw, int w_kma
     N100Args a{A, lda, W, ldw, bias, C, slab_stride, T, K, per * NBK GF_LAB_ONLY(, g_n100_stamps)};
     const dim3 grid((T + NBM - 1) / NBM, s);
     const int kw = g_n100_force_kw ? g_n100_force_kw : n100_kw(T, s);
-    if (kw == 2) {
-        if (w_kmajor) hipLaunchKernelGGL((gemm_n100_kernel<true, 2>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((gemm_n100_kernel<false, 2>), grid, dim3(512), 0, st, a);
+    if (kw == 2 && !g_n100_pad7) {
+        if (w_kmajor) hipLaunchKernelGGL((gemm_n100_kernel<true, 2, true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((gemm_n100_kernel<false, 2, true>), grid, dim3(512), 0, st, a);
+    } else if (kw == 2) {
+        if (w_kmajor) hipLaunchKernelGGL((gemm_n100_kernel<true, 2, false>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((gemm_n100_kernel<false, 2, false>), grid, dim3(512), 0, st, a);
     } else {
-        if (w_kmajor) hipLaunchKernelGGL((gemm_n100_kernel<true, 1>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gemm_n100_kernel<false, 1>), grid, dim3(256), 0, st, a);
+        if (w_kmajor) hipLaunchKernelGGL((gemm_n100_kernel<true, 1, false>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_n100_kernel<false, 1, false>), grid, dim3(256), 0, st, a);
     }
     GF_LAUNCH_CHECK();
     return 0;

@@ -5,7 +5,9 @@
 // TransformerEncoderLayer).  On the 64 x 64 tiles of gemm.hip that dimension is 2 tiles = 128: 22 % of every MFMA of the
 // launch that dominates the step's GPU time is padding (profiles/r02_*: 447 us per launch, 49 % of the fp32 MFMA peak on
 // useful FLOPs although the MFMAs it executes run at 80 %).  Here, as in gemm_n100.hip:
-//  * v_mfma_f32_16x16x4_f32 (exact fp32) with the 100-wide dimension on the m axis: 7 tiles of 16 = 112 (10.7 % padding);
+//  * v_mfma_f32_16x16x4_f32 (exact fp32) with the 100-wide dimension on the m axis: 6 tiles of 16 + rows 96..99 on
+//    v_mfma_f32_4x4x1_16B_f32 (round 4, TAIL4: 461.6 against 491.3 us per launch at T = 6016, 246.4 against 261.3 us at
+//    T = 3008 — tools/lab/tn100_tail4.py; until then a seventh tile: 112 = 10.7 % padding);
 //  * a wave owns all 7 of them for 16 columns of the other dimension: the 7 MFMAs of a k-step share one operand;
 //  * a workgroup = 4 waves = a 112 x 64 output tile; k = the token axis, read from LDS tiles of 32 tokens (both operands
 //    are token-major, so both are read with ds_read_b32; row strides 116 / 68 floats put rows 4 apart 16 banks apart);
@@ -53,6 +55,9 @@ struct W100Group {
     int* counters;                             // per (problem, tile) arrival tickets, zero at launch; null: separate reduce launch
 };
 
+// TAIL4 (gemm_n100.hip): rows 96..99 of the 100-wide dimension on v_mfma_f32_4x4x1_16B_f32 (8 cycles) instead of a seventh
+// 16-row tile that is three quarters padding (32 cycles); bit 23 of ganffn_debug_set_ffn_mode restores the padded tile
+template <bool TAIL4>
 __global__ __launch_bounds__(256) void tn100_kernel(W100Group grp) {
     constexpr int UT = WBK * LDU, STAGE = UT + WBK * LDV;
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 4];
@@ -152,12 +157,15 @@ __global__ __launch_bounds__(256) void tn100_kernel(W100Group grp) {
                 const int kr = 16 * half + 4 * g + j;
                 bv[j] = sv[kr * LDV];
 #pragma unroll
-                for (int m = 0; m < WT7; ++m) av[j][m] = su[kr * LDU + 16 * m];
+                for (int m = 0; m < WT7; ++m) av[j][m] = (TAIL4 && m == WT7 - 1) ? s[kr * LDU + 96 + (c & 3)] : su[kr * LDU + 16 * m];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int m = 0; m < WT7; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][m], bv[j], acc[m], 0, 0, 0);
+                for (int m = 0; m < WT7; ++m) {
+                    if (TAIL4 && m == WT7 - 1) acc[m] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j][m], bv[j], acc[m], 0, 0, 0);
+                    else acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][m], bv[j], acc[m], 0, 0, 0);
+                }
             if (cs_v) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) csv += bv[j];
@@ -180,6 +188,16 @@ __global__ __launch_bounds__(256) void tn100_kernel(W100Group grp) {
 #undef GF_W_VIDX
 
     // ---------------- epilogue: lane (c, g) holds m = 16 mt + 4 g + r (the 100-wide dim), n = n0 + 16 wave + c ----------------
+    if constexpr (TAIL4) {
+        // rows 96..99: register r of every lane group holds the partial sum over ITS tokens of (row 96 + r, column c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[WT7 - 1][r];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[WT7 - 1][r] = v;
+        }
+    }
     const int n = n0 + wave * 16 + c;
     const bool nok = n < Nn;
     float* const slab = grp.splits > 1 ? grp.part + (size_t)z * grp.part_stride + q.part_off : nullptr;
@@ -338,6 +356,7 @@ __global__ __launch_bounds__(256) void tn100_reduce_kernel(W100Group grp) {
 
 }  // namespace
 
+extern int g_n100_pad7;           // gemm_n100.hip: lab knob (bit 23), the padded seventh tile
 int g_tn100_force_splits = 0;     // lab knob (ganffn_debug_set_ffn_mode bits 16..19): 0 = choose
 int g_tn100_in_kernel_sum = 0;    // lab knob (bit 4): add the partial slabs in the last-arriving workgroup of a tile (measured slower)
 constexpr long TN100_COUNTERS = 4096;      // ints reserved at the end of the partial-slab workspace for the arrival tickets
@@ -412,7 +431,8 @@ int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* par
         total += q.ntiles * splits;
     }
     if (grp.counters != nullptr) GF_HIP(hipMemsetAsync(grp.counters, 0, (size_t)ctr * sizeof(int), st));
-    hipLaunchKernelGGL(tn100_kernel, dim3(total), dim3(256), 0, st, grp);
+    if (g_n100_pad7) hipLaunchKernelGGL(tn100_kernel<false>, dim3(total), dim3(256), 0, st, grp);
+    else hipLaunchKernelGGL(tn100_kernel<true>, dim3(total), dim3(256), 0, st, grp);
     GF_LAUNCH_CHECK();
     if (splits > 1 && grp.counters == nullptr) {
         hipLaunchKernelGGL(tn100_reduce_kernel, dim3(64, n), dim3(256), 0, st, grp);

@@ -295,6 +295,13 @@ int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const
                          void* stream);
 int ganffn_ffn_fused_bwd(const float* dy, const float* w1, const float* w2, const float* h, float* dh,
                          float* slabs, float* pack_ws, int T, int E, int F, float mscale, void* stream);
+/* The same block (d_model = 100, F = 2048 only) as ffn3.hip's forward kernel, straight from the row-major weights: 64 tokens
+ * x one hidden chunk per workgroup, weight tiles shared through LDS, the hidden tile passed from linear1 to linear2 in
+ * registers.  h [T x 2048] (or NULL when no backward follows) receives dropout(relu(x W1^T + b1)); the output is returned
+ * as *n_slabs (<= max_slabs <= 16) partial slabs slabs[s][slab_stride], b2 added in slab 0. */
+int ganffn_ffn3_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h,
+                    float* slabs, int64_t slab_stride, int T, float p, uint32_t site, const uint64_t* rng,
+                    uint64_t rng_offset_add, int train, int max_slabs, int* n_slabs, void* stream);
 /* n (<= 40) independent problems C_i[M_i x N_i] += At_i[K_i x M_i]^T B_i[K_i x N_i] (+ column sums) in ONE launch: the
  * deferred weight-gradient GEMMs of all encoder layers of a backward pass (dense leading dimensions).  workspace
  * (ganffn_gemm_tn_grouped_workspace_floats() floats, or NULL): lets a group with few output tiles split the token range
@@ -367,9 +374,13 @@ int ganffn_gemm_hook(int mode, int epi, const float* A, const float* W, const fl
  *   bit 5: run the discriminator head as separate GELU / GEMM / tail launches instead of csrc/disc_head.hip;
  *   bit 6: run the head of a d_model-100 encoder stack (positional encoding + dropout, layer 0's in-proj) as two launches
  *          instead of one (csrc/rowchain.hip);
+ *   bit 7: run the FORWARD feed-forward block of a d_model-100 layer as csrc/ffn3.hip's single kernel (ganffn_ffn3_fwd) instead
+ *          of two GEMMs, at up to 4096 tokens; with bit 22 also above (measured: faster alone, nothing in the step);
  *   bits 8..15: forced K-chunk count of csrc/gemm_n100.hip (0 = choose; clamped to the caller's slab capacity);
  *   bits 16..19: forced token-chunk count of csrc/gemm_tn100.hip (0 = choose; clamped to 8 and to the workspace);
- *   bits 20..21: csrc/gemm_n100.hip with 4 (value 1) or 8 (value 2) waves per workgroup (0 = choose).
+ *   bits 20..21: csrc/gemm_n100.hip with 4 (value 1) or 8 (value 2) waves per workgroup (0 = choose);
+ *   bit 23: csrc/gemm_n100.hip and csrc/gemm_tn100.hip with rows 96..99 of the 100-wide dimension on a padded seventh 16-row
+ *           MFMA tile (round 3's form) instead of v_mfma_f32_4x4x1_16B_f32 (measured: the step 34.4 -> 33.75 ms without it).
  * Every combination is parity-tested; results agree to rounding. */
 int ganffn_debug_set_ffn_mode(int bits);
 

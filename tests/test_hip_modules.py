@@ -190,14 +190,17 @@ def test_cpu_tensor_fails_loudly():
         m(torch.zeros(4, 2, 100))
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 6, 8, 32, 46, 64])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 6, 8, 32, 46, 64, 128, 128 | 1 << 22, 1 << 23])
 def test_fused_ffn_modes_agree_with_fixture(mode):
     """the encoder's FFN runs as two GEMMs (bit 0 clear, the default) or as the fused kernel (bit 0 set); the token-local
     chains around the LayerNorms of a d_model-100 layer run as single kernels (rowchain.hip; bit 1 clear, the default) or
     as separate GEMM + LayerNorm launches (bit 1 set); the [T x 2048] x [2048 x 100] products run on the 112-wide
     16x16x4 kernel (gemm_n100.hip; bit 2 clear, the default) or on the generic 64 x 64 tiles (bit 2 set); likewise the
     grouped weight gradients (gemm_tn100.hip, bit 3) and the one-kernel discriminator head (disc_head.hip, bit 5): the
-    combinations tested — including everything on the older launch sequences (46) — all match the reference"""
+    combinations tested — including everything on the older launch sequences (46) — all match the reference; so does the
+    forward feed-forward block as ffn3.hip's single kernel (bit 7; with bit 22 also above 4096 tokens — 128 tokens per
+    workgroup), and so do the 100-wide products with their last four rows on a padded seventh MFMA tile (bit 23) instead
+    of v_mfma_f32_4x4x1"""
     from gan_ffn_amd import _lib
     lib = _lib.load()
     lib.ganffn_debug_set_ffn_mode(mode)

@@ -321,12 +321,13 @@ def test_logsoftmax_nll_matches_reference_fixture(lib):
 
 @pytest.mark.parametrize("T,K,kmajor,cap", [(3008, 2048, 0, 16), (6016, 2048, 1, 16), (6016, 2048, 0, 8), (3008, 2048, 1, 5),
                                             (21, 256, 0, 16), (70, 2048, 1, 1), (1, 320, 1, 16), (2112, 2048, 0, 16)])
-@pytest.mark.parametrize("kw", [0, 1, 2])
+@pytest.mark.parametrize("kw", [0, 1, 2, 2 | 8])
 def test_gemm_n100_slabs_sum_to_the_product(lib, T, K, kmajor, cap, kw):
     """[T x K] x [K x 100] on the 112-wide 16x16x4 kernel (csrc/gemm_n100.hip): the sum of its K-chunk slabs against fp64
     torch, both weight layouts (rows of K = linear2's W2; K-major = linear1's W1 in the dgrad), bias on chunk 0; ragged T,
     a single chunk, chunk counts that do not divide K / 32; kw: the launch heuristic's choice (0), four waves per
-    workgroup (1), eight = two waves per K tile whose halves are added through LDS in fixed order (2)"""
+    workgroup (1), eight = two waves per K tile whose halves are added through LDS in fixed order (2); features 96..99
+    on v_mfma_f32_4x4x1 (the eight-wave default) or on a padded seventh 16-wide tile (2 | 8: bit 23)"""
     lib.load().ganffn_debug_set_ffn_mode(kw << 20)
     try:
         _n100_case(lib, T, K, kmajor, cap)
@@ -400,12 +401,56 @@ def test_ffn_fused_fwd_bwd(lib, T, p):
     assert rel_err(dx, dx_ref) < 3e-5
 
 
-@pytest.mark.parametrize("mode_bits", [0, 8, 2 << 16, 5 << 16, 8 << 16, 9 << 16])
+@pytest.mark.parametrize("T", [3008, 6016, 14, 130, 33, 4097, 64, 1])
+@pytest.mark.parametrize("p,save", [(0.0, True), (0.1, True), (0.1, False)])
+def test_ffn3_fwd(lib, T, p, save):
+    """ffn3.hip: linear1 + ReLU + dropout + linear2 of the d_model-100 layer in one kernel (the hidden tile never leaves
+    the registers between the two products) vs fp64 torch with the same Philox mask; ragged token counts; the hidden
+    tensor is written only when asked for; nothing is written beyond the slabs reported; bit-reproducible"""
+    E, F = 100, 2048
+    g = torch.Generator().manual_seed(T + int(p * 10))
+    x = torch.randn(T, E, generator=g)
+    w1, b1 = torch.randn(F, E, generator=g) / 10, torch.randn(F, generator=g) / 10
+    w2, b2 = torch.randn(E, F, generator=g) / 45, torch.randn(E, generator=g) / 10
+    seed, off, add, site = 31337, 2, 9, 22
+    keep = torch.from_numpy(philox.keep_mask(T, F, p, site, seed, off + add)).double() / (1 - p)
+    h_ref = torch.relu(x.double() @ w1.double().T + b1.double()) * keep
+    y_ref = h_ref @ w2.double().T + b2.double()
+    rng = torch.tensor([seed, off], dtype=torch.int64, device="cuda")
+    xd, w1d, b1d, w2d, b2d = dev(x), dev(w1), dev(b1), dev(w2), dev(b2)
+    h = torch.full((T, F), float("nan"), device="cuda")
+    cap = 16
+    slabs = torch.full((cap, T, E), float("nan"), device="cuda")
+    n = C.c_int(0)
+    args = lambda hh, sl: (ptr(xd), ptr(w1d), ptr(b1d), ptr(w2d), ptr(b2d), ptr(hh) if hh is not None else None, ptr(sl),
+                           C.c_int64(T * E), T, C.c_float(p), C.c_uint32(site), ptr(rng), C.c_uint64(add), 1, cap, C.byref(n), stream())
+    lib.call("ganffn_ffn3_fwd", *args(h if save else None, slabs))
+    assert 1 <= n.value <= 8
+    y = slabs[:n.value].sum(0)
+    assert bool(torch.isfinite(y).all())
+    assert rel_err(y, y_ref) < 2e-5
+    assert bool(torch.isnan(slabs[n.value:]).all())
+    if save:
+        assert rel_err(h, h_ref) < 5e-6
+        # the dropout pattern is the contract's, element for element
+        assert float((((h != 0).cpu() != (h_ref != 0))).double().mean()) < 1e-6
+    else:
+        assert bool(torch.isnan(h).all())
+    slabs2 = torch.full_like(slabs, float("nan"))
+    h2 = torch.full_like(h, float("nan"))
+    lib.call("ganffn_ffn3_fwd", *args(h2 if save else None, slabs2))
+    assert torch.equal(slabs2[:n.value], slabs[:n.value])
+    if save:
+        assert torch.equal(h2, h)
+
+
+@pytest.mark.parametrize("mode_bits", [0, 8, 2 << 16, 5 << 16, 8 << 16, 9 << 16, 1 << 23, 1 << 23 | 3 << 16])
 @pytest.mark.parametrize("K", [6016, 3008, 333, 40])
 def test_gemm_tn_grouped_d100_group(lib, K, mode_bits):
     """the weight-gradient group of a d_model-100 encoder pass (every problem 100-wide on one side; two layers' worth, some
     without a bias gradient, one with a strided gradient) on the 112-wide kernel (csrc/gemm_tn100.hip: default, and with
-    forced token-chunk counts — 9 is clamped to the kernel's 8) and on the generic 64 x 64 tiles (bit 3): gradients and
+    forced token-chunk counts — 9 is clamped to the kernel's 8; rows 96..99 of the 100-wide dimension on v_mfma_f32_4x4x1,
+    or with bit 23 on a padded seventh tile) and on the generic 64 x 64 tiles (bit 3): gradients and
     bias gradients against fp64, accumulation into non-zero slabs, ragged token counts (K % 32 != 0), bit-reproducible;
     and the in-kernel slab sum (the last-arriving workgroup of a tile: bit 4, opt-in — measured slower) against the
     separate reduce launch: the SAME bits"""
