@@ -21,6 +21,9 @@
 //    against 491 us at T = 6016 and 296 against 261 us at T = 3008 (gpurun_out/r4_tn100_lab*.txt): a tile's slabs are
 //    3 x 28 KB, and the last arriver reads them serially at the end of a workgroup's life, which costs more than the 21 us
 //    reduce launch that reads all of them with the whole chip.  It stays behind ganffn_debug_set_ffn_mode bit 4.)
+//    (Round 4 also built 128-column workgroup tiles — two column groups per wave sharing the 28 row-operand registers, 28
+//    instead of 20 flop per byte staged into LDS — and measured them SLOWER: 503 against 466 us at T = 6016, 269 against
+//    250 us at T = 3008 (20 back-to-back launches, HIP events): 208-228 VGPRs and 63 KB of LDS leave two waves per SIMD instead of three.)
 //  * bias gradients (column sums of dY over the tokens) are accumulated from the operand registers the MFMAs read anyway;
 //  * workgroup ids are remapped so that one XCD (one L2) gets a contiguous range of the (problem, chunk, tile) list: the
 //    tiles of a problem share its 100-wide operand panel ([T x 100], 2.4 MB at T = 6016) through that L2, the wide operand
