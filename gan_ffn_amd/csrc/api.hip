@@ -114,6 +114,7 @@ int g_ffn_fused = 0;
 // bit 7 of ganffn_debug_set_ffn_mode: the forward feed-forward block of d_model 100 as ffn3.hip's single kernel (opt-in:
 // 34.6 against 43.8 us in isolation, nothing in the three-stream step — the measurement is in ffn3.hip's header)
 int g_ffn3 = 0;
+int g_outproj_nosplit = 0;   // bit 24: the out-proj of the wide (d_model != 100) stacks unsplit (round 3's form)
 int g_ffn3_wide = 0;   // bit 22: also at T > 4096 (the 128-token variant)
 // d_model = 100: the token-local chains around the LayerNorms run as single kernels (rowchain.hip); bit 1 of
 // ganffn_debug_set_ffn_mode switches back to the separate GEMM + LayerNorm launches (both paths are parity-tested)
@@ -267,9 +268,11 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
                                             sv + so.xhat1, sv + so.rstd1, T, c->ln_eps, c->p_enc, site + 1, rng, add, train, st));
         } else {
             ea.bias = P + lo.out_b;
-            GF_TRY(launch_gemm_nt(sv + so.attn_o, E, P + lo.out_w, E, tmp, E, T, E, E, EPI_NONE, ea, st));
+            // (the 512-wide out-proj is 376 output tiles on 256 CUs: K in two halves, summed by the LayerNorm kernel)
+            int osplits = g_outproj_nosplit ? 1 : gemm_splitk_factor(T, E, E);
+            GF_TRY(launch_gemm_nt(sv + so.attn_o, E, P + lo.out_w, E, tmp, E, T, E, E, EPI_NONE, ea, st, &osplits, TE));
             GF_TRY(launch_add_drop_ln_fwd(Xcur, tmp, P + lo.n1w, P + lo.n1b, sv + so.x1, sv + so.xhat1, sv + so.rstd1, T, E,
-                                          c->ln_eps, c->p_enc, site + 1, rng, add, train, st));
+                                          c->ln_eps, c->p_enc, site + 1, rng, add, train, st, osplits, TE));
         }
         // FFN: h = drop(relu(x1 W1^T + b1)); y = h W2^T + b2
         int splits = 1;
@@ -703,6 +706,7 @@ extern "C" int ganffn_debug_set_ffn_mode(int bits) {
     g_ffn3 = (bits & 128) ? 1 : 0;
     g_ffn3_wide = (bits & (1 << 22)) ? 1 : 0;
     g_n100_pad7 = (bits & (1 << 23)) ? 1 : 0;
+    g_outproj_nosplit = (bits & (1 << 24)) ? 1 : 0;
     g_tn100_off = (bits & 8) ? 1 : 0;
     g_tn100_in_kernel_sum = (bits & 16) ? 1 : 0;
     g_tn100_force_splits = (bits >> 16) & 0xF;      // lab: force the token-chunk count of the d_model-100 grouped wgrad (0 = choose)
