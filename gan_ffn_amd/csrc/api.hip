@@ -70,7 +70,7 @@ static LayerOff layer_off(int E, int F) {
 //   per layer:   qkv 3TE | attn_o TE | x1 TE | xhat1 TE | xhat2 TE | h TF | rstd1 T4 | rstd2 T4 | lse (T H)4 | keep B H 448
 // ------------------------------------------------------------------------------------------
 struct SavedOff {
-    int64_t X, layers, per_layer, qkv, attn_o, x1, xhat1, xhat2, h, rstd1, rstd2, lse, keep, total;
+    int64_t X, layers, per_layer, qkv, attn_o, x1, xhat1, xhat2, h, rstd1, rstd2, lse, keep, hmask, total;
 };
 static SavedOff saved_off(const ganffn_enc_cfg* c) {
     SavedOff s;
@@ -88,6 +88,7 @@ static SavedOff saved_off(const ganffn_enc_cfg* c) {
     s.rstd2 = p; p += T4;
     s.lse = p; p += (T * c->H + 3) & ~int64_t(3);     // attention log-sum-exp [B*H x S]
     s.keep = p; p += (int64_t)c->B * c->H * ATTN_KEEP_WORDS;   // attention-dropout keep words (uint32) of a train-mode pass
+    s.hmask = p; p += (epi_mask_words(T, c->F) / 2 + 3) & ~int64_t(3);   // [h > 0] of the hidden activation, 1 bit each (uint16 words)
     s.per_layer = p;
     s.total = s.layers + (int64_t)c->L * s.per_layer;
     return s;
@@ -114,6 +115,9 @@ int g_ffn_fused = 0;
 // bit 7 of ganffn_debug_set_ffn_mode: the forward feed-forward block of d_model 100 as ffn3.hip's single kernel (opt-in:
 // 34.6 against 43.8 us in isolation, nothing in the three-stream step — the measurement is in ffn3.hip's header)
 int g_ffn3 = 0;
+// bit 25: the linear2 dgrad reads the saved hidden activation for its ReLU / dropout pattern (round 3's form) instead of the
+// 1-bit copy linear1's epilogue leaves beside it
+int g_mask_float = 0;
 int g_outproj_nosplit = 0;   // bit 24: the out-proj of the wide (d_model != 100) stacks unsplit (round 3's form)
 int g_ffn3_wide = 0;   // bit 22: also at T > 4096 (the 128-token variant)
 // d_model = 100: the token-local chains around the LayerNorms run as single kernels (rowchain.hip); bit 1 of
@@ -286,6 +290,7 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
         } else {
             EpiArgs e1;
             e1.bias = P + lo.b1; e1.p = c->p_enc; e1.site = site + 2; e1.rng = rng; e1.rng_add = add; e1.train = train;
+            if (saved) e1.mask_out = reinterpret_cast<uint16_t*>(sv + so.hmask);     // the pattern the linear2 dgrad will ask for
             GF_TRY(launch_gemm_nt(sv + so.x1, E, P + lo.w1, E, sv + so.h, F, T, F, E, EPI_RELU_DROP, e1, st));
             if (n100_supported(E, F) && !g_n100_off) {
                 splits = MAX_SPLITS;                   // K chunks = output slabs, summed by the LayerNorm kernel
@@ -415,6 +420,9 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
             EpiArgs em;
             em.aux_in = sv + so.h;
             em.mscale = mscale;
+            // the forward's two-GEMM path left the pattern as bits (the one-kernel forwards, debug bits 0 / 7, do not)
+            const bool fwd_was_ffn3 = g_ffn3 && ffn3_supported(E, F) && (T <= 4096 || g_ffn3_wide);
+            if (!fwd_was_ffn3 && !g_mask_float) em.mask_in = reinterpret_cast<const uint16_t*>(sv + so.hmask);
             GF_TRY(launch_gemm_nn(dyA, E, P + lo.w2, F, dh, F, T, F, E, EPI_MASK_POS, em, st));
         }
         // linear1 wgrad: gW1[F,E] += dh^T x1 ; gb1 += colsum(dh)
@@ -707,6 +715,7 @@ extern "C" int ganffn_debug_set_ffn_mode(int bits) {
     g_ffn3_wide = (bits & (1 << 22)) ? 1 : 0;
     g_n100_pad7 = (bits & (1 << 23)) ? 1 : 0;
     g_outproj_nosplit = (bits & (1 << 24)) ? 1 : 0;
+    g_mask_float = (bits & (1 << 25)) ? 1 : 0;
     g_tn100_off = (bits & 8) ? 1 : 0;
     g_tn100_in_kernel_sum = (bits & 16) ? 1 : 0;
     g_tn100_force_splits = (bits >> 16) & 0xF;      // lab: force the token-chunk count of the d_model-100 grouped wgrad (0 = choose)

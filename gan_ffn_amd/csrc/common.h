@@ -198,12 +198,20 @@ struct EpiArgs {
     float* aux_out = nullptr;     // [M x N] (EPI_DROP_GELU)
     const float* aux_in = nullptr;// [M x N]
     float mscale = 1.f;           // EPI_MASK_POS
+    // 1-bit form of the ReLU / dropout pattern of a [M x N] activation: EPI_RELU_DROP writes it (when non-null) beside the
+    // activation, EPI_MASK_POS reads it INSTEAD of aux_in (when non-null).  Word ((m / 32) * N + n) * 2 + h, h = (m / 4) & 1,
+    // holds rows 32 (m / 32) + 4 h + (i & 3) + 8 (i >> 2) of column n in bit i — one lane's 16 accumulator registers of a
+    // 32 x 32 MFMA tile; epi_mask_words(M, N) uint16 words.
+    uint16_t* mask_out = nullptr;
+    const uint16_t* mask_in = nullptr;
     float p = 0.f;                // dropout prob
     uint32_t site = 0;
     const uint64_t* rng = nullptr;
     uint64_t rng_add = 0;
     int train = 0;
 };
+
+inline long epi_mask_words(long M, long N) { return ((M + 31) / 32) * N * 2; }
 
 // C[MxN] = A[MxK] * W[NxK]^T (NT)
 int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,

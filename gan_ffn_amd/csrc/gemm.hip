@@ -260,6 +260,21 @@ template <int EPI, int TM, int TN>
 __device__ __forceinline__ void gemm_load_aux(const GemmArgs& g, float (&aux)[TM][TN][16], const int mbase, const int nbase,
                                               const int bz, const int r, const int h) {
     if (epi_has_aux<EPI>()) {
+        if constexpr (EPI == EPI_MASK_POS) {
+            if (g.ea.mask_in != nullptr) {      // the pattern as one 16-bit word per lane and tile instead of 16 activations
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        const int col = min(nbase + b * 32 + r, g.N - 1);
+                        const uint32_t w = g.ea.mask_in[((size_t)((mbase + a * 32) >> 5) * g.N + col) * 2 + h];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) aux[a][b][i] = 0.f;
+                        aux[a][b][0] = __uint_as_float(w);
+                    }
+                return;
+            }
+        }
         const bool want = (EPI == EPI_NONE) ? (g.ea.aux_in != nullptr && bz == 0) : true;   // wave-uniform
         if (want) {
 #pragma unroll
@@ -298,6 +313,9 @@ __device__ __forceinline__ void gemm_apply_store(const GemmArgs& g, floatx16 (&a
             float bias = 0.f;
             if (EPI == EPI_NONE || EPI == EPI_RELU_DROP || EPI == EPI_DROP_GELU)
                 if (g.ea.bias != nullptr && bz == 0) bias = g.ea.bias[min(col, g.N - 1)];
+            const bool bitmask = EPI == EPI_MASK_POS && g.ea.mask_in != nullptr;          // uniform
+            const uint32_t mword = EPI == EPI_MASK_POS ? __float_as_uint(aux[a][b][0]) : 0u;
+            uint32_t pos = 0;                                                              // EPI_RELU_DROP: bit i <-> register i > 0
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int rb = mbase + a * 32 + 8 * gq + 4 * h;  // 4 consecutive rows rb..rb+3
@@ -318,11 +336,13 @@ __device__ __forceinline__ void gemm_apply_store(const GemmArgs& g, floatx16 (&a
                         v += ax;                                   // fused residual / branch add (0 when absent)
                     } else if (EPI == EPI_RELU_DROP) {
                         v = fmaxf(v + bias, 0.f) * mult[q];
+                        pos |= (v > 0.f ? 1u : 0u) << (gq * 4 + q);
                     } else if (EPI == EPI_DROP_GELU) {
                         u = (v + bias) * mult[q];
                         v = gelu_f(u);
                     } else if (EPI == EPI_MASK_POS) {
-                        v = (ax > 0.f) ? v * g.ea.mscale : 0.f;
+                        const bool on = bitmask ? ((mword >> (gq * 4 + q)) & 1u) != 0u : ax > 0.f;
+                        v = on ? v * g.ea.mscale : 0.f;
                     } else if (EPI == EPI_GELU_BWD_DROP) {
                         v = v * mult[q] * gelu_grad_f(ax);
                     } else if (EPI == EPI_GELU_BWD) {
@@ -334,6 +354,8 @@ __device__ __forceinline__ void gemm_apply_store(const GemmArgs& g, floatx16 (&a
                     }
                 }
             }
+            if (EPI == EPI_RELU_DROP && g.ea.mask_out != nullptr && colok && mbase + a * 32 < g.M)
+                g.ea.mask_out[((size_t)((mbase + a * 32) >> 5) * g.N + col) * 2 + h] = (uint16_t)pos;
         }
 }
 
@@ -346,6 +368,9 @@ __device__ __forceinline__ void gemm_apply_store_full(const GemmArgs& g, const f
     constexpr bool HAS_AUX = epi_has_aux<EPI>();
     float* const cp = g.C + (size_t)(mbase + 4 * h) * g.ldc + nbase + r;
     float* const up = (EPI == EPI_DROP_GELU) ? g.ea.aux_out + (size_t)(mbase + 4 * h) * g.ldc + nbase + r : nullptr;
+    const bool bitmask = EPI == EPI_MASK_POS && g.ea.mask_in != nullptr;                  // uniform
+    const uint32_t mword = EPI == EPI_MASK_POS ? __float_as_uint(aux[0]) : 0u;
+    uint32_t pos = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int dr = (i & 3) + 8 * (i >> 2);
@@ -357,11 +382,13 @@ __device__ __forceinline__ void gemm_apply_store_full(const GemmArgs& g, const f
             v += ax;
         } else if (EPI == EPI_RELU_DROP) {
             v = fmaxf(v + bias, 0.f) * mult;
+            pos |= (v > 0.f ? 1u : 0u) << i;
         } else if (EPI == EPI_DROP_GELU) {
             u = (v + bias) * mult;
             v = gelu_f(u);
         } else if (EPI == EPI_MASK_POS) {
-            v = (ax > 0.f) ? v * g.ea.mscale : 0.f;
+            const bool on = bitmask ? ((mword >> i) & 1u) != 0u : ax > 0.f;
+            v = on ? v * g.ea.mscale : 0.f;
         } else if (EPI == EPI_GELU_BWD_DROP) {
             v = v * mult * gelu_grad_f(ax);
         } else if (EPI == EPI_GELU_BWD) {
@@ -370,6 +397,8 @@ __device__ __forceinline__ void gemm_apply_store_full(const GemmArgs& g, const f
         if (EPI == EPI_DROP_GELU) up[(size_t)dr * g.ldc] = u;
         cp[(size_t)dr * g.ldc] = v;
     }
+    if (EPI == EPI_RELU_DROP && g.ea.mask_out != nullptr)
+        g.ea.mask_out[((size_t)(mbase >> 5) * g.N + nbase + r) * 2 + h] = (uint16_t)pos;
 }
 
 template <int EPI, int TM, int TN>

@@ -381,7 +381,12 @@ int ganffn_gemm_hook(int mode, int epi, const float* A, const float* W, const fl
  *   bits 20..21: csrc/gemm_n100.hip with 4 (value 1) or 8 (value 2) waves per workgroup (0 = choose);
  *   bit 23: csrc/gemm_n100.hip and csrc/gemm_tn100.hip with rows 96..99 of the 100-wide dimension on a padded seventh 16-row
  *           MFMA tile (round 3's form) instead of v_mfma_f32_4x4x1_16B_f32 (measured: the step 34.4 -> 33.75 ms without it).
- * Every combination is parity-tested; results agree to rounding. */
+ *   bit 24: run the out-proj of the wide (d_model != 100) stacks unsplit instead of as two K halves summed by the LayerNorm kernel;
+ *   bit 25: the linear2 dgrad takes its ReLU / dropout pattern from the saved hidden activation instead of the 1-bit copy that
+ *           linear1's epilogue leaves beside it in the saved block (same predicate, same bits; 24.6 MB less to read per layer
+ *           at the headline size).
+ * Every combination is parity-tested; results agree to rounding.  The switch must not change between a forward pass and
+ * the backward pass that consumes its saved block. */
 int ganffn_debug_set_ffn_mode(int bits);
 
 #ifdef __cplusplus

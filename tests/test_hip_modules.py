@@ -192,7 +192,7 @@ def test_cpu_tensor_fails_loudly():
         m(torch.zeros(4, 2, 100))
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 6, 8, 32, 46, 64, 128, 128 | 1 << 22, 1 << 23])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 6, 8, 32, 46, 64, 128, 128 | 1 << 22, 1 << 23, 1 << 25, 1 << 24 | 1 << 25])
 def test_fused_ffn_modes_agree_with_fixture(mode):
     """the encoder's FFN runs as two GEMMs (bit 0 clear, the default) or as the fused kernel (bit 0 set); the token-local
     chains around the LayerNorms of a d_model-100 layer run as single kernels (rowchain.hip; bit 1 clear, the default) or
@@ -202,7 +202,8 @@ def test_fused_ffn_modes_agree_with_fixture(mode):
     combinations tested — including everything on the older launch sequences (46) — all match the reference; so does the
     forward feed-forward block as ffn3.hip's single kernel (bit 7; with bit 22 also above 4096 tokens — 128 tokens per
     workgroup), and so do the 100-wide products with their last four rows on a padded seventh MFMA tile (bit 23) instead
-    of v_mfma_f32_4x4x1"""
+    of v_mfma_f32_4x4x1; the linear2 dgrad taking its ReLU / dropout pattern from the saved activation (bit 25) instead of the
+    1-bit copy beside it, and the 512-wide out-proj unsplit (bit 24; these two also on the 512-wide generator)"""
     from gan_ffn_amd import _lib
     lib = _lib.load()
     lib.ganffn_debug_set_ffn_mode(mode)
@@ -214,6 +215,9 @@ def test_fused_ffn_modes_agree_with_fixture(mode):
         # (strict), not to the fixture's kink-tolerant bounds
         test_module_matches_reference_fixture(("TextGenerator", 100), (110, 3), fixture_grads=not (mode & 128))
         test_train_mode_matches_oracle_with_same_masks("AcousticDiscriminator", 100, 94, 4)
+        if mode & (3 << 24):
+            test_module_matches_reference_fixture(("VisualGenerator", 512), (110, 3))
+            test_train_mode_matches_oracle_with_same_masks("VisualGenerator", 512, 38, 2)
     finally:
         lib.ganffn_debug_set_ffn_mode(0)
 
@@ -239,3 +243,33 @@ def test_parameter_gradients_do_not_depend_on_whether_the_input_wants_a_gradient
         assert (xi.grad is not None) == want
     for k in grads[0]:
         assert torch.equal(grads[0][k], grads[1][k]), k
+
+
+@pytest.mark.parametrize("case,d_in,S,B", [("TextGenerator", 100, 41, 3), ("VisualGenerator", 512, 33, 3), ("AcousticDiscriminator", 100, 94, 5)])
+def test_one_bit_relu_pattern_gives_the_bits_of_the_saved_activation(case, d_in, S, B):
+    """linear1's epilogue leaves [h > 0] as one bit per hidden unit beside the saved activation and the linear2 dgrad
+    (dh = (dy W2) * [h > 0] / (1 - p)) reads that instead of h (24.6 MB per layer at the headline size).  Same predicate on
+    the same values: every gradient keeps its BITS against the run that reads h (debug bit 25), train mode with dropout,
+    ragged token counts (S * B not a multiple of 32), both kernels that carry the epilogue (K = 100 weight-resident and the
+    generic tiles of the 512-wide stack)"""
+    from gan_ffn_amd import _lib, model, ops
+    lib = _lib.load()
+    torch.manual_seed(23)
+    m = getattr(model, case)(100).cuda().train()
+    x = torch.randn(S, B, d_in, device="cuda")
+    runs = []
+    try:
+        for bits in (0, 1 << 25):
+            lib.ganffn_debug_set_ffn_mode(bits)
+            ops.manual_seed(9, "cuda")
+            xi = x.clone().requires_grad_(True)
+            m.zero_grad(set_to_none=True)
+            out = m(xi)
+            out.square().sum().backward()
+            runs.append((out.detach().clone(), xi.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    finally:
+        lib.ganffn_debug_set_ffn_mode(0)
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert len(runs[0][2]) >= 100
+    for k in runs[0][2]:
+        assert torch.equal(runs[0][2][k], runs[1][2][k]), k
