@@ -113,7 +113,7 @@ static int check_cfg(const ganffn_enc_cfg* c) {
 // (357 MB per launch at T = 6016), so it stays opt-in.
 int g_ffn_fused = 0;
 // bit 7 of ganffn_debug_set_ffn_mode: the forward feed-forward block of d_model 100 as ffn3.hip's single kernel (opt-in:
-// 34.6 against 43.8 us in isolation, nothing in the three-stream step — the measurement is in ffn3.hip's header)
+// 34.6 against 43.8 us in isolation, +0.4 ms in the three-stream step — the measurement is in ffn3.hip's header)
 int g_ffn3 = 0;
 // bit 25: the linear2 dgrad reads the saved hidden activation for its ReLU / dropout pattern (round 3's form) instead of the
 // 1-bit copy linear1's epilogue leaves beside it

@@ -26,8 +26,8 @@
 //
 // Measured (MI355X, tools/lab/ffn3_time.py, back-to-back launches, train mode): 34.6 us against 43.8 us for the two kernels
 // at T = 3008, 60.7 against 64.2 us at T = 6016; eval 30.9 / 53.0 us.  In the step it does NOT pay (tools/lab/ffn3_ab.sh):
-// single stream 45.05 -> 44.18 ms — of which 0.72 ms is the 160 launch floors it removes, which the three-stream schedule
-// hides anyway — and the default three-stream step 34.3-34.5 -> 34.5-34.6 ms.  The reason is in the instruction mix: per
+// single stream 44.30 -> 43.81 ms — less than the 0.72 ms of launch floors it removes, which the three-stream schedule hides
+// anyway — and the default three-stream step 33.42 -> 33.85 ms (T <= 4096 only) / 34.19 ms (every T).  The reason is in the instruction mix: per
 // hidden tile a wave issues 53 MFMAs (1,696 cycles) and ~100 VALU instructions (Philox 50, epilogue, addresses), and on
 // this chip fp32 MFMA and VALU time ADD (issuing the Philox rounds between product 1's MFMAs changed nothing: 36.3 us) —
 // 2 waves x 13 pairs x ~2,300 cycles = 25 us + fill/drain = the 28 us it runs at, and the two-kernel path pays the same

@@ -375,7 +375,7 @@ int ganffn_gemm_hook(int mode, int epi, const float* A, const float* W, const fl
  *   bit 6: run the head of a d_model-100 encoder stack (positional encoding + dropout, layer 0's in-proj) as two launches
  *          instead of one (csrc/rowchain.hip);
  *   bit 7: run the FORWARD feed-forward block of a d_model-100 layer as csrc/ffn3.hip's single kernel (ganffn_ffn3_fwd) instead
- *          of two GEMMs, at up to 4096 tokens; with bit 22 also above (measured: faster alone, nothing in the step);
+ *          of two GEMMs, at up to 4096 tokens; with bit 22 also above (measured: faster alone, slower in the step);
  *   bits 8..15: forced K-chunk count of csrc/gemm_n100.hip (0 = choose; clamped to the caller's slab capacity);
  *   bits 16..19: forced token-chunk count of csrc/gemm_tn100.hip (0 = choose; clamped to 8 and to the workspace);
  *   bits 20..21: csrc/gemm_n100.hip with 4 (value 1) or 8 (value 2) waves per workgroup (0 = choose);
