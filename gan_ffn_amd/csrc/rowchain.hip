@@ -50,18 +50,21 @@ constexpr int LDX = 116;             // LDS row stride of a 16 x 100 row tile (z
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-// one lane's operand fragments over K (a multiple of 4) from a K-contiguous row: group q = floats 16 q + 4 g .. + 3
+// one lane's operand fragments over K (a multiple of 4) from a K-contiguous row: full group q = floats 16 q + 4 g .. + 3 (four
+// MFMAs, lane group g taking k = 16 q + 4 g + j at the j-th); the K % 16 values behind the last full group go ONE k per lane
+// group and MFMA (k = 16 KF + 4 j + g): K = 100 is 6 groups + 1 MFMA = 25 MFMAs per tile, not 7 groups = 28 with three
+// quarters of the last four empty (round 4)
 template <int K>
 struct Frag {
-    static constexpr int KQ = (K + 15) / 16;
-    float4 v[KQ];
+    static_assert(K % 4 == 0, "K must be a multiple of 4");
+    static constexpr int KF = K / 16, R = (K % 16) / 4;
+    float4 v[KF];
+    float t[R > 0 ? R : 1];
     __device__ __forceinline__ void load(const float* __restrict__ row, int g) {
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-            const int col = 16 * q + 4 * g;
-            const float4 t = f4(row + min(col, K - 4));
-            v[q] = (16 * q + 12 < K || col < K) ? t : zero4();     // compile-time true except in the last group
-        }
+        for (int q = 0; q < KF; ++q) v[q] = f4(row + 16 * q + 4 * g);
+#pragma unroll
+        for (int j = 0; j < R; ++j) t[j] = row[16 * KF + 4 * j + g];
     }
 };
 
@@ -69,7 +72,7 @@ struct Frag {
 template <int K, int NI>
 __device__ __forceinline__ void mma(floatx4 (&acc)[NI], const Frag<K> (&wf)[NI], const Frag<K>& xf) {
 #pragma unroll
-    for (int q = 0; q < Frag<K>::KQ; ++q) {
+    for (int q = 0; q < Frag<K>::KF; ++q) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].v[q].x, xf.v[q].x, acc[i], 0, 0, 0);
 #pragma unroll
@@ -79,6 +82,10 @@ __device__ __forceinline__ void mma(floatx4 (&acc)[NI], const Frag<K> (&wf)[NI],
 #pragma unroll
         for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].v[q].w, xf.v[q].w, acc[i], 0, 0, 0);
     }
+#pragma unroll
+    for (int j = 0; j < Frag<K>::R; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].t[j], xf.t[j], acc[i], 0, 0, 0);
 }
 
 template <int R>
@@ -276,9 +283,8 @@ __global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) pb[j] = f4(a.post_b + min(16 * (w + 4 * j) + 4 * g, NP - 4));
         __syncthreads();
-        Frag<RE> af;                                        // (columns 100 .. 111 of the tile are the zero padding)
-#pragma unroll
-        for (int q = 0; q < Frag<RE>::KQ; ++q) af.v[q] = f4(xs + c * LDX + 16 * q + 4 * g);
+        Frag<RE> af;
+        af.load(xs + c * LDX, g);
         floatx4 acc[3] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
         mma<RE, 3>(acc, wpost, af);
         floatx4 acc2[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
@@ -485,8 +491,7 @@ __global__ __launch_bounds__(256) void rc_bwd_kernel(RcBwdArgs a) {
     if constexpr (POST_GEMM) {
         __syncthreads();
         Frag<RE> af;
-#pragma unroll
-        for (int q = 0; q < Frag<RE>::KQ; ++q) af.v[q] = f4(xs + c * LDX + 16 * q + 4 * g);
+        af.load(xs + c * LDX, g);
         floatx4 acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
         mma<RE, 2>(acc, wpost, af);
 #pragma unroll
