@@ -54,6 +54,14 @@ def flops_per_token(S, config="iemocap"):
     return fwd + bwd
 
 
+def frozen_wgrad_flops_per_token(config="iemocap"):
+    """FLOPs per padded token per iteration the reference spends on the frozen discriminator's weight gradients inside
+    train_gen (computed by autograd, zeroed unused: train_IEMOCAP.py:216,245) — the engine does not execute them.
+    6 (iemocap) / 2 (meld) discriminator backward passes: 8 layers x 2 x (linear1 + linear2 + out-proj + in-proj weights) + head"""
+    per_pass = 8 * 2.0 * (100 * 2048 * 2 + 100 * 100 + 300 * 100) + 2.0 * (100 * 64 + 64 * 16 + 16)
+    return (2 if config == "meld" else 6) * per_pass
+
+
 def wgrad_groups(S, B, config="iemocap"):
     """The dominant kernel `gemm_tn_grouped_kernel` = the deferred weight-gradient GEMMs of one encoder backward pass
     (8 layers x {linear2, linear1, out_proj, in_proj}: dW[M x N] += dY^T[M x K] X[K x N], K = tokens; one owner workgroup
@@ -158,39 +166,32 @@ def time_dominant_kernel(S, B, reps=3, config="iemocap"):
     return e0.elapsed_time(e1) * 1e-3 / (reps * n), flops, n
 
 
-def time_linear1_kernel(S, B, reps=3):
-    """Live HIP-event timing (launch stream = torch's current stream) of the heavy kernel that sits lowest on its roofline:
-    the d_model-100 feed-forward linear1 GEMM with its fused bias + ReLU + dropout epilogue, `gemm_wres_kernel<0,1,100>`
-    ([T x 100] x [2048 x 100]^T, K = 100).  One iteration launches it 112 times at
-    T = S*B (4 generator + 6 frozen-discriminator + 4 no-save generator passes x 8 layers) and 48 times at T = 2*S*B (the
-    six batched [real | fake] discriminator passes).  Returns (avg seconds per launch, avg algorithmic flops per launch, launches)."""
+def time_k100_family(S, B, reps=3):
+    """Live HIP-event timing (launch stream = torch's current stream) of the K = 100 -> 2048 family `gemm_wres_kernel`, one
+    iteration's launch mix exactly as the encoder stack issues it (measurement hook ganffn_ffn_k100_hook):
+    linear1 forward `<0,1,100>` ([T x 100] x [2048 x 100]^T + bias + ReLU + dropout, writing the 1-bit ReLU pattern when the
+    pass is saved for a backward): at T1 = S*B 32 train-mode saved launches (4 generator passes x 8 layers), 48 eval-mode
+    saved (6 frozen-discriminator passes) and 32 eval-mode unsaved (the generators inside train_disc); at T2 = 2*S*B 48
+    train-mode saved (the six [real | fake] discriminator passes);
+    linear2 dgrad `<1,3,100>` ([T x 100] x [100 x 2048], masked by the pattern bits): 80 at T1, 48 at T2.
+    Returns (avg seconds per launch, avg algorithmic flops per launch, launches)."""
     from gan_ffn_amd import _lib, ops
-    st = ops._stream()
+    st, P = ops._stream(), ops._ptr
     E, F = 100, 2048
     rng = torch.tensor([3407, 0], dtype=torch.int64, device="cuda")
     calls = []
-    for T, cnt in ((S * B, 112), (2 * S * B, 48)):
+    for T, mix in ((S * B, ((0, 1, 1, 32), (0, 0, 1, 48), (0, 0, 0, 32), (1, 1, 1, 80))), (2 * S * B, ((0, 1, 1, 48), (1, 1, 1, 48)))):
         x = torch.rand(T, E, device="cuda") - 0.5
         w1, b1 = (torch.rand(F, E, device="cuda") - 0.5) * 0.2, torch.zeros(F, device="cuda")
+        w2 = (torch.rand(E, F, device="cuda") - 0.5) * 0.2
         h = torch.empty(T, F, device="cuda")
-        calls.append((cnt, T, (x, w1, b1, h)))
-
-    def one_iteration():
-        for cnt, T, (x, w1, b1, h) in calls:
-            for _ in range(cnt):
-                _lib.call("ganffn_ffn_linear1_fwd", ops._ptr(x), ops._ptr(w1), ops._ptr(b1), ops._ptr(h), T, E, F, C.c_float(0.1),
-                          C.c_uint32(18), ops._ptr(rng), C.c_uint64(0), 1, st)
-    one_iteration()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(reps):
-        one_iteration()
-    e1.record()
-    torch.cuda.synchronize()
-    n = sum(c[0] for c in calls)
-    flops = sum(c[0] * 2.0 * c[1] * E * F for c in calls) / n
-    return e0.elapsed_time(e1) * 1e-3 / (reps * n), flops, n
+        hmask = torch.zeros(((T + 31) // 32) * F, device="cuda")
+        for which, train, saved, cnt in mix:
+            def fn(which=which, train=train, saved=saved, x=x, w1=w1, b1=b1, w2=w2, h=h, hmask=hmask, T=T):
+                return lambda: _lib.call("ganffn_ffn_k100_hook", which, P(x), P(w2 if which else w1), None if which else P(b1), P(h),
+                                         P(hmask) if saved else None, None, T, C.c_float(0.1), C.c_uint32(18), P(rng), C.c_uint64(0), train, st)
+            calls.append((cnt, fn(), 2.0 * T * E * F))
+    return _time_mix(calls, reps)
 
 
 def time_n100_kernel(S, B, reps=3):
@@ -559,6 +560,184 @@ def host_threads():
     return max(1, n)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Self-launcher (replaces /root/reference/train_IEMOCAP.py:587-593, the nn.DataParallel wrap): `python bench.py --gpus N`
+# with no WORLD_SIZE in the environment starts its own N ranks.  The parent makes NO GPU call (it never imports
+# gan_ffn_amd, never asks torch.cuda anything): it spawns N children of this same file with RANK / LOCAL_RANK /
+# WORLD_SIZE / MASTER_* set, relays their stderr, takes rank 0's JSON line and exits with the children's return code.
+# It is also the watchdog: the in-line 3-communicator data-parallel default has never run on more than one rank (no
+# multi-GPU node was available to this build), so if the children go silent for too long or fail, the parent ends
+# THOSE processes (the exact process groups it started) and starts FRESH children on the next rung of LADDER.
+# ---------------------------------------------------------------------------------------------------------------------
+LADDER = [
+    # (name, environment of the rung, --streams or None = as asked)
+    ("inline-3streams", {"GANFFN_DP_MODE": "inline", "GANFFN_COMM_PER_STREAM": "1"}, None),
+    ("inline-1stream", {"GANFFN_DP_MODE": "inline", "GANFFN_COMM_PER_STREAM": "0"}, 1),
+    ("buckets", {"GANFFN_DP_MODE": "buckets", "GANFFN_COMM_PER_STREAM": "0"}, None),
+]
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def rank_environments(n, port, rung_env=None, base=None):
+    """the N child environments of one rung: what `python -m torch.distributed.run --nproc-per-node N` would export"""
+    envs = []
+    for r in range(n):
+        e = dict(os.environ if base is None else base)
+        e.update(rung_env or {})
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=e.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), GANFFN_BENCH_CHILD="1")
+        envs.append(e)
+    return envs
+
+
+def _child_argv(argv, streams):
+    """the parent's own arguments, with --streams replaced when the rung asks for it (and never --launcher: a child runs)"""
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a in ("--launcher", "--streams") and (a == "--launcher" or streams is not None):
+            skip = True
+            continue
+        if a.startswith("--launcher=") or (streams is not None and a.startswith("--streams=")):
+            continue
+        out.append(a)
+    if streams is not None:
+        out += ["--streams", str(streams)]
+    return out
+
+
+def _end_children(procs, grace=10.0):
+    """end exactly the process groups this launcher started (each child is its own session leader)"""
+    import signal
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        alive = [p_ for p_ in procs if p_.poll() is None]
+        if not alive:
+            return
+        for p_ in alive:
+            try:
+                os.killpg(p_.pid, sig)
+            except (ProcessLookupError, PermissionError):
+                pass
+        t_end = time.time() + grace
+        while time.time() < t_end and any(p_.poll() is None for p_ in alive):
+            time.sleep(0.2)
+
+
+def launch(args, argv, cmd=None):
+    """parent of `--gpus N`: returns the process exit code.  No GPU call is made here.
+    cmd: the child command line (default: this file with the parent's arguments) — tests/test_bench_launcher_cpu.py passes a
+    stand-in child to exercise the watchdog and the ladder without a GPU."""
+    import subprocess
+    import threading
+    n = args.gpus
+    silence = float(os.environ.get("GANFFN_LAUNCH_SILENCE_S", "300"))     # a fresh box pages torch in for 1-2 min per process
+    total_cap = float(os.environ.get("GANFFN_LAUNCH_RUNG_S", "1500"))
+    ladder = LADDER if (n > 1 or os.environ.get("GANFFN_FORCE_DIST", "0") == "1") else [("single", {}, None)]
+    if os.environ.get("GANFFN_LAUNCH_RUNGS"):                              # e.g. "1,2": start further down (tests, a known-bad box)
+        ladder = [LADDER[int(i)] for i in os.environ["GANFFN_LAUNCH_RUNGS"].split(",")]
+    if os.environ.get("GANFFN_DP_MODE"):                                   # the caller pinned the mode: one rung, as asked
+        ladder = [("as-asked", {}, None)]
+    tried = []
+    for name, rung_env, streams in ladder:
+        port = _free_port()
+        envs = rank_environments(n, port, dict(rung_env, GANFFN_BENCH_RUNG=name, GANFFN_BENCH_FALLBACK_FROM=",".join(tried)))
+        rung_cmd = (cmd if cmd is not None else [sys.executable, os.path.abspath(__file__)]) + _child_argv(argv, streams)
+        print("[bench launcher] rung %r: starting %d ranks (port %d)%s" % (name, n, port, ", after " + ",".join(tried) if tried else ""),
+              file=sys.stderr, flush=True)
+        procs, last, lines = [], [time.time()], []
+        for r in range(n):
+            procs.append(subprocess.Popen(rung_cmd, env=envs[r], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                          start_new_session=True, cwd=ROOT))
+
+        def pump(stream, sink, rank, keep):
+            for line in stream:
+                last[0] = time.time()
+                if keep is not None and line.startswith("{"):
+                    keep.append(line.strip())
+                else:
+                    sink.write(line if rank == 0 else "[rank %d] %s" % (rank, line))
+                    sink.flush()
+        threads = []
+        for r, p_ in enumerate(procs):
+            threads.append(threading.Thread(target=pump, args=(p_.stdout, sys.stderr, r, lines if r == 0 else None), daemon=True))
+            threads.append(threading.Thread(target=pump, args=(p_.stderr, sys.stderr, r, None), daemon=True))
+        for t_ in threads:
+            t_.start()
+        t0, why = time.time(), None
+        while True:
+            rcs = [p_.poll() for p_ in procs]
+            if all(rc is not None for rc in rcs):
+                break
+            if any(rc not in (None, 0) for rc in rcs):
+                why = "rank(s) %s exited with %s" % ([i for i, rc in enumerate(rcs) if rc not in (None, 0)], [rc for rc in rcs if rc not in (None, 0)])
+                break
+            if time.time() - last[0] > silence:
+                why = "no output from any rank for %.0f s" % silence
+                break
+            if time.time() - t0 > total_cap:
+                why = "rung exceeded %.0f s" % total_cap
+                break
+            time.sleep(0.25)
+        if why is not None:
+            _end_children(procs)
+        for t_ in threads:
+            t_.join(timeout=5)
+        rcs = [p_.poll() for p_ in procs]
+        if why is None and all(rc == 0 for rc in rcs) and lines:
+            try:
+                d = json.loads(lines[-1])
+                d.setdefault("config", {})
+                d["config"]["launcher"] = {"spawned_ranks": n, "rung": name, "fallback_from": tried or None,
+                                           "how": "bench.py started its own ranks (no external torch.distributed.run)"}
+                print(json.dumps(d), flush=True)
+            except Exception:
+                print(lines[-1], flush=True)
+            return 0
+        why = why or ("children returned %s%s" % (rcs, "" if lines else " and rank 0 printed no JSON line"))
+        print("[bench launcher] rung %r failed: %s" % (name, why), file=sys.stderr, flush=True)
+        tried.append(name)
+    print("[bench launcher] every rung failed: %s" % tried, file=sys.stderr, flush=True)
+    return 1
+
+
+def heartbeat(msg, rank=0, every_rank=False):
+    """progress line for the launcher's watchdog (stderr; any rank's output counts as a sign of life)"""
+    if rank == 0 or every_rank:
+        print("[bench] %s" % msg, file=sys.stderr, flush=True)
+
+
+def preroll(step, sync, pg, dev, window=5, tol=0.003, cap_s=1.5):
+    """internal pre-roll: run the step until two consecutive `window`-iteration blocks agree within `tol` (the clocks of an
+    idle MI355X need a few hundred ms of load to settle), at most cap_s seconds; the caller's --warmup comes after it.  With a
+    process group rank 0 decides and the others follow (one tiny broadcast per window).  -> iterations run"""
+    t_begin, prev, n = time.perf_counter(), None, 0
+    while True:
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(window):
+            step()
+        sync()
+        dt = time.perf_counter() - t0
+        n += window
+        stop = (prev is not None and abs(dt - prev) <= tol * prev) or (time.perf_counter() - t_begin > cap_s)
+        if pg is not None:
+            import torch.distributed as dist
+            flag = torch.tensor([1 if stop else 0], device=dev, dtype=torch.int32)
+            dist.broadcast(flag, src=0)
+            stop = bool(int(flag))
+        if stop:
+            return n
+        prev = dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -583,7 +762,10 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="HIP streams running independent sub-steps concurrently")
     ap.add_argument("--cpu-sample-batch", type=int, default=None,
                     help="dialogues of the CPU-baseline sample (default: the whole batch, BASELINE.md §3)")
-    ap.add_argument("--replay-family", choices=["wgrad", "gemm_generic", "attention"], default=None,
+    ap.add_argument("--launcher", choices=["auto", "spawn", "none"], default="auto",
+                    help="auto: when --gpus N > 1 and no WORLD_SIZE is set, this process starts the N ranks itself (and a fallback "
+                         "ladder of data-parallel modes if they hang); spawn: always go through that path (also at N = 1); none: never")
+    ap.add_argument("--replay-family", choices=["wgrad", "gemm_generic", "attention", "ffn_k100", "ffn_n100"], default=None,
                     help="only replay one kernel family's launch mix (warm-up pass + one timed pass): the command "
                          "tools/traffic_pmc.sh / tools/attention_pmc.sh profile with rocprofv3 --pmc, one counter set per pass")
     args = ap.parse_args()
@@ -595,11 +777,18 @@ def main():
         args.cpu_sample_batch = args.batch
     cfgname = args.config
 
+    # ---- N ranks from one command: the parent launches, the children (WORLD_SIZE set) run.  Nothing above touches the GPU.
+    is_child = "WORLD_SIZE" in os.environ or os.environ.get("GANFFN_BENCH_CHILD") == "1"
+    if args.launcher == "spawn" or (args.launcher == "auto" and args.gpus > 1 and not is_child):
+        if not is_child:
+            sys.exit(launch(args, sys.argv[1:]))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    heartbeat("rank %d of %d up (pid %d)" % (rank, world, os.getpid()), rank, every_rank=True)
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the hot path has no CPU fallback"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -611,6 +800,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
+        heartbeat("rank %d: process group up (RCCL, %d ranks)" % (rank, dist.get_world_size()), rank, every_rank=True)
 
     from gan_ffn_amd import _lib, engine, ops
     if args.config == "drnn":
@@ -625,7 +815,7 @@ def main():
     if args.replay_family:
         _lib.load()
         fn = {"wgrad": lambda S_, B_, reps: time_dominant_kernel(S_, B_, reps=reps, config=cfgname), "gemm_generic": time_generic_gemm,
-              "attention": time_attention}[args.replay_family]
+              "attention": time_attention, "ffn_k100": time_k100_family, "ffn_n100": time_n100_kernel}[args.replay_family]
         kt, kwork, klaunch = fn(args.seq, args.batch, reps=1)
         print(json.dumps({"family": args.replay_family, "avg_kernel_us": kt * 1e6, "launches": klaunch}), flush=True)
         return
@@ -654,6 +844,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    heartbeat("rank %d: engine built (dp_mode %s, %d streams)" % (rank, engine.dp_mode() if pg is not None else "none", eng.n_streams), rank, every_rank=True)
+    # internal pre-roll (not counted in --warmup): until two consecutive 5-iteration windows agree within 0.3 %, <= 1.5 s —
+    # so that the line does not depend on how many warm-up steps the caller asked for
+    n_preroll = 0 if os.environ.get("GANFFN_BENCH_PREROLL", "1") == "0" else preroll(lambda: eng.iteration(batch), sync, pg, dev)
+    heartbeat("rank %d: pre-roll %d iterations" % (rank, n_preroll), rank, every_rank=True)
     for _ in range(args.warmup):
         eng.iteration(batch)
     sync()
@@ -663,19 +858,43 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     losses = eng.loss_dict()
+    heartbeat("rank %d: %d timed steps, %.3f ms per step" % (rank, args.steps, dt / args.steps * 1e3), rank, every_rank=True)
+    # second, separately timed block (median over >= 20 device-synchronised iterations): here every iteration
+    # is bracketed by a device synchronisation (+ barrier), so consecutive iterations do NOT overlap as they do in the block
+    # above — it reads a little slower and is reported beside the headline, never instead of it
+    per_iter = []
+    for _ in range(0 if args.step_only else max(20, min(args.steps, 60))):
+        sync()
+        t1 = time.perf_counter()
+        eng.iteration(batch)
+        sync()
+        per_iter.append((time.perf_counter() - t1) * 1e3)
+    per_iter.sort()
 
     utts = torch.tensor([float(batch["umask"].sum()), dt], device=dev, dtype=torch.float64)
+    rank_ms = [dt / args.steps * 1e3]
     if pg is not None:
         import torch.distributed as dist
         tmax = utts[1:2].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         usum = utts[0:1].clone()
         dist.all_reduce(usum, op=dist.ReduceOp.SUM)
+        allt = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allt, utts[1:2].clone())
+        rank_ms = [float(t_) / args.steps * 1e3 for t_ in allt]
         dt, total_utts = float(tmax), float(usum)
     else:
         total_utts = float(utts[0])
     ms_per_step = dt / args.steps * 1e3
     value = total_utts * args.steps / dt
+    if pg is not None:
+        import torch.distributed as dist
+    dist_info = {"rccl_ranks": dist.get_world_size() if pg is not None else 0,          # ranks RCCL really connected (0: no process group)
+                 "dp_mode": engine.dp_mode() if pg is not None else None,
+                 "communicators": len(getattr(eng, "pgs", [None])) if pg is not None else 0,
+                 "launcher_rung": os.environ.get("GANFFN_BENCH_RUNG"),
+                 "fallback_from": [x for x in os.environ.get("GANFFN_BENCH_FALLBACK_FROM", "").split(",") if x] or None,
+                 "ms_per_step_min_max_over_ranks": [round(min(rank_ms), 3), round(max(rank_ms), 3)]}
     if rank == 0:
         print("[bench] gpu: %.3f ms/step, %.1f utterances/s (%s)" % (ms_per_step, value, "hipGraph" if use_graph else "eager"),
               file=sys.stderr, flush=True)
@@ -683,7 +902,7 @@ def main():
     if rank == 0 and args.step_only:
         print(json.dumps({"metric": "utterances/sec per GAN train step (step only)", "value": round(value, 2), "unit": "utterances/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-                          "config": {"workload": cfgname, "streams": eng.n_streams}}), flush=True)
+                          "config": dict({"workload": cfgname, "streams": eng.n_streams, "preroll_iterations": n_preroll}, **dist_info)}), flush=True)
     elif rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import roofline_model as RM
@@ -707,6 +926,18 @@ def main():
                        "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager", "streams": eng.n_streams,
                        "step_tflops_reference_equivalent": round(step_tflops, 2),
                        "step_frac_of_fp32_mfma_peak": round(step_tflops * 1e12 / (FP32_MFMA_PEAK * world), 4),
+                       # what the engine EXECUTES: the reference computes the frozen discriminator's weight gradients in
+                       # train_gen and never uses them (train_IEMOCAP.py:216 zeroes them first); the engine skips those 6 passes
+                       "step_tflops_executed": round(step_tflops * (1.0 - frozen_wgrad_flops_per_token(cfgname) / fpt), 2),
+                       "step_frac_executed": round(step_tflops * (1.0 - frozen_wgrad_flops_per_token(cfgname) / fpt) * 1e12 / (FP32_MFMA_PEAK * world), 4),
+                       "preroll_iterations": n_preroll,
+                       "median_ms_per_step_synchronised": round(per_iter[len(per_iter) // 2], 3) if per_iter else None,
+                       "min_max_ms_per_step_synchronised": [round(per_iter[0], 3), round(per_iter[-1], 3)] if per_iter else None,
+                       "synchronised_iterations": len(per_iter),
+                       "timing": "ms_per_step / value: EXACTLY --steps iterations between two barrier + device-synchronise points "
+                                 "(consecutive iterations overlap on the three streams, as in training); median_ms_per_step_synchronised: "
+                                 "a second block, device-synchronised at every iteration boundary (SURVEY.md 8d)",
+                       **dist_info,
                        "last_losses": {k: round(v, 4) for k, v in losses.items()}},
         }
         if cfgname != "iemocap":
@@ -729,7 +960,7 @@ def main():
             current = profile_is_current(IN_STEP_FILE)
             instep = RM.in_step(prof_path, S, B) if (full and os.path.exists(prof_path)) else None
             live = {}
-            for key, fn in (("gemm_generic", time_generic_gemm), ("ffn_k100", time_linear1_kernel), ("ffn_n100", time_n100_kernel),
+            for key, fn in (("gemm_generic", time_generic_gemm), ("ffn_k100", time_k100_family), ("ffn_n100", time_n100_kernel),
                             ("wgrad", lambda S_, B_: time_dominant_kernel(S_, B_, config=cfgname)), ("attention", time_attention)):
                 t_, w_, n_ = fn(S, B)
                 live[key] = dict(avg_kernel_us=round(t_ * 1e6, 2), avg_gflop_per_launch=round(w_ / 1e9, 4), launches_replayed=n_,
@@ -752,29 +983,53 @@ def main():
                     d.update(achieved=d.get("in_step_achieved"), frac=d.get("in_step_frac"), avg_kernel_us=None,
                              live="not replayed in isolation (its launches only exist inside an encoder pass): in-step figures only")
                 fams.append(d)
-            dom = fams[0]
+            # a stale profile (taken on other kernel sources) ranks nothing: dominant / worst are then chosen among the families
+            # replayed live, on their live fractions
+            rankable = fams if current or not instep else [d for d in fams if d["family"] in live]
+            dom = rankable[0] if current or not instep else max(rankable, key=lambda d: d["avg_kernel_us"] * d["launches_replayed"])
             traffic = committed_traffic(S, B, GEMM_TRAFFIC_FILE if dom["family"] == "gemm_generic" else TRAFFIC_FILE)
+            alg_bytes = round(generic_gemm_algorithmic_bytes(S, B)) if dom["family"] == "gemm_generic" else \
+                (round(wgrad_algorithmic_bytes(S, B, cfgname)) if dom["family"] == "wgrad" else None)
+            traffic_note = None
+            if traffic is not None and alg_bytes and dom.get("avg_kernel_us"):
+                rate = traffic / (dom["avg_kernel_us"] * 1e-6) / 1e12
+                traffic_note = ("%.2fx the algorithmic bytes; %s: %.1f MB per %.1f us launch = %.2f TB/s of the 8 TB/s HBM peak"
+                                % (traffic / alg_bytes, "NOT the bound" if rate < 0.5 * HBM_PEAK_GBS / 1e3 else "close to the HBM roof",
+                                   traffic / 1e6, dom["avg_kernel_us"], rate)) + \
+                    ("; the excess over 1x is the weight operand, which each of the 8 XCDs reads through its own L2"
+                     if dom["family"] == "gemm_generic" else "")
             out["roofline"] = {
                 "bound": dom["bound"], "kernel": dom["kernel"], "family": dom["family"],
                 "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
-                "traffic": traffic,
+                "traffic": traffic, "traffic_note": traffic_note,
                 "traffic_unit": ("bytes per launch, averaged over the replayed launch mix (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE, "
                                  "separate rocprofv3 --pmc passes: " + (GEMM_TRAFFIC_FILE if dom["family"] == "gemm_generic" else TRAFFIC_FILE) + ")")
                 if traffic is not None else None,
-                "algorithmic_bytes_per_launch": round(generic_gemm_algorithmic_bytes(S, B)) if dom["family"] == "gemm_generic" else
-                (round(wgrad_algorithmic_bytes(S, B, cfgname)) if dom["family"] == "wgrad" else None),
+                "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_kernel_us": dom.get("avg_kernel_us"), "avg_gflop_per_launch": dom.get("avg_gflop_per_launch"),
-                "share_of_step_kernel_time_pct": dom.get("share_pct"), "in_step_frac": dom.get("in_step_frac"),
+                "share_of_step_kernel_time_pct": dom.get("share_pct"), "in_step_frac": dom.get("in_step_frac") if current else None,
                 "how": "the kernel family with the largest share of GPU time in the committed single-stream rocprofv3 summary " + IN_STEP_FILE +
                        " (chosen by tools/roofline_model.py, not by hand); achieved / frac = algorithmic FLOPs per launch / average launch "
                        "duration of one iteration's launch mix of that family replayed live in isolation, HIP events on the launch stream; "
                        "in_step_frac = the family's algorithmic FLOPs per iteration / its kernel time per iteration inside the "
-                       "single-stream step, from that summary" + ("" if current else " (STALE: taken on other kernel sources)")}
+                       "single-stream step, from that summary" +
+                       ("" if current else " (the committed summary is STALE — taken on other kernel sources: the family was chosen "
+                                           "among the live replays by replayed time, in-step figures are not used)")}
             out["roofline_families"] = fams
-            worst = min(fams, key=lambda d: d.get("in_step_frac") if d.get("in_step_frac") is not None else d["frac"])
-            out["roofline_worst"] = dict(worst)
-            out["roofline_worst"]["how"] = ("the lowest in-step roofline fraction among the kernel families with >= 5 % of the step's "
-                                            "kernel time (every such family is listed in roofline_families)")
+
+            def rank_frac(d):
+                return d["in_step_frac"] if (current and d.get("in_step_frac") is not None) else d["frac"]
+            # the worst family PER ROOF: fractions of the MFMA peak and of the HBM peak are not comparable
+            for bound, key in (("mfma", "roofline_worst"), ("hbm", "roofline_worst_hbm")):
+                cands = [d for d in rankable if d["bound"] == bound]
+                if not cands:
+                    continue
+                worst = min(cands, key=rank_frac)
+                out[key] = dict(worst)
+                out[key]["how"] = ("the lowest %s roofline fraction among the %s-bound kernel families with >= 5 %% of the step's kernel "
+                                   "time (every such family is listed in roofline_families; the other roof's worst family is in %s)"
+                                   % ("in-step" if current and worst.get("in_step_frac") is not None else "live", bound,
+                                      "roofline_worst_hbm" if bound == "mfma" else "roofline_worst"))
             out["profile"] = {"file": IN_STEP_FILE, "matches_kernel_sources": current,
                               "kernel_time_ms_per_iteration_single_stream": instep["kernel_time_ms_per_iteration"] if instep else None,
                               "families_cover_pct": round(sum(d.get("share_pct", 0) for d in fams), 1) if instep else None}

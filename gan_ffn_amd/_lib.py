@@ -81,6 +81,7 @@ SIGNATURES = {
     "ganffn_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),
     "ganffn_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),
     "ganffn_gemm_hook": (_I, [_I, _I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _U32, _P, _U64, _I, _I, _P, _P]),
+    "ganffn_ffn_k100_hook": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _F, _U32, _P, _U64, _I, _P]),
     "ganffn_attention_keep_words": (_L, [_I, _I]),
     "ganffn_attention_fwd_keep": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),
     "ganffn_attention_bwd_keep": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),

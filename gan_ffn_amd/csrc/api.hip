@@ -690,6 +690,27 @@ extern "C" int ganffn_gemm_hook(int mode, int epi, const float* A, const float* 
     if (n_slabs) *n_slabs = splits;
     return 0;
 }
+// measurement hook: the K = 100 -> 2048 products of the d_model-100 feed-forward block with the arguments the encoder stack
+// gives them (bench.py --replay-family ffn_k100, tools/family_pmc.sh)
+extern "C" int ganffn_ffn_k100_hook(int which, const float* a, const float* w, const float* bias, float* out, void* hmask,
+                                    const float* h_saved, int T, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
+                                    void* stream) {
+    GF_CHECK_ARG((which == 0 || which == 1) && a && w && out && T > 0, "ffn_k100_hook: bad arguments");
+    const int E = 100, F = 2048;
+    EpiArgs e;
+    if (which == 0) {
+        GF_CHECK_ARG(bias, "ffn_k100_hook: linear1 needs its bias");
+        GF_CHECK_ARG(!(train && p > 0.f) || rng, "ffn_k100_hook: rng required when dropout is active");
+        e.bias = bias; e.p = p; e.site = site; e.rng = rng; e.rng_add = add; e.train = train;
+        e.mask_out = reinterpret_cast<uint16_t*>(hmask);
+        return launch_gemm_nt(a, E, w, E, out, F, T, F, E, EPI_RELU_DROP, e, (hipStream_t)stream);
+    }
+    GF_CHECK_ARG(hmask || h_saved, "ffn_k100_hook: the linear2 dgrad needs the pattern bits or the saved activation");
+    e.aux_in = h_saved;
+    e.mask_in = reinterpret_cast<const uint16_t*>(hmask);
+    e.mscale = (train && p > 0.f) ? 1.f / (1.f - p) : 1.f;
+    return launch_gemm_nn(a, E, w, F, out, F, T, F, E, EPI_MASK_POS, e, (hipStream_t)stream);
+}
 extern "C" int ganffn_gemm_n100(const float* A, const float* W, int w_kmajor, const float* bias, float* slabs, int64_t slab_stride,
                                 int T, int K, int max_slabs, int* n_slabs, void* stream) {
     GF_CHECK_ARG(n_slabs && max_slabs >= 1 && max_slabs <= MAX_SPLITS, "gemm_n100: max_slabs=%d out of [1,%d]", max_slabs, MAX_SPLITS);

@@ -267,7 +267,10 @@ __device__ __forceinline__ void gemm_load_aux(const GemmArgs& g, float (&aux)[TM
 #pragma unroll
                     for (int b = 0; b < TN; ++b) {
                         const int col = min(nbase + b * 32 + r, g.N - 1);
-                        const uint32_t w = g.ea.mask_in[((size_t)((mbase + a * 32) >> 5) * g.N + col) * 2 + h];
+                        // row tile clamped like the aux_in rows below: a wave whose 32 rows lie wholly past M (M % 64 in 1..32)
+                        // would read one tile past the ceil(M / 32)-tile pattern (its outputs are never stored)
+                        const int rt = min((mbase + a * 32) >> 5, (g.M - 1) >> 5);
+                        const uint32_t w = g.ea.mask_in[((size_t)rt * g.N + col) * 2 + h];
 #pragma unroll
                         for (int i = 0; i < 16; ++i) aux[a][b][i] = 0.f;
                         aux[a][b][0] = __uint_as_float(w);

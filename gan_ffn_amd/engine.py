@@ -307,6 +307,18 @@ class GanEngine(_Runner):
         # One communicator per sub-step stream (default in the in-line mode, see dp_mode(); GANFFN_COMM_PER_STREAM overrides).
         self.pgs = [process_group]
         per_stream = os.environ.get("GANFFN_COMM_PER_STREAM", "1" if dp_mode() == "inline" else "0") == "1"
+        if process_group is not None and self.n_streams > 1 and not per_stream and dp_mode() == "inline":
+            import torch.distributed as dist
+            if dist.get_backend(process_group) == "nccl":
+                # in-line collectives of different sub-step streams would share ONE RCCL communicator and may be in flight
+                # together: RCCL (like NCCL) does not support that.  (gloo reduces on the host, synchronously: no such limit.)
+                raise RuntimeError("GANFFN_DP_MODE=inline with %d sub-step streams needs one communicator per stream: "
+                                   "leave GANFFN_COMM_PER_STREAM at 1, or use n_streams=1, or GANFFN_DP_MODE=buckets" % self.n_streams)
+        # Ordering assumption of the in-line mode: every rank runs the SAME host program, so the
+        # collectives of the three communicators are issued in the same host order on every rank; whatever order a rank's
+        # hardware queues impose is a sub-order of that one, so no two ranks can wait on each other's collectives in a cycle.
+        # Never measured on more than one rank (no multi-GPU node was available): `python bench.py --gpus N` therefore runs
+        # under a watchdog that falls back to one stream / one communicator and then to the bucket mode.
         if process_group is not None and self.n_streams > 1 and per_stream:
             # in-line collectives run on the sub-step streams themselves; two of them may be in flight at once, and one
             # communicator must never carry two collectives concurrently: one communicator per sub-step stream (every rank

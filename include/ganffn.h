@@ -362,6 +362,16 @@ int ganffn_gemm_hook(int mode, int epi, const float* A, const float* W, const fl
                      int64_t slab_stride, int M, int N, int K, float p, uint32_t site, const uint64_t* rng,
                      uint64_t rng_offset_add, int train, int max_slabs, int* n_slabs, void* stream);
 
+/* Measurement hook: the K = 100 -> 2048 products of the d_model-100 feed-forward block (csrc/gemm.hip gemm_wres_kernel) with the
+ * arguments ganffn_encoder_fwd / _bwd give them (linear1 / linear2 of nn.TransformerEncoderLayer, call sites model.py:1210,1307).
+ * which 0: out[T x 2048] = dropout_p(relu(a[T x 100] w[2048 x 100]^T + bias)); hmask != NULL: also the 1-bit [out > 0] pattern
+ *          (ceil(T/32) * 2048 floats) a saved pass leaves for the backward.
+ * which 1: out[T x 2048] = (a[T x 100] w[100 x 2048]) * pattern / (1-p) — the linear2 dgrad; pattern from hmask when given,
+ *          else from h_saved [T x 2048] > 0. */
+int ganffn_ffn_k100_hook(int which, const float* a, const float* w, const float* bias, float* out, void* hmask,
+                         const float* h_saved, int T, float p, uint32_t site, const uint64_t* rng, uint64_t rng_offset_add,
+                         int train, void* stream);
+
 /* A/B measurement hook (process-wide), a bit mask; 0 = the default path.
  *   bit 0: run the d_model-100 feed-forward block as the fused kernel of ffn.hip instead of two GEMMs (measured slower);
  *   bit 1: run the token-local chains around the LayerNorms of a d_model-100 layer (out-proj + LN1, LN2 + next in-proj and

@@ -2,7 +2,7 @@
 # north_star's "MFMA utilisation on the attention GEMMs against gfx950 peak": SQ counters of the attention kernels over one
 # iteration's launch mix (bench.py --replay-family attention: attn16_fwd/bwd<10,6,..> at 320 and 640 (dialogue, head)
 # problems, attention_fwd/bwd<64,3> at 256), rocprofv3 --pmc with --kernel-trace only (one counter set per pass, program
-# directly after `--`).  Run from the repo root on the GPU box; writes gpurun_out/r04_attention_pmc.json.
+# directly after `--`).  Run from the repo root on the GPU box; writes gpurun_out/r05_attention_pmc.json.
 set -e
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
@@ -56,7 +56,7 @@ for key, c in sorted(agg.items()):
             if n in m:
                 row[n + "_frac_of_wave_cycles"] = round(m[n] / m["SQ_WAVE_CYCLES"], 4)
     out["kernels"][key] = row
-json.dump(out, open("gpurun_out/r04_attention_pmc.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r05_attention_pmc.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:6000])
 PY
 rm -rf gpurun_out/pmc_attn1 gpurun_out/pmc_attn2

@@ -1,6 +1,6 @@
 # The N = 1 point of the scaling curve on one GPU: the plain engine against the data-parallel code path with a 1-rank RCCL
 # group (GANFFN_FORCE_DIST=1: bucketed backward in 4-5 layer ranges, async all-reduce per bucket, Adam per bucket), same
-# box, interleaved, step only.  Writes gpurun_out/r04_bench_dist1.json.
+# box, interleaved, step only.  Writes gpurun_out/r05_bench_dist1.json.
 R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
@@ -20,6 +20,6 @@ p, d = min(rows["plain"]), min(rows["dist1"])
 out = {"what": "ms per GAN step at 1 rank, 3 streams, step only: the plain engine against the data-parallel path with a 1-rank RCCL group "
                "(GANFFN_FORCE_DIST=1), same box, interleaved runs", "plain_ms": rows["plain"], "dist1_ms": rows["dist1"],
        "best_plain_ms": p, "best_dist1_ms": d, "overhead_pct": round(100 * (d / p - 1), 2)}
-json.dump(out, open("gpurun_out/r04_bench_dist1.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r05_bench_dist1.json", "w"), indent=1)
 print(json.dumps(out))
 PY

@@ -1,8 +1,8 @@
 #!/bin/bash
 # HBM-side traffic of a kernel family's launch mix, per MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE in SEPARATE
 # rocprofv3 --pmc passes (kernel trace only), FETCH_SIZE doubled on gfx950.  Run from the repo root on the GPU box:
-#   bash tools/traffic_pmc.sh wgrad          -> gpurun_out/r04_wgrad_traffic.json
-#   bash tools/traffic_pmc.sh gemm_generic   -> gpurun_out/r04_gemm_traffic.json
+#   bash tools/traffic_pmc.sh wgrad          -> gpurun_out/r05_wgrad_traffic.json
+#   bash tools/traffic_pmc.sh gemm_generic   -> gpurun_out/r05_gemm_traffic.json
 # (copied into profiles/ afterwards; the raw per-dispatch CSVs stay under gpurun_out/).
 set -e
 FAM=${1:-wgrad}
@@ -40,7 +40,7 @@ out = {"family": fam, "kernel": table["title"], "seq_len": 94, "dialogues_per_gp
        "traffic_bytes_per_launch": round(2 * fetch_kb * 1024 + write_kb * 1024), "csrc_sha16": RM.csrc_sha16(),
        "method": "rocprofv3 --kernel-trace --pmc <one counter per pass> -- python3 bench.py --replay-family %s; averages over the "
                  "launches of one iteration's mix, warm-up pass included; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B)" % fam}
-name = {"wgrad": "r04_wgrad_traffic.json", "gemm_generic": "r04_gemm_traffic.json"}.get(fam, "r04_%s_traffic.json" % fam)
+name = {"wgrad": "r05_wgrad_traffic.json", "gemm_generic": "r05_gemm_traffic.json"}.get(fam, "r05_%s_traffic.json" % fam)
 json.dump(out, open("gpurun_out/" + name, "w"), indent=1)
 print(json.dumps(out))
 PY
