@@ -106,33 +106,9 @@ static int check_cfg(const ganffn_enc_cfg* c) {
     return 0;
 }
 
-// d_model = 100 feed-forward block: two GEMMs (default) or the fused kernel of ffn.hip (ganffn_debug_set_ffn_mode(1)).
-// Both paths are parity-tested.  Measured on MI355X, in-step, single stream (profiles/README.md): fused 48 / 52 us
-// (forward / dgrad, T = 3008) and 88 / 93 us (T = 6016) against 52 / 50 us and 74 / 75 us for the GEMM pairs — the fused
-// kernel streams 30 KB of packed weights per (32 tokens x 32 hidden units) and is bound by L2 -> CU bandwidth
-// (357 MB per launch at T = 6016), so it stays opt-in.
-int g_ffn_fused = 0;
-// bit 7 of ganffn_debug_set_ffn_mode: the forward feed-forward block of d_model 100 as ffn3.hip's single kernel (opt-in:
-// 34.6 against 43.8 us in isolation, +0.4 ms in the three-stream step — the measurement is in ffn3.hip's header)
-int g_ffn3 = 0;
-// bit 25: the linear2 dgrad reads the saved hidden activation for its ReLU / dropout pattern (round 3's form) instead of the
-// 1-bit copy linear1's epilogue leaves beside it
-int g_mask_float = 0;
-int g_outproj_nosplit = 0;   // bit 24: the out-proj of the wide (d_model != 100) stacks unsplit (round 3's form)
-int g_ffn3_wide = 0;   // bit 22: also at T > 4096 (the 128-token variant)
-// d_model = 100: the token-local chains around the LayerNorms run as single kernels (rowchain.hip); bit 1 of
-// ganffn_debug_set_ffn_mode switches back to the separate GEMM + LayerNorm launches (both paths are parity-tested)
-int g_rc_off = 0;
-// N = 100, long-K products (linear2 forward, linear1 dgrad) on the 112-wide 16x16x4 kernel (gemm_n100.hip); bit 2 of
-// ganffn_debug_set_ffn_mode switches back to the generic 64 x 64 tiles
-int g_n100_off = 0;
-// the discriminator head as one kernel per direction (disc_head.hip); bit 5 of ganffn_debug_set_ffn_mode switches back to
-// the separate GELU / GEMM / tail launches
-int g_dhead_off = 0;
-// bit 6: positional encoding + dropout and layer 0's in-proj as two launches instead of rowchain.hip's one
-int g_pe_off = 0;
-extern int g_n100_force_splits, g_n100_force_kw, g_n100_pad7;
-extern int g_tn100_off, g_tn100_force_splits, g_tn100_in_kernel_sum;
+// A/B switches: one atomic word (common.h `Mode`); what each bit selects and what was measured is in include/ganffn.h and
+// DESIGN.md section 6.
+std::atomic<uint32_t> g_mode_word{0};
 GF_LAB_ONLY(extern unsigned long long* g_n100_stamps; extern unsigned long long* g_wres_stamps;)
 constexpr int MAX_SPLITS = 16;  // partial-output slabs: fused FFN (16 F splits) / split-K GEMMs (<= 8)
 
@@ -209,6 +185,7 @@ extern "C" int64_t ganffn_encoder_workspace_floats(const ganffn_enc_cfg* c) {
 extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, const float* pe, const float* params,
                                   float* out, float* saved, float* workspace, const uint64_t* rng, uint64_t add,
                                   void* stream) {
+    const Mode md = mode();
     GF_TRY(check_cfg(c));
     GF_CHECK_ARG(x_in && pe && params && out && workspace, "encoder_fwd: null pointer");
     GF_CHECK_ARG(aligned16(x_in) && aligned16(params) && aligned16(out) && aligned16(workspace) && (!saved || aligned16(saved)),
@@ -232,15 +209,15 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
         Xcur = workspace;
     }
     // d_model 100: the feed-forward block runs as ONE fused kernel per layer on weights packed in MFMA fragment order
-    const bool fused = ffn_fused_supported(E, F) && g_ffn_fused;
+    const bool fused = ffn_fused_supported(E, F) && md.ffn_fused();
     float* pack = tmp + (int64_t)MAX_SPLITS * TE;
     const int64_t PK = fused ? ffn_pack_floats(F) : 0;
     if (fused) GF_TRY(launch_ffn_pack(params, lo.total, lo.w1, lo.w2, pack, L, F, 0, st));
     // d_model 100: out-proj + residual + dropout + LN1 is one kernel, and LN2 carries the NEXT layer's in-proj (rowchain.hip);
     // the positional encoding + dropout at the head of the stack carries layer 0's
-    const bool rc = rc_supported(E) && !g_rc_off;
+    const bool rc = rc_supported(E) && !md.rc_off();
     auto layer_saved = [&](int l) { return saved ? saved + so.layers + (int64_t)l * so.per_layer : workspace + 2 * TE; };
-    if (rc && !g_pe_off) {
+    if (rc && !md.pe_off()) {
         GF_TRY(launch_rc_pe_inproj_fwd(x_in, pe, Xcur, params + lo.in_w, params + lo.in_b, layer_saved(0) + so.qkv, T, B, c->p_pe, rng,
                                        add, train, st));
     } else {
@@ -273,14 +250,14 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
         } else {
             ea.bias = P + lo.out_b;
             // (the 512-wide out-proj is 376 output tiles on 256 CUs: K in two halves, summed by the LayerNorm kernel)
-            int osplits = g_outproj_nosplit ? 1 : gemm_splitk_factor(T, E, E);
+            int osplits = md.outproj_nosplit() ? 1 : gemm_splitk_factor(T, E, E);
             GF_TRY(launch_gemm_nt(sv + so.attn_o, E, P + lo.out_w, E, tmp, E, T, E, E, EPI_NONE, ea, st, &osplits, TE));
             GF_TRY(launch_add_drop_ln_fwd(Xcur, tmp, P + lo.n1w, P + lo.n1b, sv + so.x1, sv + so.xhat1, sv + so.rstd1, T, E,
                                           c->ln_eps, c->p_enc, site + 1, rng, add, train, st, osplits, TE));
         }
         // FFN: h = drop(relu(x1 W1^T + b1)); y = h W2^T + b2
         int splits = 1;
-        if (g_ffn3 && ffn3_supported(E, F) && (T <= 4096 || g_ffn3_wide)) {
+        if (md.ffn3() && ffn3_supported(E, F) && (T <= 4096 || md.ffn3_wide())) {
             GF_TRY(launch_ffn3_fwd(sv + so.x1, P + lo.w1, P + lo.b1, P + lo.w2, P + lo.b2, saved ? sv + so.h : nullptr, tmp, TE, T,
                                    c->p_enc, site + 2, rng, add, train, MAX_SPLITS, &splits, st));
         } else if (fused) {
@@ -292,7 +269,7 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
             e1.bias = P + lo.b1; e1.p = c->p_enc; e1.site = site + 2; e1.rng = rng; e1.rng_add = add; e1.train = train;
             if (saved) e1.mask_out = reinterpret_cast<uint16_t*>(sv + so.hmask);     // the pattern the linear2 dgrad will ask for
             GF_TRY(launch_gemm_nt(sv + so.x1, E, P + lo.w1, E, sv + so.h, F, T, F, E, EPI_RELU_DROP, e1, st));
-            if (n100_supported(E, F) && !g_n100_off) {
+            if (n100_supported(E, F) && !md.n100_off()) {
                 splits = MAX_SPLITS;                   // K chunks = output slabs, summed by the LayerNorm kernel
                 GF_TRY(launch_gemm_n100(sv + so.h, F, P + lo.w2, F, 0, P + lo.b2, tmp, TE, T, F, &splits, st));
             } else {
@@ -331,6 +308,7 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
 extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int layer_hi, float* dx, const float* params,
                                    float* grads, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
                                    int need_dx_in, void* stream) {
+    const Mode md = mode();
     GF_TRY(check_cfg(c));
     GF_CHECK_ARG(dx && params && saved && workspace, "encoder_bwd: null pointer");
     GF_CHECK_ARG(0 <= layer_lo && layer_lo < layer_hi && layer_hi <= c->L, "encoder_bwd: bad layer range [%d,%d)", layer_lo, layer_hi);
@@ -359,17 +337,18 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
     float* lnp0 = tmp + (int64_t)MAX_SPLITS * TE;   // [L][2] LayerNorm partial-sum blocks
     const int64_t LNP = ln_part_floats(c);
     float* pack = lnp0 + (int64_t)c->L * 2 * LNP;    // packed FFN weights of the layers of this range (backward orientation)
-    const bool fused = ffn_fused_supported(E, F) && g_ffn_fused;
+    const bool fused = ffn_fused_supported(E, F) && md.ffn_fused();
     const int64_t PK = fused ? ffn_pack_floats(F) : 0;
     float* tnp = pack + (ffn_fused_supported(E, F) ? (int64_t)c->L * ffn_pack_floats(F) : 0);   // grouped-wgrad partial slabs
     tnp = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(tnp) + 15) & ~(uintptr_t)15);
     if (fused)
         GF_TRY(launch_ffn_pack(params + (int64_t)layer_lo * lo.total, lo.total, lo.w1, lo.w2, pack, layer_hi - layer_lo, F, 1, st));
-    const bool rc = rc_supported(E) && !g_rc_off;
+    const bool rc = rc_supported(E) && !md.rc_off();
     float* rcw = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(tnp + gemm_tn_grouped_part_floats()) + 15) & ~(uintptr_t)15);
     const int64_t RCW = rc_pack_floats();              // per layer: in_w^T [E x 3E] | out_w^T [E x E]
     if (rc) GF_TRY(launch_rc_pack(params + (int64_t)layer_lo * lo.total, lo.total, lo.in_w, lo.out_w, rcw, layer_hi - layer_lo, st));
     const int lnblk = rc ? rc_blocks(T) : ln_bwd_blocks(T);
+    const int dq_parts = (rc && !md.attn_split_off()) ? attn16_bwd_split_parts(E, H, S) : 1;
     TnDesc tn[40];
     int ntn = 0;
     float* r_gw[2 * 64]; float* r_gb[2 * 64]; const float* r_part[2 * 64]; int r_nb[2 * 64];
@@ -400,9 +379,10 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
                 GF_TRY(launch_rc_ln_bwd(nullptr, nullptr, dx, 1, 0, nullptr, sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dyA,
                                         G ? lnp2 : nullptr, nullptr, nullptr, T, c->p_enc, site + 3, rng, add, train, st));
             else
+                // (+ the partial dQ slabs the key-split attention backward of layer l + 1 left in `tmp`)
                 GF_TRY(launch_rc_ln_bwd(bs + SET + TF + 2 * TE, rcw + (int64_t)(l + 1 - layer_lo) * RCW, nullptr, 0, 0, dz1,
                                         sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dyA, G ? lnp2 : nullptr, nullptr, nullptr, T,
-                                        c->p_enc, site + 3, rng, add, train, st));
+                                        c->p_enc, site + 3, rng, add, train, st, tmp, dq_parts, TE));
         } else {
             GF_TRY(launch_add_drop_ln_bwd(dxin, sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dyA, G ? G + lo.n2w : nullptr,
                                           G ? G + lo.n2b : nullptr, T, E, c->p_enc, site + 3, rng, add, train, st, dxin_slabs, TE,
@@ -421,15 +401,15 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
             em.aux_in = sv + so.h;
             em.mscale = mscale;
             // the forward's two-GEMM path left the pattern as bits (the one-kernel forwards, debug bits 0 / 7, do not)
-            const bool fwd_was_ffn3 = g_ffn3 && ffn3_supported(E, F) && (T <= 4096 || g_ffn3_wide);
-            if (!fwd_was_ffn3 && !g_mask_float) em.mask_in = reinterpret_cast<const uint16_t*>(sv + so.hmask);
+            const bool fwd_was_ffn3 = md.ffn3() && ffn3_supported(E, F) && (T <= 4096 || md.ffn3_wide());
+            if (!fwd_was_ffn3 && !md.mask_float()) em.mask_in = reinterpret_cast<const uint16_t*>(sv + so.hmask);
             GF_TRY(launch_gemm_nn(dyA, E, P + lo.w2, F, dh, F, T, F, E, EPI_MASK_POS, em, st));
         }
         // linear1 wgrad: gW1[F,E] += dh^T x1 ; gb1 += colsum(dh)
         if (G) tn[ntn++] = TnDesc{dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T};
         if (!fused) {
             // d x1 = dh W1 (split-K slabs) + dz2, consumed directly by the LN1 backward
-            if (n100_supported(E, F) && !g_n100_off) {
+            if (n100_supported(E, F) && !md.n100_off()) {
                 splits = MAX_SPLITS;
                 GF_TRY(launch_gemm_n100(dh, F, P + lo.w1, E, 1, nullptr, tmp, TE, T, F, &splits, st));
             } else {
@@ -452,8 +432,14 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
         if (G) tn[ntn++] = TnDesc{dyB, E, sv + so.attn_o, E, G + lo.out_w, E, G + lo.out_b, E, E, T};
         if (!rc) GF_TRY(launch_gemm_nn(dyB, E, P + lo.out_w, E, d_attn, E, T, E, E, EPI_NONE, none, st));
         // attention core backward
-        GF_TRY(launch_attention_bwd(sv + so.qkv, sv + so.attn_o, sv + so.lse, d_attn, reinterpret_cast<const uint32_t*>(sv + so.keep), d_qkv, S, B, E,
-                                    H, c->p_enc, site + 0, rng, add, train, st));
+        // d_model 100 (head_dim 10), every layer but the bottom one of the range: split by key tiles, dQ as partial slabs in `tmp`
+        // (free between this layer's LN1 backward and the next linear1 dgrad), summed by the rowchain kernel that reads d_qkv next
+        if (dq_parts > 1 && l > layer_lo)
+            GF_TRY(launch_attn16_bwd_split(sv + so.qkv, sv + so.attn_o, sv + so.lse, d_attn, reinterpret_cast<const uint32_t*>(sv + so.keep),
+                                           d_qkv, tmp, TE, S, B, E, H, c->p_enc, site + 0, rng, add, train, st));
+        else
+            GF_TRY(launch_attention_bwd(sv + so.qkv, sv + so.attn_o, sv + so.lse, d_attn, reinterpret_cast<const uint32_t*>(sv + so.keep), d_qkv, S, B, E,
+                                        H, c->p_enc, site + 0, rng, add, train, st));
         // in-proj wgrad + dgrad; dX[l] = d_qkv W_in + dz1
         if (G) tn[ntn++] = TnDesc{d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T};
         if (ntn == 40 || (l == layer_lo && ntn > 0)) {
@@ -516,6 +502,7 @@ extern "C" int ganffn_head_fwd(const ganffn_head_cfg* c, const float* x, const f
                                const float* b2, const float* w3, const float* b3, float* out, float* saved, float* workspace,
                                const uint64_t* rng, uint64_t add, void* stream) {
     GF_TRY(check_head(c));
+    const Mode md = mode();
     GF_CHECK_ARG(x && w1 && b1 && w2 && b2 && out && saved, "head_fwd: null pointer");
     GF_CHECK_ARG(c->kind == 0 || (w3 && b3), "head_fwd: disc needs fc3");
     GF_CHECK_ARG(!(c->train && c->p > 0.f) || rng, "head_fwd: rng required in train mode");
@@ -533,7 +520,7 @@ extern "C" int ganffn_head_fwd(const ganffn_head_cfg* c, const float* x, const f
         GF_TRY(launch_gemm_nt(s0, E, w1, E, a1, D1, T, D1, E, EPI_DROP_GELU, e, st));
         e.bias = b2; e.site = SITE_HEAD2; e.aux_out = u2;
         GF_TRY(launch_gemm_nt(a1, D1, w2, D1, out, D2, T, D2, D1, EPI_DROP_GELU, e, st));
-    } else if (disc_head_fused_supported(E, D1, D2) && !g_dhead_off) {
+    } else if (disc_head_fused_supported(E, D1, D2) && !md.dhead_off()) {
         float* a2 = u2 + (int64_t)T * D2;
         float* prob = a2 + (int64_t)T * D2;
         GF_TRY(launch_disc_head_fwd(x, w1, b1, w2, b2, w3, b3, s0, u1, a1, u2, a2, prob, out, T, c->p, rng, add, train, st));
@@ -558,6 +545,7 @@ extern "C" int ganffn_head_bwd(const ganffn_head_cfg* c, const float* d_out, con
                                float* dx, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
                                void* stream) {
     GF_TRY(check_head(c));
+    const Mode md = mode();
     GF_CHECK_ARG(d_out && x && w1 && w2 && dx && saved && workspace, "head_bwd: null pointer");
     GF_CHECK_ARG(aligned16(workspace), "head_bwd: workspace must be 16-byte aligned");
     GF_CHECK_ARG(c->kind == 0 || w3, "head_bwd: disc needs fc3");
@@ -573,7 +561,7 @@ extern "C" int ganffn_head_bwd(const ganffn_head_cfg* c, const float* d_out, con
     float* part2 = d_pre2 + a4((int64_t)T * D2);     // split-K slabs of gw2
     float* part1 = part2 + head_part2(c);            // split-K slabs of gw1
     float* tailp = part1 + head_part1(c);            // discriminator tail: per-block sums
-    if (c->kind == 1 && disc_head_fused_supported(E, D1, D2) && !g_dhead_off) {
+    if (c->kind == 1 && disc_head_fused_supported(E, D1, D2) && !md.dhead_off()) {
         // one kernel: dprob -> d_pre3 -> d_pre2 -> d_pre1 -> dx; the fc1 / fc2 weight gradients (token reductions) stay GEMMs
         const float* a2 = u2 + (int64_t)T * D2;
         const float* prob = a2 + (int64_t)T * D2;
@@ -727,22 +715,7 @@ extern "C" int ganffn_lab_set_n100_stamps(void* dev_buf) { g_n100_stamps = (unsi
 extern "C" int ganffn_lab_set_wres_stamps(void* dev_buf) { g_wres_stamps = (unsigned long long*)dev_buf; return 0; }
 #endif
 extern "C" int ganffn_debug_set_ffn_mode(int bits) {
-    g_ffn_fused = (bits & 1) ? 1 : 0;
-    g_rc_off = (bits & 2) ? 1 : 0;
-    g_n100_off = (bits & 4) ? 1 : 0;
-    g_dhead_off = (bits & 32) ? 1 : 0;
-    g_pe_off = (bits & 64) ? 1 : 0;
-    g_ffn3 = (bits & 128) ? 1 : 0;
-    g_ffn3_wide = (bits & (1 << 22)) ? 1 : 0;
-    g_n100_pad7 = (bits & (1 << 23)) ? 1 : 0;
-    g_outproj_nosplit = (bits & (1 << 24)) ? 1 : 0;
-    g_mask_float = (bits & (1 << 25)) ? 1 : 0;
-    g_tn100_off = (bits & 8) ? 1 : 0;
-    g_tn100_in_kernel_sum = (bits & 16) ? 1 : 0;
-    g_tn100_force_splits = (bits >> 16) & 0xF;      // lab: force the token-chunk count of the d_model-100 grouped wgrad (0 = choose)
-    g_n100_force_splits = (bits >> 8) & 0xFF;       // lab: force the K-chunk count of gemm_n100 (0 = choose)
-    g_n100_force_kw = (bits >> 20) & 0x3;           // lab: force 4 (1) or 8 (2) waves per gemm_n100 workgroup (0 = choose; 3 -> 2)
-    if (g_n100_force_kw == 3) g_n100_force_kw = 2;
+    g_mode_word.store((uint32_t)bits, std::memory_order_relaxed);
     return 0;
 }
 extern "C" int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h,
@@ -794,6 +767,17 @@ extern "C" int ganffn_attention_bwd_keep(const float* qkv, const float* o, const
                                          float* d_qkv, int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng,
                                          uint64_t add, void* stream) {
     return launch_attention_bwd(qkv, o, lse, d_o, keep, d_qkv, S, B, E, H, p, site, rng, add, 1, (hipStream_t)stream);
+}
+// key-split backward of the head_dim-10 networks as the encoder stack launches it for every layer but the bottom one: dK / dV
+// complete, dQ as *n_parts partial slabs (part 0 in d_qkv's q columns, part j >= 1 at dq_slabs + (j - 1) * slab_stride, [T x E])
+extern "C" int ganffn_attention_bwd_split(const float* qkv, const float* o, const float* lse, const float* d_o, const uint32_t* keep,
+                                          float* d_qkv, float* dq_slabs, int64_t slab_stride, int* n_parts, int S, int B, int E, int H,
+                                          float p, uint32_t site, const uint64_t* rng, uint64_t add, void* stream) {
+    GF_CHECK_ARG(n_parts, "attention_bwd_split: null n_parts");
+    *n_parts = attn16_bwd_split_parts(E, H, S);
+    GF_CHECK_ARG(*n_parts > 1, "attention_bwd_split: E=%d H=%d S=%d is not split (head_dim 10, S > 32 only)", E, H, S);
+    return launch_attn16_bwd_split(qkv, o, lse, d_o, keep, d_qkv, dq_slabs, (long)slab_stride, S, B, E, H, p, site, rng, add, 1,
+                                   (hipStream_t)stream);
 }
 extern "C" int ganffn_attention_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv, int S,
                                     int B, int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add,

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/ganffn.h"
 
@@ -16,6 +17,35 @@
 #endif
 
 namespace ganffn {
+
+// The library's only mutable process state besides the per-(kernel, device) "LDS opt-in done" masks: ONE word, the A/B mode
+// mask of ganffn_debug_set_ffn_mode (include/ganffn.h lists the bits; default 0 = the product path).  It is a relaxed atomic —
+// a setter racing with a launch makes that launch take either path, never a torn mixture of switches — and every entry
+// point / launcher takes ONE snapshot (`const Mode md = mode();`) and decides from it.
+struct Mode {
+    uint32_t bits;
+    bool ffn_fused() const { return bits & 1u; }                    // bit 0: ffn.hip's fused feed-forward kernel
+    bool rc_off() const { return bits & 2u; }                       // bit 1: separate GEMM + LayerNorm launches instead of rowchain.hip
+    bool n100_off() const { return bits & 4u; }                     // bit 2: generic tiles instead of gemm_n100.hip
+    bool tn100_off() const { return bits & 8u; }                    // bit 3: generic tiles instead of gemm_tn100.hip
+    bool tn100_in_kernel_sum() const { return bits & 16u; }         // bit 4: last-arriver slab sum (measured slower)
+    bool dhead_off() const { return bits & 32u; }                   // bit 5: discriminator head as separate launches
+    bool pe_off() const { return bits & 64u; }                      // bit 6: positional encoding and layer 0's in-proj as two launches
+    bool ffn3() const { return bits & 128u; }                       // bit 7: ffn3.hip's one-kernel feed-forward forward
+    int n100_force_splits() const { return (int)((bits >> 8) & 0xFFu); }     // bits 8..15 (lab): K-chunk count of gemm_n100
+    int tn100_force_splits() const { return (int)((bits >> 16) & 0xFu); }    // bits 16..19 (lab): token-chunk count of tn100
+    int n100_force_kw() const { const int k = (int)((bits >> 20) & 3u); return k == 3 ? 2 : k; }   // bits 20..21 (lab)
+    bool ffn3_wide() const { return bits & (1u << 22); }            // bit 22: ffn3 also at T > 4096
+    bool n100_pad7() const { return bits & (1u << 23); }            // bit 23: padded seventh tile instead of the 4x4x1 tail
+    bool outproj_nosplit() const { return bits & (1u << 24); }      // bit 24: the wide out-proj unsplit
+    bool mask_float() const { return bits & (1u << 25); }           // bit 25: linear2 dgrad reads the saved activation, not the bits
+    bool attn_split_off() const { return bits & (1u << 26); }       // bit 26: whole-problem attention backward (round 4's form)
+    bool rc_split_off() const { return bits & (1u << 27); }         // bit 27: one workgroup per 16 token rows in every rowchain kernel
+    bool adam_slabs_off() const { return bits & (1u << 28); }       // bit 28: tn100 slabs through the reduce launch (round 4's form)
+    bool attn_split_philox() const { return bits & (1u << 29); }    // bit 29 (lab): the key-split attention backward re-evaluates Philox
+};
+extern std::atomic<uint32_t> g_mode_word;
+inline Mode mode() { return Mode{g_mode_word.load(std::memory_order_relaxed)}; }
 
 // ---------------------------------------------------------------------------------------
 // error reporting (thread-local message, int return codes; no exceptions across the ABI)
@@ -287,6 +317,16 @@ int launch_attn16_bwd(const float* qkv, const float* o, const float* lse, const 
                       int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
                       hipStream_t st);
 
+// key-split small-head backward (head_dim 10): the dQ of a (dialogue, head) problem leaves as attn16_bwd_split_parts partial
+// slabs — part 0 in d_qkv's q columns, parts 1.. in dq_slabs [parts - 1][T x E] — which launch_rc_ln_bwd adds in part order
+// (and writes back into d_qkv for the weight-gradient launch)
+constexpr int ATTN_SPLIT_KW = 2;            // key tiles (= waves) per workgroup
+constexpr int ATTN_SPLIT_MAX_PARTS = 4;     // ceil(7 / 2)
+int attn16_bwd_split_parts(int E, int H, int S);
+int launch_attn16_bwd_split(const float* qkv, const float* o, const float* lse, const float* d_o, const uint32_t* keepw, float* d_qkv,
+                            float* dq_slabs, long slab_stride, int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng,
+                            uint64_t add, int train, hipStream_t st);
+
 int launch_pe_dropout(const float* x, const float* pe, float* out, int S, int B, int E, float p,
                       const uint64_t* rng, uint64_t add, int train, hipStream_t st);
 int launch_dropout_bwd_inplace(float* dx, int R, int C, float p, uint32_t site, const uint64_t* rng, uint64_t add,
@@ -329,10 +369,12 @@ int launch_rc_pe_inproj_fwd(const float* x_in, const float* pe, float* out, cons
 int launch_rc_ln_inproj_fwd(const float* y, int nslab, long slab_stride, const float* x, const float* gamma, const float* beta,
                             float* out, float* xhat, float* rstd, const float* w_in, const float* b_in, float* qkv, int T,
                             float eps, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st);
-int launch_rc_ln_bwd(const float* d_qkv, const float* w_in_t, const float* d_out, int nslab, long slab_stride, const float* addend,
+// q_slabs / n_q_parts: d_qkv's q columns hold part 0 of a key-split attention backward and q_slabs [n_q_parts - 1][T x E] the
+// other parts: they are added in part order and the sum is written back into d_qkv (d_qkv is then NOT const)
+int launch_rc_ln_bwd(float* d_qkv, const float* w_in_t, const float* d_out, int nslab, long slab_stride, const float* addend,
                      const float* xhat, const float* rstd, const float* gamma, float* dz, float* dy, float* gpart,
                      const float* wo_t, float* d_attn, int T, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
-                     hipStream_t st);
+                     hipStream_t st, const float* q_slabs = nullptr, int n_q_parts = 1, long q_slab_stride = 0);
 int launch_gelu_drop_fwd(const float* x, float* out, int R, int C, float p, uint32_t site, const uint64_t* rng,
                          uint64_t add, int train, hipStream_t st);
 

@@ -1136,12 +1136,11 @@ long gemm_tn_grouped_part_floats() { return (long)(TN_GROUP_TILES + 256) * (64 *
 // whole token range and adds its result in place.  Narrower groups (a 2-layer gradient bucket: 284 tiles on 256 CUs) with
 // a workspace: the token range is split, the partial tiles go to per-split slabs and one reduce launch adds them in split
 // order.  Deterministic either way.
-int g_tn100_off = 0;    // ganffn_debug_set_ffn_mode bit 3: keep d_model-100 groups on the 64 x 64 tiles below
 
 int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws, long part_floats) {
     GF_CHECK_ARG(d && n >= 1 && n <= MAXP, "gemm_tn_grouped: n=%d out of [1,%d]", n, MAXP);
     // every problem 100-wide on one side (a d_model-100 encoder pass): 112-wide 16x16x4 tiles (gemm_tn100.hip)
-    if (!g_tn100_off && part_ws != nullptr && aligned16(part_ws) && tn100_supported(d, n))
+    if (!mode().tn100_off() && part_ws != nullptr && aligned16(part_ws) && tn100_supported(d, n))
         return launch_gemm_tn100_grouped(d, n, st, part_ws, part_floats);
     TnGroup grp;
     grp.n = n;

@@ -244,9 +244,8 @@ __global__ __launch_bounds__(256 * KW) void gemm_n100_kernel(N100Args a) {
 
 }  // namespace
 
-int g_n100_force_splits = 0;      // lab knob (ganffn_debug_set_ffn_mode bits 8..15): 0 = choose
-int g_n100_pad7 = 0;              // lab knob (bit 23): features 96..99 on a padded seventh 16-wide tile (round 3's form)
-int g_n100_force_kw = 0;          // lab knob (bits 20..21): 0 = choose, 1 = four waves per workgroup, 2 = eight (two per K tile)
+// lab knobs of the mode word (common.h `Mode`): bits 8..15 force the K-chunk count, bit 23 = features 96..99 on a padded seventh
+// 16-wide tile (round 3's form), bits 20..21 force four (1) or eight (2) waves per workgroup
 GF_LAB_ONLY(unsigned long long* g_n100_stamps = nullptr;)   // lab builds only: device buffer for in-kernel time stamps
 
 bool n100_supported(int N, int K) { return N == NE && K >= 256 && (K % NBK) == 0; }
@@ -263,7 +262,7 @@ bool n100_supported(int N, int K) { return N == NE && K >= 256 && (K % NBK) == 0
 // chunk's K tiles, plus the slab traffic: every slab is written here and read again by the LayerNorm-side consumer
 // (~0.8 tile-times per slab at T = 3008; the consumer at T = 6016 with 8 slabs is bandwidth-bound on them: 19 MB).
 int n100_splits(int T, int K, int max_splits, int w_kmajor) {
-    if (g_n100_force_splits > 0) return g_n100_force_splits < max_splits ? g_n100_force_splits : max_splits;
+    if (const int fs = mode().n100_force_splits(); fs > 0) return fs < max_splits ? fs : max_splits;
     const int tiles_m = (T + NBM - 1) / NBM, ksteps = K / NBK;
     int best = 1;
     double best_cost = 1e30;
@@ -299,8 +298,9 @@ int launch_gemm_n100(const float* A, int lda, const float* W, int ldw, int w_kma
     *splits_io = s;
     N100Args a{A, lda, W, ldw, bias, C, slab_stride, T, K, per * NBK GF_LAB_ONLY(, g_n100_stamps)};
     const dim3 grid((T + NBM - 1) / NBM, s);
-    const int kw = g_n100_force_kw ? g_n100_force_kw : n100_kw(T, s);
-    if (kw == 2 && !g_n100_pad7) {
+    const Mode md = mode();
+    const int kw = md.n100_force_kw() ? md.n100_force_kw() : n100_kw(T, s);
+    if (kw == 2 && !md.n100_pad7()) {
         if (w_kmajor) hipLaunchKernelGGL((gemm_n100_kernel<true, 2, true>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((gemm_n100_kernel<false, 2, true>), grid, dim3(512), 0, st, a);
     } else if (kw == 2) {

@@ -359,9 +359,8 @@ __global__ __launch_bounds__(256) void tn100_reduce_kernel(W100Group grp) {
 
 }  // namespace
 
-extern int g_n100_pad7;           // gemm_n100.hip: lab knob (bit 23), the padded seventh tile
-int g_tn100_force_splits = 0;     // lab knob (ganffn_debug_set_ffn_mode bits 16..19): 0 = choose
-int g_tn100_in_kernel_sum = 0;    // lab knob (bit 4): add the partial slabs in the last-arriving workgroup of a tile (measured slower)
+// lab knobs of the mode word (common.h `Mode`): bit 23 = the padded seventh tile, bits 16..19 force the token-chunk count,
+// bit 4 = add the partial slabs in the last-arriving workgroup of a tile (measured slower)
 constexpr long TN100_COUNTERS = 4096;      // ints reserved at the end of the partial-slab workspace for the arrival tickets
 
 // every problem has a 100-wide dimension, 16-byte aligned dense operands
@@ -383,6 +382,7 @@ long tn100_part_floats(const TnDesc* d, int n) {
 
 int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws, long part_floats) {
     GF_CHECK_ARG(tn100_supported(d, n), "gemm_tn100_grouped: unsupported group");
+    const Mode md = mode();
     W100Group grp;
     grp.n = n;
     long tiles = 0, per_split = tn100_part_floats(d, n);
@@ -396,7 +396,7 @@ int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* par
     // finish within 5 % of each other), at least 256 tokens per workgroup, within the workspace
     int splits = 1;
     int* counters = nullptr;
-    if (part_ws != nullptr && aligned16(part_ws) && g_tn100_in_kernel_sum && tiles <= TN100_COUNTERS && part_floats > 2 * TN100_COUNTERS) {
+    if (part_ws != nullptr && aligned16(part_ws) && md.tn100_in_kernel_sum() && tiles <= TN100_COUNTERS && part_floats > 2 * TN100_COUNTERS) {
         part_floats -= TN100_COUNTERS;
         counters = reinterpret_cast<int*>(part_ws + part_floats);
     }
@@ -404,7 +404,7 @@ int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* par
         splits = (int)((1700 + tiles - 1) / tiles);
         if (splits > WMAXSPLIT) splits = WMAXSPLIT;
         if (splits > kmax / 256) splits = kmax / 256;
-        if (g_tn100_force_splits > 0) splits = g_tn100_force_splits < WMAXSPLIT ? g_tn100_force_splits : WMAXSPLIT;
+        if (md.tn100_force_splits() > 0) splits = md.tn100_force_splits() < WMAXSPLIT ? md.tn100_force_splits() : WMAXSPLIT;
         if ((long)splits * per_split > part_floats) splits = (int)(part_floats / per_split);
         if (splits < 2) splits = 1;
     }
@@ -434,7 +434,7 @@ int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* par
         total += q.ntiles * splits;
     }
     if (grp.counters != nullptr) GF_HIP(hipMemsetAsync(grp.counters, 0, (size_t)ctr * sizeof(int), st));
-    if (g_n100_pad7) hipLaunchKernelGGL(tn100_kernel<false>, dim3(total), dim3(256), 0, st, grp);
+    if (md.n100_pad7()) hipLaunchKernelGGL(tn100_kernel<false>, dim3(total), dim3(256), 0, st, grp);
     else hipLaunchKernelGGL(tn100_kernel<true>, dim3(total), dim3(256), 0, st, grp);
     GF_LAUNCH_CHECK();
     if (splits > 1 && grp.counters == nullptr) {

@@ -302,7 +302,11 @@ __global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
 
 struct RcBwdArgs {
     // incoming gradient d = (pre_a . pre_wt^T | sum of slabs | one tensor) + addend
-    const float* pre_a; const float* pre_wt;     // PRE = 2: d_qkv of the layer above [T x 3E], its in-proj weight TRANSPOSED [E x 3E]
+    float* pre_a; const float* pre_wt;           // PRE = 2: d_qkv of the layer above [T x 3E], its in-proj weight TRANSPOSED [E x 3E]
+    // PRE = 2, key-split attention backward (attention16.hip): pre_a's q columns hold part 0 of dQ, q_slabs [n_q_parts - 1][T x E]
+    // the other parts; the kernel adds them in part order and writes the sum back into pre_a (the weight-gradient launch reads
+    // it).  n_q_parts == 1: q_slabs is any readable address (never added)
+    const float* q_slabs; int n_q_parts; long q_slab_stride;
     const float* d_out; int nslab; long slab_stride;
     const float* addend;                         // may be null
     const float* xhat; const float* rstd; const float* gamma;
@@ -360,7 +364,22 @@ __global__ __launch_bounds__(256) void rc_bwd_kernel(RcBwdArgs a) {
             const int q = w + 4 * u, col = 16 * q + 4 * g;
             const bool ok = q < KQ3 && col < K3;
             const int colc = min(col, K3 - 4);
-            const float4 tx = f4(a.pre_a + trow * K3 + colc);
+            float4 tx = f4(a.pre_a + trow * K3 + colc);
+            if (u < 2) {
+                // q columns (col < E; only k groups 0..6 = u < 2 hold any): + the other parts of a key-split dQ, in part order.
+                // Every (token, column) of d_qkv is read by exactly one lane of one workgroup, which also writes the sum back.
+                const bool isq = ok && col < RE;
+                const float* qs = a.q_slabs + trow * RE + min(col, RE - 4);
+                float4 pv[ATTN_SPLIT_MAX_PARTS - 1];
+#pragma unroll
+                for (int j = 0; j < ATTN_SPLIT_MAX_PARTS - 1; ++j) pv[j] = f4(qs + (size_t)min(j, max(a.n_q_parts - 2, 0)) * a.q_slab_stride);
+#pragma unroll
+                for (int j = 0; j < ATTN_SPLIT_MAX_PARTS - 1; ++j) {
+                    const float m = (isq && j + 1 < a.n_q_parts) ? 1.f : 0.f;
+                    tx.x += m * pv[j].x; tx.y += m * pv[j].y; tx.z += m * pv[j].z; tx.w += m * pv[j].w;
+                }
+                if (isq && tok && a.n_q_parts > 1) *reinterpret_cast<float4*>(a.pre_a + trow * K3 + col) = tx;
+            }
             xq[u] = ok ? tx : zero4();
 #pragma unroll
             for (int m = 0; m < RT; ++m) {
@@ -585,10 +604,12 @@ int launch_rc_pe_inproj_fwd(const float* x_in, const float* pe, float* out, cons
 // [E x 3E]) when d_qkv is given, else the nslab slabs of d_out; + addend.  Outgoing: dz, dy = dz * dropout multiplier, the
 // per-workgroup partial sums of the LayerNorm parameter gradients (gpart: rc_blocks(T) * 2 * E floats), and with wo_t
 // (out-proj weight transposed) d_attn = dy . wo_t^T.
-int launch_rc_ln_bwd(const float* d_qkv, const float* w_in_t, const float* d_out, int nslab, long slab_stride, const float* addend,
+int launch_rc_ln_bwd(float* d_qkv, const float* w_in_t, const float* d_out, int nslab, long slab_stride, const float* addend,
                      const float* xhat, const float* rstd, const float* gamma, float* dz, float* dy, float* gpart,
                      const float* wo_t, float* d_attn, int T, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
-                     hipStream_t st) {
+                     hipStream_t st, const float* q_slabs, int n_q_parts, long q_slab_stride) {
+    GF_CHECK_ARG(n_q_parts >= 1 && n_q_parts <= ATTN_SPLIT_MAX_PARTS && (n_q_parts == 1 || (d_qkv && q_slabs && aligned16(q_slabs) && (q_slab_stride & 3) == 0)),
+                 "rc_ln_bwd: bad dQ slabs (parts=%d)", n_q_parts);
     GF_CHECK_ARG((d_qkv || d_out) && xhat && rstd && gamma && dz && T > 0, "rc_ln_bwd: bad arguments");
     GF_CHECK_ARG(!d_qkv || (w_in_t && aligned16(d_qkv) && aligned16(w_in_t)), "rc_ln_bwd: in-proj dgrad needs the transposed weight");
     GF_CHECK_ARG(!wo_t || (d_attn && dy && aligned16(wo_t) && aligned16(d_attn)), "rc_ln_bwd: out-proj dgrad needs dy and an output");
@@ -598,6 +619,7 @@ int launch_rc_ln_bwd(const float* d_qkv, const float* w_in_t, const float* d_out
     a.pre_a = d_qkv; a.pre_wt = w_in_t; a.d_out = d_out; a.nslab = nslab; a.slab_stride = slab_stride; a.addend = addend;
     a.xhat = xhat; a.rstd = rstd; a.gamma = gamma; a.dz = dz; a.dy = dy; a.gpart = gpart; a.post_wt = wo_t; a.post_out = d_attn;
     a.T = T; a.p = p; a.site = site; a.rng = rng; a.add = add; a.train = train;
+    a.q_slabs = n_q_parts > 1 ? q_slabs : d_qkv; a.n_q_parts = n_q_parts; a.q_slab_stride = n_q_parts > 1 ? q_slab_stride : 0;
     const dim3 grid(rc_blocks(T)), blk(256);
     if (d_qkv) {
         if (wo_t) hipLaunchKernelGGL((rc_bwd_kernel<2, true>), grid, blk, 0, st, a);

@@ -330,6 +330,16 @@ int ganffn_attention_fwd_keep(const float* qkv, float* o, float* lse, uint32_t* 
 int ganffn_attention_bwd_keep(const float* qkv, const float* o, const float* lse, const float* d_o,
                               const uint32_t* keep, float* d_qkv, int S, int B, int E, int H, float p, uint32_t site,
                               const uint64_t* rng, uint64_t rng_offset_add, void* stream);
+/* Key-split form of the backward (head_dim 10, S > 32: the d_model-100 networks' attention core behind model.py:1210,1276,
+ * 1307,1340,1377), as ganffn_encoder_bwd launches it for every layer but the bottom one of its range: a (dialogue, head)
+ * problem runs as *n_parts workgroups of two key tiles each.  dK and dV come out complete and bit-identical to
+ * ganffn_attention_bwd_keep; dQ comes out as *n_parts PARTIAL slabs — part 0 in d_qkv's q columns, part j >= 1 at
+ * dq_slabs + (j - 1) * slab_stride ([T x E], q layout) — whose sum in part order is dQ (the rowchain kernel that consumes
+ * d_qkv adds them).  keep may be NULL (Philox re-evaluated). */
+int ganffn_attention_bwd_split(const float* qkv, const float* o, const float* lse, const float* d_o,
+                               const uint32_t* keep, float* d_qkv, float* dq_slabs, int64_t slab_stride, int* n_parts,
+                               int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng,
+                               uint64_t rng_offset_add, void* stream);
 /* z = x + drop(y); xhat = (z-mean)*rstd; out = xhat*w + b   (norm1/norm2 of the encoder layer) */
 int ganffn_add_dropout_layernorm_fwd(const float* x, const float* y, const float* w, const float* b,
                                      float* out, float* xhat, float* rstd, int T, int E, float eps,
