@@ -64,6 +64,10 @@ SIGNATURES = {
     "ganffn_bce2_fwd": (_I, [_P, _F, _F, _I, _I, _I, _F, _P, _I, _P]),
     "ganffn_bce2_bwd": (_I, [_P, _F, _F, _I, _I, _I, _F, _P, _P]),
     "ganffn_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P]),
+    "ganffn_adam_step_parts": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P, _L, _I, _L, _L, _L, _P]),
+    "ganffn_encoder_bwd_parts_supported": (_I, [_PE]),
+    "ganffn_encoder_bwd_parts_covered": (_L, [_I, _I]),
+    "ganffn_encoder_bwd_parts": (_I, [_PE, _P, _P, _P, _P, _P, _P, _U64, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int), _P]),
     "ganffn_adam_update": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P]),
     "ganffn_adam_bump": (_I, [_P, _P]),
     "ganffn_add3": (_I, [_P, _P, _P, _P, _L, _P]),

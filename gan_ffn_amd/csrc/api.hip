@@ -305,9 +305,41 @@ extern "C" int ganffn_encoder_bwd(const ganffn_enc_cfg* c, int layer_lo, int lay
                                   void* stream) {
     return ganffn_encoder_bwd2(c, layer_lo, layer_hi, dx, params, grads, saved, workspace, rng, add, 1, stream);
 }
+static int encoder_bwd_impl(const ganffn_enc_cfg* c, int layer_lo, int layer_hi, float* dx, const float* params,
+                            float* grads, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
+                            int need_dx_in, void* stream, TnSlabs* slabs);
 extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int layer_hi, float* dx, const float* params,
                                    float* grads, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
                                    int need_dx_in, void* stream) {
+    return encoder_bwd_impl(c, layer_lo, layer_hi, dx, params, grads, saved, workspace, rng, add, need_dx_in, stream, nullptr);
+}
+// does ganffn_encoder_bwd_parts leave the weight gradients of this stack unreduced?  (d_model 100 on the rowchain / tn100 kernels,
+// at most 10 layers: one grouped weight-gradient launch for the whole pass)
+static bool bwd_parts_supported(const ganffn_enc_cfg* c, const Mode md) {
+    return rc_supported(c->E) && !md.rc_off() && !md.tn100_off() && !md.tn100_in_kernel_sum() && !md.adam_slabs_off() && c->F == 2048 &&
+           4 * c->L <= 40;
+}
+extern "C" int ganffn_encoder_bwd_parts_supported(const ganffn_enc_cfg* c) {
+    if (check_cfg(c) != 0) return -1;
+    return bwd_parts_supported(c, mode()) ? 1 : 0;
+}
+extern "C" int64_t ganffn_encoder_bwd_parts_covered(int E, int F) { return layer_off(E, F).n1w; }
+extern "C" int ganffn_encoder_bwd_parts(const ganffn_enc_cfg* c, float* dx, const float* params, float* grads, const float* saved,
+                                        float* workspace, const uint64_t* rng, uint64_t add, int need_dx_in, int64_t* part_offset,
+                                        int64_t* part_stride, int* n_parts, void* stream) {
+    GF_TRY(check_cfg(c));
+    GF_CHECK_ARG(grads && part_offset && part_stride && n_parts, "encoder_bwd_parts: null pointer");
+    GF_CHECK_ARG(bwd_parts_supported(c, mode()), "encoder_bwd_parts: this stack's weight gradients are reduced in the launch (ask ganffn_encoder_bwd_parts_supported)");
+    TnSlabs sl{grads, (long)c->L * layer_off(c->E, c->F).total, 1, nullptr, 0};
+    GF_TRY(encoder_bwd_impl(c, 0, c->L, dx, params, grads, saved, workspace, rng, add, need_dx_in, stream, &sl));
+    *n_parts = sl.n_parts;
+    *part_offset = sl.part ? sl.part - workspace : 0;
+    *part_stride = sl.part_stride;
+    return 0;
+}
+static int encoder_bwd_impl(const ganffn_enc_cfg* c, int layer_lo, int layer_hi, float* dx, const float* params,
+                            float* grads, const float* saved, float* workspace, const uint64_t* rng, uint64_t add,
+                            int need_dx_in, void* stream, TnSlabs* slabs) {
     const Mode md = mode();
     GF_TRY(check_cfg(c));
     GF_CHECK_ARG(dx && params && saved && workspace, "encoder_bwd: null pointer");
@@ -443,7 +475,7 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
         // in-proj wgrad + dgrad; dX[l] = d_qkv W_in + dz1
         if (G) tn[ntn++] = TnDesc{d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T};
         if (ntn == 40 || (l == layer_lo && ntn > 0)) {
-            GF_TRY(launch_gemm_tn_grouped(tn, ntn, st, tnp, gemm_tn_grouped_part_floats()));
+            GF_TRY(launch_gemm_tn_grouped(tn, ntn, st, tnp, gemm_tn_grouped_part_floats(), slabs));
             ntn = 0;
         }
         EpiArgs eadd;
@@ -461,7 +493,8 @@ extern "C" int ganffn_encoder_bwd2(const ganffn_enc_cfg* c, int layer_lo, int la
             GF_TRY(launch_gemm_nn(d_qkv, 3 * E, P + lo.in_w, E, dx, E, T, E, 3 * E, EPI_NONE, eadd, st));
         }   // (else: the stack's input needs no gradient — autograd would not compute this product either)
     }
-    if (nred > 0) GF_TRY(launch_ln_param_reduce(nred, r_gw, r_gb, r_part, r_nb, E, st));
+    // (unreduced mode: nobody zeroed the gradient slab's encoder region — the LayerNorm parameter gradients are WRITTEN too)
+    if (nred > 0) GF_TRY(launch_ln_param_reduce(nred, r_gw, r_gb, r_part, r_nb, E, st, slabs != nullptr));
     if (layer_lo == 0 && need_dx_in) GF_TRY(launch_dropout_bwd_inplace(dx, T, E, c->p_pe, SITE_PE, rng, add, train, st));
     return 0;
 }

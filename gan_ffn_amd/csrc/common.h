@@ -291,11 +291,19 @@ struct TnDesc {
 // part_ws (optional, gemm_tn_grouped_part_floats() floats): when the group has too few output tiles to load every CU
 // evenly, the token range is split over 2..8 workgroups per tile; each writes its partial tile to the workspace and one
 // grouped reduce launch adds the partials in split order (deterministic).  Without a workspace: one owner per tile.
-int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws = nullptr, long part_floats = 0);
+// Unreduced weight gradients of a d_model-100 pass (round 5; single-GPU step): in  — grad_base / range_floats: the gradient
+// slab region every problem's C and colsum lie in (densely, ldc == N); out — n_parts token chunks were computed: chunk 0 WROTE
+// (not added) its partial gradients into the slab region itself, chunk z >= 1 into part + (z - 1) * part_stride, shaped like the
+// region.  ganffn_adam_step_parts adds them in chunk order: the sum the reduce launch would have formed, bit for bit.
+struct TnSlabs {
+    float* grad_base; long range_floats;
+    int n_parts; float* part; long part_stride;
+};
+int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws = nullptr, long part_floats = 0, TnSlabs* slabs = nullptr);
 // gemm_tn100.hip: the same for groups whose every problem has a 100-wide dimension (d_model-100 encoder passes), on
 // 112-wide 16x16x4 tiles; needs the partial-slab workspace
 bool tn100_supported(const TnDesc* d, int n);
-int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws, long part_floats);
+int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws, long part_floats, TnSlabs* slabs = nullptr);
 long gemm_tn_grouped_part_floats();
 
 // lse [B*H x S]: log-sum-exp of every score row, written by the forward (may be NULL: not kept) and, together with the
@@ -345,8 +353,9 @@ int launch_add_drop_ln_bwd(const float* d_out, const float* xhat, const float* r
                            float* dy, float* gw, float* gb, int T, int E, float p, uint32_t site,
                            const uint64_t* rng, uint64_t add, int train, hipStream_t st, int nslab = 1,
                            long slab_stride = 0, const float* addend = nullptr, float* gpart = nullptr);
+// overwrite: gw / gb = the sums (the caller did not zero them) instead of +=
 int launch_ln_param_reduce(int n, float* const* gw, float* const* gb, const float* const* part, const int* nblk, int E,
-                           hipStream_t st);
+                           hipStream_t st, bool overwrite = false);
 int launch_add_inplace(float* a, const float* b, int64_t n, hipStream_t st);
 
 // gemm_n100.hip — [T x K] x [K x 100] with a long K on 16x16x4 MFMAs (112-wide feature tile), K cut into output slabs

@@ -310,7 +310,7 @@ struct LnRedGroup {
     const float* part[LN_RED_MAX];
     int nblk[LN_RED_MAX];
 };
-__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(LnRedGroup grp, int E) {
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(LnRedGroup grp, int E, int overwrite) {
     // 64 columns x 16 partial groups per workgroup: thread (c, q) adds partial blocks q, q + 16, ... (independent loads, a
     // fixed order), then the 16 group sums are added in order — the association is fixed, so the result is reproducible
     __shared__ float red[2][16][64];
@@ -332,8 +332,8 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(LnRedGroup grp, i
         float tw = 0.f, tb = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { tw += red[0][i][cl]; tb += red[1][i][cl]; }
-        grp.gw[j][c] += tw;
-        grp.gb[j][c] += tb;
+        if (overwrite) { grp.gw[j][c] = tw; grp.gb[j][c] = tb; }
+        else { grp.gw[j][c] += tw; grp.gb[j][c] += tb; }
     }
 }
 
@@ -460,6 +460,7 @@ __device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& 
     pi = pi - lr_bc1 * (mi / denom);
 }
 
+constexpr int ADAM_MAX_EXTRA = 7;      // token chunks beyond the first of an unreduced weight gradient (gemm_tn100.hip WMAXSPLIT - 1)
 // VEC = 4: one float4 of p, g, m, v per thread (the slabs are 16-byte aligned); the n % 4 tail goes to a VEC = 1 launch.
 // HBM-bound: 28 B per parameter (read p, g, m, v; write p, m, v).
 template <int VEC>
@@ -487,6 +488,40 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         adam_one(pi, g[i], mi, vi, lr_bc1, rs_bc2, b1, b2, eps, wd, gscale);
         m[i] = mi; v[i] = vi; p[i] = pi;
     }
+}
+// Adam over a slab whose encoder weight / bias gradients are UNREDUCED (ganffn_encoder_bwd_parts): for the covered elements —
+// i < enc_floats and (i % layer_floats) < covered — the gradient is g[i] (token chunk 0) + part[0][i] + part[1][i] + ... in chunk
+// order, the sum tn100_reduce_kernel would have formed (same association -> same bits); everything else (LayerNorm parameters,
+// heads, `object`) is g[i] alone.  layer_floats and covered are multiples of 4: a float4 is covered or not as a whole.
+__global__ __launch_bounds__(256) void adam_parts_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, const int32_t* __restrict__ step, long n, float lr,
+                                                         float b1, float b2, float eps, float wd, float gscale,
+                                                         const float* __restrict__ part, long part_stride, int n_extra,
+                                                         long enc_floats, long layer_floats, long covered) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float t = (float)(*step + 1);
+    const float bc1 = 1.0f - powf(b1, t);
+    const float bc2 = 1.0f - powf(b2, t);
+    const float lr_bc1 = lr / bc1, rs_bc2 = sqrtf(bc2);
+    float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+    float4 gg = *reinterpret_cast<const float4*>(g + i);
+    const bool cov = i < enc_floats && (i % layer_floats) < covered;           // (uniform over long runs of threads)
+    if (cov) {
+        float4 e[ADAM_MAX_EXTRA];
+#pragma unroll
+        for (int z = 0; z < ADAM_MAX_EXTRA; ++z) e[z] = *reinterpret_cast<const float4*>(part + (size_t)min(z, n_extra - 1) * part_stride + i);
+#pragma unroll
+        for (int z = 0; z < ADAM_MAX_EXTRA; ++z)
+            if (z < n_extra) { gg.x += e[z].x; gg.y += e[z].y; gg.z += e[z].z; gg.w += e[z].w; }
+    }
+    adam_one(pp.x, gg.x, mm.x, vv.x, lr_bc1, rs_bc2, b1, b2, eps, wd, gscale);
+    adam_one(pp.y, gg.y, mm.y, vv.y, lr_bc1, rs_bc2, b1, b2, eps, wd, gscale);
+    adam_one(pp.z, gg.z, mm.z, vv.z, lr_bc1, rs_bc2, b1, b2, eps, wd, gscale);
+    adam_one(pp.w, gg.w, mm.w, vv.w, lr_bc1, rs_bc2, b1, b2, eps, wd, gscale);
+    *reinterpret_cast<float4*>(m + i) = mm;
+    *reinterpret_cast<float4*>(v + i) = vv;
+    *reinterpret_cast<float4*>(p + i) = pp;
 }
 __global__ void adam_step_inc(int32_t* step) { *step += 1; }
 
@@ -734,14 +769,14 @@ int launch_add_drop_ln_bwd(const float* d_out, const float* xhat, const float* r
 
 // add the per-block partial sums of n LayerNorm backward launches (gw[i], gb[i] += sum over nblk[i] blocks of part[i])
 int launch_ln_param_reduce(int n, float* const* gw, float* const* gb, const float* const* part, const int* nblk, int E,
-                           hipStream_t st) {
+                           hipStream_t st, bool overwrite) {
     for (int i0 = 0; i0 < n; i0 += LN_RED_MAX) {
         LnRedGroup grp;
         const int m = n - i0 < LN_RED_MAX ? n - i0 : LN_RED_MAX;
         for (int i = 0; i < m; ++i) {
             grp.gw[i] = gw[i0 + i]; grp.gb[i] = gb[i0 + i]; grp.part[i] = part[i0 + i]; grp.nblk[i] = nblk[i0 + i];
         }
-        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((E + 63) / 64, m), dim3(1024), 0, st, grp, E);
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((E + 63) / 64, m), dim3(1024), 0, st, grp, E, overwrite ? 1 : 0);
         GF_LAUNCH_CHECK();
     }
     return 0;
@@ -877,6 +912,26 @@ extern "C" int ganffn_adam_update(float* params, const float* grads, float* exp_
         GF_LAUNCH_CHECK();
     }
     return 0;
+}
+
+extern "C" int ganffn_adam_step_parts(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t* step, int64_t n,
+                                      float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                      const float* parts, int64_t part_stride, int n_parts, int64_t enc_floats, int64_t layer_floats,
+                                      int64_t covered_per_layer, void* stream) {
+    GF_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && step && n > 0, "adam_step_parts: bad arguments");
+    GF_CHECK_ARG(n_parts >= 1 && n_parts <= ADAM_MAX_EXTRA + 1, "adam_step_parts: n_parts=%d out of [1,%d]", n_parts, ADAM_MAX_EXTRA + 1);
+    if (n_parts == 1) return ganffn_adam_step(params, grads, exp_avg, exp_avg_sq, step, n, lr, beta1, beta2, eps, weight_decay, grad_scale, stream);
+    GF_CHECK_ARG(parts && aligned16(parts) && (part_stride & 3) == 0 && part_stride >= enc_floats, "adam_step_parts: bad partial slabs");
+    GF_CHECK_ARG((n & 3) == 0 && aligned16(params) && aligned16(grads) && aligned16(exp_avg) && aligned16(exp_avg_sq),
+                 "adam_step_parts: slabs must be 16-byte aligned and a multiple of 4 floats");
+    GF_CHECK_ARG(layer_floats > 0 && (layer_floats & 3) == 0 && (covered_per_layer & 3) == 0 && covered_per_layer <= layer_floats &&
+                     enc_floats % layer_floats == 0 && enc_floats <= n, "adam_step_parts: bad layer geometry");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_parts_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq,
+                       (const int32_t*)step, (long)n, lr, beta1, beta2, eps, weight_decay, grad_scale, parts, (long)part_stride,
+                       n_parts - 1, (long)enc_floats, (long)layer_floats, (long)covered_per_layer);
+    GF_LAUNCH_CHECK();
+    return ganffn_adam_bump(step, stream);
 }
 
 extern "C" int ganffn_add3(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream) {

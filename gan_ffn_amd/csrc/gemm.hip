@@ -1137,11 +1137,12 @@ long gemm_tn_grouped_part_floats() { return (long)(TN_GROUP_TILES + 256) * (64 *
 // a workspace: the token range is split, the partial tiles go to per-split slabs and one reduce launch adds them in split
 // order.  Deterministic either way.
 
-int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws, long part_floats) {
+int launch_gemm_tn_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws, long part_floats, TnSlabs* slabs) {
     GF_CHECK_ARG(d && n >= 1 && n <= MAXP, "gemm_tn_grouped: n=%d out of [1,%d]", n, MAXP);
     // every problem 100-wide on one side (a d_model-100 encoder pass): 112-wide 16x16x4 tiles (gemm_tn100.hip)
     if (!mode().tn100_off() && part_ws != nullptr && aligned16(part_ws) && tn100_supported(d, n))
-        return launch_gemm_tn100_grouped(d, n, st, part_ws, part_floats);
+        return launch_gemm_tn100_grouped(d, n, st, part_ws, part_floats, slabs);
+    GF_CHECK_ARG(slabs == nullptr, "gemm_tn_grouped: unreduced gradient slabs exist only for the d_model-100 kernel");
     TnGroup grp;
     grp.n = n;
     // 64 x 128 tiles (two accumulators per wave sharing the A fragment: the single-accumulator MFMA chain of the 64 x 64

@@ -50,12 +50,17 @@ struct W100Problem {
     int M, N;                                  // the gradient's shape (partial-slab layout: [M x N] dense, then [M] column sums)
     long part_off;
     int ctr0;                                  // first arrival counter of this problem (one per 64-wide tile)
+    long c_off, cs_off;                        // to_slabs: offsets of C / colsum from the gradient slab's base
 };
 struct W100Group {
     W100Problem p[WMAXP];
     int n, splits;
     float* part; long part_stride;
     int* counters;                             // per (problem, tile) arrival tickets, zero at launch; null: separate reduce launch
+    // to_slabs (round 5, single-GPU step): NO reduce launch and NO zeroed gradient — token chunk 0 OVERWRITES the gradient
+    // (C / colsum), chunk z >= 1 writes slab z - 1 of `part`, each slab shaped like the gradient slab itself (element at the
+    // same offset from its base); the Adam launch adds them in chunk order (elementwise.hip adam_parts_kernel)
+    int to_slabs;
 };
 
 // TAIL4 (gemm_n100.hip): rows 96..99 of the 100-wide dimension on v_mfma_f32_4x4x1_16B_f32 (8 cycles) instead of a seventh
@@ -203,6 +208,42 @@ __global__ __launch_bounds__(256) void tn100_kernel(W100Group grp) {
     }
     const int n = n0 + wave * 16 + c;
     const bool nok = n < Nn;
+    if (grp.to_slabs) {
+        // plain stores, every chunk: chunk 0 into the gradient itself, chunk z into gradient-shaped slab z - 1
+        float* const Cb = z == 0 ? q.C : grp.part + (size_t)(z - 1) * grp.part_stride + q.c_off;
+        float* const Sb = z == 0 ? q.colsum : grp.part + (size_t)(z - 1) * grp.part_stride + q.cs_off;
+        if (q.side == 0) {
+#pragma unroll
+            for (int m = 0; m < WT7; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mm = 16 * m + 4 * g + r;
+                    if (mm < WE && nok) Cb[(size_t)mm * q.ldc + n] = acc[m][r];
+                }
+        } else if (nok) {
+#pragma unroll
+            for (int m = 0; m < WT7; ++m) {
+                const int mm = 16 * m + 4 * g;
+                if (mm < WE) *reinterpret_cast<float4*>(Cb + (size_t)n * q.ldc + mm) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+            }
+        }
+        if (cs_v) {
+            csv += __shfl_xor(csv, 16, 64);
+            csv += __shfl_xor(csv, 32, 64);
+            if (g == 0 && nok) Sb[n] = csv;
+        }
+        if (cs_u) {
+#pragma unroll
+            for (int m = 0; m < WT7; ++m) {
+                float v = csu[m];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                const int mm = 16 * m + c;
+                if (g == 0 && mm < WE) Sb[mm] = v;
+            }
+        }
+        return;
+    }
     float* const slab = grp.splits > 1 ? grp.part + (size_t)z * grp.part_stride + q.part_off : nullptr;
     if (q.side == 0) {
         // gradient [100 x Nn]: element (m, n)
@@ -380,11 +421,14 @@ long tn100_part_floats(const TnDesc* d, int n) {
     return per;
 }
 
-int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws, long part_floats) {
+// slabs (optional): the caller wants the weight gradients UNREDUCED (TnSlabs, common.h): no reduce launch, chunk 0 overwrites the
+// gradient slab, chunks 1.. go to gradient-shaped slabs at the head of part_ws
+int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* part_ws, long part_floats, TnSlabs* slabs) {
     GF_CHECK_ARG(tn100_supported(d, n), "gemm_tn100_grouped: unsupported group");
     const Mode md = mode();
     W100Group grp;
     grp.n = n;
+    grp.to_slabs = 0;
     long tiles = 0, per_split = tn100_part_floats(d, n);
     int kmax = 0;
     for (int i = 0; i < n; ++i) {
@@ -405,13 +449,29 @@ int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* par
         if (splits > WMAXSPLIT) splits = WMAXSPLIT;
         if (splits > kmax / 256) splits = kmax / 256;
         if (md.tn100_force_splits() > 0) splits = md.tn100_force_splits() < WMAXSPLIT ? md.tn100_force_splits() : WMAXSPLIT;
-        if ((long)splits * per_split > part_floats) splits = (int)(part_floats / per_split);
+        if (slabs != nullptr) {
+            if ((long)(splits - 1) * slabs->range_floats > part_floats) splits = 1 + (int)(part_floats / slabs->range_floats);
+        } else if ((long)splits * per_split > part_floats) splits = (int)(part_floats / per_split);
         if (splits < 2) splits = 1;
     }
     grp.splits = splits;
     grp.part = splits > 1 ? part_ws : nullptr;
     grp.part_stride = per_split;
     grp.counters = splits > 1 ? counters : nullptr;
+    if (slabs != nullptr) {
+        GF_CHECK_ARG(slabs->grad_base && (slabs->range_floats & 3) == 0, "gemm_tn100_grouped: bad gradient-slab description");
+        for (int i = 0; i < n; ++i) {
+            const long co = d[i].C - slabs->grad_base, so = d[i].colsum ? d[i].colsum - slabs->grad_base : 0;
+            GF_CHECK_ARG(co >= 0 && co + (long)d[i].M * d[i].N <= slabs->range_floats && so >= 0 && so + d[i].M <= slabs->range_floats &&
+                             d[i].ldc == d[i].N, "gemm_tn100_grouped: problem %d does not lie densely inside the gradient slab", i);
+        }
+        grp.to_slabs = 1;
+        grp.part_stride = slabs->range_floats;
+        grp.counters = nullptr;
+        slabs->n_parts = splits;
+        slabs->part = splits > 1 ? part_ws : nullptr;
+        slabs->part_stride = slabs->range_floats;
+    }
     int total = 0, ctr = 0;
     long off = 0;
     for (int i = 0; i < n; ++i) {
@@ -428,6 +488,8 @@ int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* par
         q.ntiles = (q.Nn + WBN - 1) / WBN;
         q.block0 = total;
         q.part_off = off;
+        q.c_off = slabs ? d[i].C - slabs->grad_base : 0;
+        q.cs_off = (slabs && d[i].colsum) ? d[i].colsum - slabs->grad_base : 0;
         q.ctr0 = ctr;
         ctr += q.ntiles;
         off += (((long)d[i].M * d[i].N + d[i].M) + 3) & ~3L;
@@ -437,7 +499,7 @@ int launch_gemm_tn100_grouped(const TnDesc* d, int n, hipStream_t st, float* par
     if (md.n100_pad7()) hipLaunchKernelGGL(tn100_kernel<false>, dim3(total), dim3(256), 0, st, grp);
     else hipLaunchKernelGGL(tn100_kernel<true>, dim3(total), dim3(256), 0, st, grp);
     GF_LAUNCH_CHECK();
-    if (splits > 1 && grp.counters == nullptr) {
+    if (splits > 1 && grp.counters == nullptr && !grp.to_slabs) {
         hipLaunchKernelGGL(tn100_reduce_kernel, dim3(64, n), dim3(256), 0, st, grp);
         GF_LAUNCH_CHECK();
     }

@@ -65,6 +65,7 @@ class NetState:
         self.D1 = module.fc1.weight.shape[0]
         self.D2 = module.fc2.weight.shape[0]
         self.layer_floats = enc // self.L
+        self.covered = int(_lib.load().ganffn_encoder_bwd_parts_covered(self.E, 2048))    # chunked head of a layer block (weights, biases)
         self.has_obj = bool(module.HAS_OBJECT)
         self.obj_in = int(module.OBJECT_IN) if self.has_obj else 0       # raw-modality width `object` maps to D_h
         # `object` (weight [D_h x obj_in] | bias [D_h], each padded to 4 floats) sits right after the layers
@@ -539,7 +540,7 @@ class GanEngine(_Runner):
                          ps.out, ps.hsaved, self.ws, self.rng.state, a1)
         return a0, a1
 
-    def _net_bwd(self, net, ps, d_out, train, adds, want_wgrad, reduce_cb=None, need_dx=None):
+    def _net_bwd(self, net, ps, d_out, train, adds, want_wgrad, reduce_cb=None, need_dx=None, parts=False):
         """head + encoder backward; ps.dx <- dL/d(network input) when `need_dx` (default: exactly when the network is the
         frozen one that only passes gradient through).  Weight grads accumulate into net.grad."""
         cfg = ps.cfg_train if train else ps.cfg_eval
@@ -558,6 +559,10 @@ class GanEngine(_Runner):
         # train_gen passes its input gradient on to the generator
         if need_dx is None:
             need_dx = not want_wgrad
+        if parts and want_wgrad and reduce_cb is None:
+            # single GPU, d_model 100: the weight gradients stay as token-chunk slabs for Adam to add (no reduce launch, and the
+            # caller did not zero the encoder region of net.grad) -> (parts view of self.ws, stride, chunks)
+            return ops.encoder_bwd_parts_raw(cfg, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0, need_dx)
         if reduce_cb is None or not want_wgrad:
             ops.encoder_bwd_raw(cfg, 0, net.L, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0, need_dx)
         else:
@@ -569,9 +574,28 @@ class GanEngine(_Runner):
                 ops.encoder_bwd_raw(cfg, lo, hi, ps.dx, net.slab, gslab, ps.saved, self.ws, self.rng.state, a0, need_dx)
                 reduce_cb(lo_f, hi_f, last=(i == len(bks) - 2))
 
-    def _adam(self, net):
+    def _adam(self, net, parts=None):
+        if parts is not None and parts[2] > 1:
+            ops.adam_step_parts_raw(net.slab, net.grad, net.exp_avg, net.exp_avg_sq, net.step, net.total, net.lr, net.betas[0],
+                                    net.betas[1], parts[0], parts[1], parts[2], net.enc_floats, net.layer_floats, net.covered,
+                                    1e-8, net.wd, 1.0 / self.world)
+            return
         ops.adam_step_raw(net.slab, net.grad, net.exp_avg, net.exp_avg_sq, net.step, net.total, net.lr,
                           net.betas[0], net.betas[1], 1e-8, net.wd, 1.0 / self.world)
+
+    def _parts_ok(self, net, ps):
+        """single GPU, d_model 100: leave the weight gradients of this backward pass as token-chunk slabs and let Adam add them
+        (ganffn_encoder_bwd_parts / ganffn_adam_step_parts): no reduce launch, no zero-fill of the encoder region of net.grad.
+        With a process group the all-reduce needs the summed slab: today's path.  GANFFN_ADAM_PARTS=0 switches it off."""
+        return self.pg is None and os.environ.get("GANFFN_ADAM_PARTS", "1") == "1" and net.total % 4 == 0 and \
+            ops.encoder_bwd_parts_supported(ps.cfg_train)
+
+    def _zero_grad(self, net, parts):
+        """opt.zero_grad() (train_IEMOCAP.py:216,245); with unreduced weight gradients only what still accumulates: heads, `object`"""
+        if parts:
+            net.grad[net.enc_floats:].zero_()
+        else:
+            net.grad.zero_()
 
     def _adam_slice(self, net, lo, hi):
         ops.adam_update_raw(net.slab[lo:hi], net.grad[lo:hi], net.exp_avg[lo:hi], net.exp_avg_sq[lo:hi], net.step, hi - lo,
@@ -583,15 +607,15 @@ class GanEngine(_Runner):
         divides by world: grad_scale) to each slice as soon as its reduce is done; without a process group it is the
         plain whole-slab Adam step."""
         if self.pg is None:
-            def plain(net_key):
+            def plain(net_key, parts=None):
                 self._pre_write(net_key)
-                self._adam(net)
+                self._adam(net, parts)
             return None, plain
         if dp_mode() == "inline":
             import torch.distributed as dist
             group = getattr(self, "_cur_pg", None) or self.pg
 
-            def inline(net_key):
+            def inline(net_key, parts=None):
                 # on the CURRENT stream (the sub-step's own): sum over ranks, then Adam divides by world (grad_scale)
                 dist.all_reduce(net.grad, op=dist.ReduceOp.SUM, group=group, async_op=False)
                 self._pre_write(net_key)
@@ -602,7 +626,7 @@ class GanEngine(_Runner):
         def cb(lo, hi, last):
             red.reduce_async(net.grad[lo:hi], lo, hi)
 
-        def finish_and_step(net_key):
+        def finish_and_step(net_key, parts=None):
             self._pre_write(net_key)            # other streams' readers of these parameters first (WAR)
             red.finish(lambda lo, hi: self._adam_slice(net, lo, hi) if hi > lo else None)
             ops.adam_bump_raw(net.step)
@@ -631,16 +655,19 @@ class GanEngine(_Runner):
                       ops._ptr(self.losses[loss_slot:loss_slot + 1]), 0, ops._stream())
         ops._lib.call("ganffn_bce2_bwd", ops._ptr(pd.out), C.c_float(1.0), C.c_float(0.0), 2 * B, B, n, C.c_float(1.0),
                       ops._ptr(self.dprob2), ops._stream())
-        Dn.grad.zero_()                                              # opt.zero_grad(), :216
+        parts_mode = self._parts_ok(Dn, pd)
+        self._zero_grad(Dn, parts_mode)                              # opt.zero_grad(), :216
         cb, finish = self._make_reducer(Dn)
-        self._net_bwd(Dn, pd, self.dprob2, True, adds, True, cb, need_dx=Dn.has_obj)
+        parts = self._net_bwd(Dn, pd, self.dprob2, True, adds, True, cb, need_dx=Dn.has_obj, parts=parts_mode)
         if Dn.has_obj:
             self.d_real.copy_(pd.dx[:, :B])                      # gradient of the real half of the batch
+            # (scratch: the workspace BELOW the unreduced weight-gradient chunks the Adam launch is about to read)
+            scratch = self.ws[:parts[3]] if (parts is not None and parts[2] > 1) else self.ws
             ops.linear_bwd_raw(self.d_real, batch[who], Dn.w("object.weight"), None, Dn.w("object.weight", True),
-                               Dn.w("object.bias", True), S * B, Dn.obj_in, self.D_h, self.ws)
+                               Dn.w("object.bias", True), S * B, Dn.obj_in, self.D_h, scratch)
             if cb is not None:
                 cb(Dn.enc_floats, Dn.enc_floats + Dn.obj_floats, last=True)
-        finish(("D", who))
+        finish(("D", who), parts)
 
     def train_gen_forward(self, who, batch, loss_slot):
         """the generator's own forward of train_gen (train mode, saved for backward): it reads nothing but the generator's
@@ -661,10 +688,11 @@ class GanEngine(_Runner):
         ops.bce_fwd_raw(pd.out, 1.0, n, 1.0, self.losses[loss_slot:loss_slot + 1], False)
         ops.bce_bwd_raw(pd.out, 1.0, n, 1.0, self.dprob1)
         self._net_bwd(Dn, pd, self.dprob1, False, d_adds, False)             # through the frozen D: dgrad only
-        Gn.grad.zero_()
+        parts_mode = self._parts_ok(Gn, pg_)
+        self._zero_grad(Gn, parts_mode)
         cb, finish = self._make_reducer(Gn)
-        self._net_bwd(Gn, pg_, pd.dx, True, g_adds, True, cb)
-        finish(("G", who))
+        parts = self._net_bwd(Gn, pg_, pd.dx, True, g_adds, True, cb, parts=parts_mode)
+        finish(("G", who), parts)
 
     def _pre_write(self, net_key):
         """called right before a sub-step's Adam: wait for other streams' readers of that network (WAR)"""

@@ -189,6 +189,21 @@ class _Net(nn.Module):
         super().__setstate__(state)
         self._pack()
 
+    def _replicate_for_data_parallel(self):
+        """nn.DataParallel with MORE than one device replicates the module and scatters the inputs along dim 0.  The trainer's
+        tensors are (seq_len, batch, dim) (train_IEMOCAP.py:142-147), so that wrap (train_IEMOCAP.py:587-593) cuts every
+        DIALOGUE into sequence fragments, one per GPU, each with its positional encoding restarting at 0 — the reference's own
+        README reports the F1 drop (README.md:82-83).  The build refuses to reproduce that: one process per GPU, dialogues
+        (dim 1) sharded, gradients all-reduced over RCCL.  (With ONE device — `nn.DataParallel(m, device_ids=[0])`, or the
+        reference's plain `nn.DataParallel(m)` on a one-GPU machine — torch never replicates and the wrap is harmless:
+        tests/test_hip_module_path.py.)"""
+        raise RuntimeError(
+            "%s: nn.DataParallel over several GPUs scatters dim 0, which for this model's (seq_len, batch, dim) tensors is the "
+            "SEQUENCE axis (the reference's train_IEMOCAP.py:587-593 bug: every dialogue is cut into per-GPU fragments; its README "
+            "reports the F1 drop).  Use one process per GPU with dialogues sharded along dim 1 — `python bench.py --gpus N` / "
+            "engine.GanEngine(process_group=...), INTEGRATION.md section 3 — or restrict the wrap to one device "
+            "(device_ids=[0])." % type(self).__name__)
+
     @property
     def slab(self):
         self._ensure_packed()

@@ -145,6 +145,27 @@ def encoder_bwd_raw(cfg, lo, hi, dx, slab, gslab, saved, ws, rng, add, need_dx_i
               _ptr(rng), C.c_uint64(add), 1 if need_dx_in else 0, _stream())
 
 
+def encoder_bwd_parts_supported(cfg):
+    """does the whole-stack backward of this configuration leave its weight gradients unreduced (ganffn_encoder_bwd_parts)?"""
+    return int(_lib.load().ganffn_encoder_bwd_parts_supported(C.byref(cfg))) == 1
+
+
+def encoder_bwd_parts_raw(cfg, dx, slab, gslab, saved, ws, rng, add, need_dx_in=True):
+    """whole-stack backward with unreduced weight gradients -> (parts tensor view into ws or None, part_stride, n_parts, offset
+    of the parts in ws): hand them to adam_step_parts_raw before anything else touches ws[offset:]"""
+    off, stride, n = C.c_int64(0), C.c_int64(0), C.c_int(0)
+    _lib.call("ganffn_encoder_bwd_parts", C.byref(cfg), _ptr(dx), _ptr(slab), _ptr(gslab), _ptr(saved), _ptr(ws), _ptr(rng),
+              C.c_uint64(add), 1 if need_dx_in else 0, C.byref(off), C.byref(stride), C.byref(n), _stream())
+    return (ws[off.value:] if n.value > 1 else None), stride.value, n.value, off.value
+
+
+def adam_step_parts_raw(p, g, m, v, step, n, lr, b1, b2, parts, part_stride, n_parts, enc_floats, layer_floats, covered, eps=1e-8,
+                        wd=0.0, gscale=1.0):
+    _lib.call("ganffn_adam_step_parts", _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(step), C.c_int64(n), C.c_float(lr), C.c_float(b1),
+              C.c_float(b2), C.c_float(eps), C.c_float(wd), C.c_float(gscale), _ptr(parts), C.c_int64(part_stride), n_parts,
+              C.c_int64(enc_floats), C.c_int64(layer_floats), C.c_int64(covered), _stream())
+
+
 def head_fwd_raw(cfg, x, w1, b1, w2, b2, w3, b3, out, saved, ws, rng, add):
     _lib.call("ganffn_head_fwd", C.byref(cfg), _ptr(x), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3),
               _ptr(out), _ptr(saved), _ptr(ws), _ptr(rng), C.c_uint64(add), _stream())

@@ -131,6 +131,24 @@ int ganffn_encoder_bwd2(const ganffn_enc_cfg* cfg, int layer_lo, int layer_hi, f
                         const float* params, float* grads, const float* saved, float* workspace,
                         const uint64_t* rng, uint64_t rng_offset_add, int need_dx_in, void* stream);
 
+/* The whole-stack backward of a d_model-100 network with its weight gradients left UNREDUCED (round 5; the single-GPU step
+ * runner): replaces `opt.zero_grad(); loss.backward()` + the gradient read of `opt.step()` of train_disc / train_gen
+ * (train_IEMOCAP.py:216-226, 245-251) without the 14.5 MB zero-fill of the gradient slab and without the reduce launch.
+ * The grouped weight-gradient launch cuts the token range into *n_parts chunks; chunk 0 WRITES (not +=) its partial
+ * gradients into grads' encoder region, chunk z >= 1 into workspace + *part_offset + (z - 1) * *part_stride, a buffer shaped
+ * like that region; the LayerNorm parameter gradients are written too.  So grads' encoder region [0, L * layer floats) need
+ * NOT be zeroed by the caller (everything behind it — heads, `object` — still accumulates).  ganffn_adam_step_parts then adds
+ * the chunks in order: exactly the sum, in exactly the association, that ganffn_encoder_bwd2's reduce launch forms — the
+ * update is bit-identical.  The workspace must stay untouched between the two calls.
+ * ganffn_encoder_bwd_parts_supported(cfg): 1 when this form exists for cfg (d_model 100, default kernel paths), else 0;
+ * ganffn_encoder_bwd_parts_covered(E, F): floats at the head of each layer block that the chunks cover (weights and biases of
+ * in-proj, out-proj, linear1, linear2; the LayerNorm parameters behind them are not chunked). */
+int ganffn_encoder_bwd_parts_supported(const ganffn_enc_cfg* cfg);
+int64_t ganffn_encoder_bwd_parts_covered(int E, int F);
+int ganffn_encoder_bwd_parts(const ganffn_enc_cfg* cfg, float* dx, const float* params, float* grads, const float* saved,
+                             float* workspace, const uint64_t* rng, uint64_t rng_offset_add, int need_dx_in,
+                             int64_t* part_offset, int64_t* part_stride, int* n_parts, void* stream);
+
 /* ---- A3-A6: heads ------------------------------------------------------------------- */
 /* x [T x E] = encoder output.  w1[D1,E] b1[D1] w2[D2,D1] b2[D2]; disc only: w3[1,D2] b3[1].
  * out: gen -> fusion [T x D2]; disc -> prob [T x 1]. */
@@ -175,6 +193,14 @@ int ganffn_bce2_bwd(const float* prob, float target_a, float target_b, int perio
 int ganffn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                      int32_t* step, int64_t n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, float grad_scale, void* stream);
+/* ganffn_adam_step over a slab whose encoder weight gradients ganffn_encoder_bwd_parts left unreduced: for element i of the
+ * covered part of a layer block (i < enc_floats, i % layer_floats < covered_per_layer) the gradient is
+ * grads[i] + parts[i] + parts[part_stride + i] + ... (n_parts - 1 extra chunks, in order); elsewhere grads[i].
+ * n_parts == 1 is ganffn_adam_step. */
+int ganffn_adam_step_parts(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t* step, int64_t n,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                           const float* parts, int64_t part_stride, int n_parts, int64_t enc_floats, int64_t layer_floats,
+                           int64_t covered_per_layer, void* stream);
 /* The same update on a SLICE of the slabs with t = *step + 1 and the counter left alone, and the bump on its own:
  * data-parallel training applies Adam bucket by bucket, each as soon as its gradient all-reduce has finished
  * (ganffn_adam_update per bucket, then one ganffn_adam_bump) — identical to one ganffn_adam_step over the whole slab. */

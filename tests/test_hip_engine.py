@@ -159,6 +159,37 @@ def test_iteration_is_bit_reproducible(n_streams):
             assert torch.equal(res[0][1][key][n], res[1][1][key][n]), (key, n)
 
 
+@pytest.mark.parametrize("S,B,n_streams", [(40, 8, 1), (40, 8, 3), (94, 32, 3)])
+def test_unreduced_weight_gradient_chunks_give_the_reduce_launchs_bits(S, B, n_streams, monkeypatch):
+    """round 5: on one GPU the d_model-100 weight gradients stay as token-chunk slabs that the Adam launch adds itself
+    (ganffn_encoder_bwd_parts + ganffn_adam_step_parts: no tn100_reduce launch, no zero-fill of the gradient slab) — the same
+    sum in the same association, so two iterations leave EVERY parameter of all six networks and every loss bit-identical to
+    the path through the reduce launch (GANFFN_ADAM_PARTS=0).  (40, 8): the generators' passes (320 tokens) run one chunk,
+    the discriminators' [real | fake] passes (640 tokens) two; (94, 32): three chunks everywhere."""
+    from gan_ffn_amd import engine, ops
+    batch = gan_batch(S=S, B=B)
+    res = []
+    for parts in ("1", "0"):
+        monkeypatch.setenv("GANFFN_ADAM_PARTS", parts)
+        gens, discs = build_all(zero_dropout=False)
+        ops.manual_seed(77)
+        eng = engine.GanEngine(gens, discs, n_streams=n_streams)
+        ls = []
+        for _ in range(2):
+            losses = eng.iteration(batch)
+            eng.synchronize()
+            ls.append(losses.clone())
+        torch.cuda.synchronize()
+        slabs = {("G", k): m.slab.detach().cpu().clone() for k, m in gens.items()}
+        slabs.update({("D", k): m.slab.detach().cpu().clone() for k, m in discs.items()})
+        res.append((torch.stack(ls).cpu(), slabs))
+        if parts == "1":
+            assert eng._parts_ok(eng.D["text"], eng.pass_D2["text"]) and not eng._parts_ok(eng.G["visual"], eng.pass_G["visual"])
+    assert torch.equal(res[0][0], res[1][0]), (res[0][0] - res[1][0]).abs().max()
+    for key in res[0][1]:
+        assert torch.equal(res[0][1][key], res[1][1][key]), key
+
+
 def test_phase2_step_matches_reference_fixture():
     """GAN_FFN forward + MaskedNLLLoss + backward (A11) through the fast runner vs the reference's own numbers"""
     from gan_ffn_amd import engine, model

@@ -73,3 +73,15 @@ def test_engine_reproduces_reference_iteration_at_headline_size(n_streams):
         losses = eng.losses.tolist()
     err = np.abs(np.array(losses) - g["gan/losses"])
     assert (err <= np.array(HEAD_LOSS_TOL)).all(), err
+
+
+@pytest.mark.parametrize("cls_name,din", [("TextDiscriminator", 100), ("AcousticGenerator", 100)])
+def test_weight_gradients_over_all_32_dialogues_are_strict_on_the_hip_relu_pattern(cls_name, din):
+    """at the headline size the weight gradients were pinned to the reference fixture only at rtol 1e-2 with
+    5 % outliers (the fixture's own fp32 ReLU-kink noise), and the STRICT comparison — fp64 oracle on the HIP forward's own
+    ReLU pattern and the same Philox masks — ran on 2 of the 32 dialogues.  Here it runs on ALL 32, train mode: every one of the
+    3008 tokens contributes to the token-summed weight gradients, which are held to rtol 1e-3 of scale with NO outliers
+    (so are the output at 1e-4 and dx at 2e-4).  Reference ops: /root/reference/model.py:1200-1231, 1367-1397 under
+    train_IEMOCAP.py:200-252's backward."""
+    from test_hip_properties import train_mode_backward_vs_oracle
+    train_mode_backward_vs_oracle(cls_name, din, list(range(B)), grad_rtol=1e-3)

@@ -173,3 +173,51 @@ def test_shim_modules_pickle_and_reload_like_the_trainer_does():
     assert type(m2).__name__ == "TextDiscriminator" and torch.equal(m2(x), y0)
     with pytest.raises(NotImplementedError):
         ns.FocalLoss()
+
+
+def test_literal_trainer_binding_dataparallel_wrap_and_cpu_batches():
+    """the trainer's own two lines that INTEGRATION.md section 1 used to ask a maintainer to edit, taken literally on a one-GPU
+    machine: every module wrapped as `nn.DataParallel(m).cuda()` (/root/reference/train_IEMOCAP.py:587-593; device_ids = [0]
+    here so that the test means the same on a multi-GPU box) and the batch handed over as CPU FloatTensors
+    (`real_text = Variable(textf.type(FloatTensor))`, :349-351, FloatTensor = the CPU alias of :40), labels on the device
+    (:341-346).  torch's single-device DataParallel scatters the inputs to cuda:0 and calls the module: 4 sub-steps against
+    the reference's own trajectory (tests/golden/gan_steps.npz)."""
+    from torch import nn
+    g = golden("gan_steps")
+    gens, discs = build_six(bind_model("shim"))
+    inner = {("G", k): m for k, m in gens.items()}
+    inner.update({("D", k): m for k, m in discs.items()})
+    gens = {k: nn.DataParallel(m, device_ids=[0]).cuda() for k, m in gens.items()}
+    discs = {k: nn.DataParallel(m, device_ids=[0]).cuda() for k, m in discs.items()}
+    opts = make_optimizers(gens, discs)                          # Adam over wrapper.parameters() = the slab views
+    FloatTensor = torch.FloatTensor
+    batch = {k: torch.from_numpy(F_.formula_input("gan." + k, 7, 2, DIN[k], pad_from=5)).cuda().type(FloatTensor) for k in DIN}
+    assert all(not v.is_cuda for v in batch.values())
+    valid = torch.ones(7, 2, 1, device="cuda")
+    fake = torch.zeros(7, 2, 1, device="cuda")
+    losses = []
+    for kind, who, partner in SCHEDULE[:4]:
+        if kind == "D":
+            losses.append(float(train_disc(discs[who], batch[who], gens[partner], batch[partner], opts[("D", who)], valid, fake)))
+        else:
+            losses.append(float(train_gen(gens[who], batch[who], discs[partner], opts[("G", who)], valid, fake)))
+    err = np.abs(np.array(losses) - g["gan/losses"][:4])
+    assert (err <= np.array(GAN_LOSS_TOL[:4])).all(), err
+    for (grp, k), m in inner.items():                            # the wrap did not move or re-pack anything
+        assert m.slab.is_cuda and m.fc1.weight.data_ptr() >= m.slab.data_ptr()
+    sd = dict(inner[("D", "visual")].named_parameters())
+    check_first_update(g, "D", "visual", lambda k: sd[k].detach().cpu().numpy())
+
+
+def test_dataparallel_over_several_devices_is_refused_with_the_reason():
+    """nn.DataParallel with more than one device would replicate() the module and scatter dim 0 = the SEQUENCE axis
+    (train_IEMOCAP.py:587-593 on (seq_len, batch, dim) tensors): the build refuses and says what to do instead"""
+    m = bind_model("package").TextGenerator(100, dropout=0.2).cuda()
+    with pytest.raises(RuntimeError) as e:
+        m._replicate_for_data_parallel()              # what torch.nn.parallel.replicate calls on every module of the network
+    msg = str(e.value)
+    assert "SEQUENCE axis" in msg and "INTEGRATION.md section 3" in msg and "587-593" in msg
+    if torch.cuda.device_count() > 1:
+        from torch import nn
+        with pytest.raises(RuntimeError):
+            nn.DataParallel(m, device_ids=[0, 1])(torch.rand(7, 2, 100))

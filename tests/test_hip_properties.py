@@ -61,10 +61,16 @@ def test_full_size_train_mode_backward_matches_oracle_on_two_dialogues(cls_name,
     gradient zero outside those two dialogues the HIP weight gradients are exactly the two-dialogue sums the oracle
     computes; the oracle draws the FULL batch's Philox masks and slices them (Rng.select), and takes the ReLU pattern
     the HIP forward took.  Strict bounds, no outliers."""
+    train_mode_backward_vs_oracle(cls_name, din, [5, 17])
+
+
+def train_mode_backward_vs_oracle(cls_name, din, sel, grad_rtol=1e-3):
+    """the comparison above for the dialogues `sel` (tests/test_hip_headline.py runs it with ALL 32: every token of the
+    headline batch then contributes to the token-summed weight gradients that are held to `grad_rtol`, no outliers)"""
     import test_hip_modules as M
     from gan_ffn_amd import ops
     from util import _assert_close
-    S, B, sel = 94, 32, [5, 17]
+    S, B = 94, 32
     kind, _, E, H, fcs, has_obj = NETS[cls_name]
     net = build(cls_name).train()
     seed = 8675309
@@ -75,7 +81,9 @@ def test_full_size_train_mode_backward_matches_oracle_on_two_dialogues(cls_name,
     gy = torch.zeros(S, B, y.shape[-1])
     gy[:, sel] = torch.rand(S, len(sel), y.shape[-1], generator=g) - 0.5
     (y * gy.cuda()).sum().backward()
-    assert float(x.grad[:, [b for b in range(B) if b not in sel]].abs().max()) == 0.0   # no cross-dialogue leakage
+    others = [b for b in range(B) if b not in sel]
+    if others:
+        assert float(x.grad[:, others].abs().max()) == 0.0   # no cross-dialogue leakage
 
     onet = O.OracleNet(kind, formula_sd(cls_name), H, 0.2, torch.float64)
     xo = x.detach()[:, sel].double().cpu().requires_grad_(True)
@@ -92,7 +100,7 @@ def test_full_size_train_mode_backward_matches_oracle_on_two_dialogues(cls_name,
     sd = dict(net.named_parameters())
     keys = M.GRAD_KEYS + (("object.weight",) if has_obj and din == 512 else ())
     for k in keys:
-        _assert_close(sd[k].grad.cpu().double().numpy(), onet.P[k].grad.numpy(), 1e-3, 1e-8, "grad " + k, 0.0, 1.0)
+        _assert_close(sd[k].grad.cpu().double().numpy(), onet.P[k].grad.numpy(), grad_rtol, 1e-8, "grad " + k, 0.0, 1.0)
 
 
 @pytest.mark.parametrize("cls_name,din", [("TextGenerator", 100), ("VisualDiscriminator", 512)])
