@@ -89,7 +89,6 @@ SIGNATURES = {
     "ganffn_attention_keep_words": (_L, [_I, _I]),
     "ganffn_attention_fwd_keep": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),
     "ganffn_attention_bwd_keep": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),
-    "ganffn_attention_bwd_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, C.POINTER(C.c_int), _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),
     "ganffn_add_dropout_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U32, _P, _U64, _P]),
     "ganffn_add_dropout_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U32, _P, _U64, _P]),
     "ganffn_general2_attention_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

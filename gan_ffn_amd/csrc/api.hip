@@ -380,7 +380,6 @@ static int encoder_bwd_impl(const ganffn_enc_cfg* c, int layer_lo, int layer_hi,
     const int64_t RCW = rc_pack_floats();              // per layer: in_w^T [E x 3E] | out_w^T [E x E]
     if (rc) GF_TRY(launch_rc_pack(params + (int64_t)layer_lo * lo.total, lo.total, lo.in_w, lo.out_w, rcw, layer_hi - layer_lo, st));
     const int lnblk = rc ? rc_blocks(T) : ln_bwd_blocks(T);
-    const int dq_parts = (rc && !md.attn_split_off()) ? attn16_bwd_split_parts(E, H, S) : 1;
     TnDesc tn[40];
     int ntn = 0;
     float* r_gw[2 * 64]; float* r_gb[2 * 64]; const float* r_part[2 * 64]; int r_nb[2 * 64];
@@ -411,10 +410,9 @@ static int encoder_bwd_impl(const ganffn_enc_cfg* c, int layer_lo, int layer_hi,
                 GF_TRY(launch_rc_ln_bwd(nullptr, nullptr, dx, 1, 0, nullptr, sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dyA,
                                         G ? lnp2 : nullptr, nullptr, nullptr, T, c->p_enc, site + 3, rng, add, train, st));
             else
-                // (+ the partial dQ slabs the key-split attention backward of layer l + 1 left in `tmp`)
                 GF_TRY(launch_rc_ln_bwd(bs + SET + TF + 2 * TE, rcw + (int64_t)(l + 1 - layer_lo) * RCW, nullptr, 0, 0, dz1,
                                         sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dyA, G ? lnp2 : nullptr, nullptr, nullptr, T,
-                                        c->p_enc, site + 3, rng, add, train, st, tmp, dq_parts, TE));
+                                        c->p_enc, site + 3, rng, add, train, st));
         } else {
             GF_TRY(launch_add_drop_ln_bwd(dxin, sv + so.xhat2, sv + so.rstd2, P + lo.n2w, dz2, dyA, G ? G + lo.n2w : nullptr,
                                           G ? G + lo.n2b : nullptr, T, E, c->p_enc, site + 3, rng, add, train, st, dxin_slabs, TE,
@@ -464,14 +462,8 @@ static int encoder_bwd_impl(const ganffn_enc_cfg* c, int layer_lo, int layer_hi,
         if (G) tn[ntn++] = TnDesc{dyB, E, sv + so.attn_o, E, G + lo.out_w, E, G + lo.out_b, E, E, T};
         if (!rc) GF_TRY(launch_gemm_nn(dyB, E, P + lo.out_w, E, d_attn, E, T, E, E, EPI_NONE, none, st));
         // attention core backward
-        // d_model 100 (head_dim 10), every layer but the bottom one of the range: split by key tiles, dQ as partial slabs in `tmp`
-        // (free between this layer's LN1 backward and the next linear1 dgrad), summed by the rowchain kernel that reads d_qkv next
-        if (dq_parts > 1 && l > layer_lo)
-            GF_TRY(launch_attn16_bwd_split(sv + so.qkv, sv + so.attn_o, sv + so.lse, d_attn, reinterpret_cast<const uint32_t*>(sv + so.keep),
-                                           d_qkv, tmp, TE, S, B, E, H, c->p_enc, site + 0, rng, add, train, st));
-        else
-            GF_TRY(launch_attention_bwd(sv + so.qkv, sv + so.attn_o, sv + so.lse, d_attn, reinterpret_cast<const uint32_t*>(sv + so.keep), d_qkv, S, B, E,
-                                        H, c->p_enc, site + 0, rng, add, train, st));
+        GF_TRY(launch_attention_bwd(sv + so.qkv, sv + so.attn_o, sv + so.lse, d_attn, reinterpret_cast<const uint32_t*>(sv + so.keep), d_qkv, S, B, E,
+                                    H, c->p_enc, site + 0, rng, add, train, st));
         // in-proj wgrad + dgrad; dX[l] = d_qkv W_in + dz1
         if (G) tn[ntn++] = TnDesc{d_qkv, 3 * E, Xl, E, G + lo.in_w, E, G + lo.in_b, 3 * E, E, T};
         if (ntn == 40 || (l == layer_lo && ntn > 0)) {
@@ -800,17 +792,6 @@ extern "C" int ganffn_attention_bwd_keep(const float* qkv, const float* o, const
                                          float* d_qkv, int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng,
                                          uint64_t add, void* stream) {
     return launch_attention_bwd(qkv, o, lse, d_o, keep, d_qkv, S, B, E, H, p, site, rng, add, 1, (hipStream_t)stream);
-}
-// key-split backward of the head_dim-10 networks as the encoder stack launches it for every layer but the bottom one: dK / dV
-// complete, dQ as *n_parts partial slabs (part 0 in d_qkv's q columns, part j >= 1 at dq_slabs + (j - 1) * slab_stride, [T x E])
-extern "C" int ganffn_attention_bwd_split(const float* qkv, const float* o, const float* lse, const float* d_o, const uint32_t* keep,
-                                          float* d_qkv, float* dq_slabs, int64_t slab_stride, int* n_parts, int S, int B, int E, int H,
-                                          float p, uint32_t site, const uint64_t* rng, uint64_t add, void* stream) {
-    GF_CHECK_ARG(n_parts, "attention_bwd_split: null n_parts");
-    *n_parts = attn16_bwd_split_parts(E, H, S);
-    GF_CHECK_ARG(*n_parts > 1, "attention_bwd_split: E=%d H=%d S=%d is not split (head_dim 10, S > 32 only)", E, H, S);
-    return launch_attn16_bwd_split(qkv, o, lse, d_o, keep, d_qkv, dq_slabs, (long)slab_stride, S, B, E, H, p, site, rng, add, 1,
-                                   (hipStream_t)stream);
 }
 extern "C" int ganffn_attention_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, float* d_qkv, int S,
                                     int B, int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add,

@@ -63,26 +63,25 @@ struct HeadStage {
     static constexpr int LD = A16<HD>::LD, PR = LD / 2, ROWS = 16 * NT, PER = ROWS * PR, NTH = 64 * NW;
     static constexpr int U = (PER + NTH - 1) / NTH;
     float2 v[NM][U];
-    // s0: first sequence position of this image (a workgroup of the key-split backward stages only its own keys' K / V rows)
-    __device__ __forceinline__ void load(const HeadSrc16 (&m)[NM], int S, int B, int b, int tid, int s0 = 0) {
+    __device__ __forceinline__ void load(const HeadSrc16 (&m)[NM], int S, int B, int b, int tid) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = min(tid + u * NTH, PER - 1);
             const int s = i / PR, j = i - s * PR;
-            const size_t row = (size_t)(min(s0 + s, S - 1) * B + b);
+            const size_t row = (size_t)(min(s, S - 1) * B + b);
             const int col = min(2 * j, HD - 2);
 #pragma unroll
             for (int mi = 0; mi < NM; ++mi) v[mi][u] = *reinterpret_cast<const float2*>(m[mi].src + row * m[mi].ld_src + col);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    __device__ __forceinline__ void store(const HeadSrc16 (&m)[NM], int S, int tid, int s0 = 0) const {
+    __device__ __forceinline__ void store(const HeadSrc16 (&m)[NM], int S, int tid) const {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = tid + u * NTH;
             if (PER % NTH == 0 || i < PER) {
                 const int s = i / PR, j = i - s * PR;
-                const float in = (s0 + s < S && 2 * j < HD) ? 1.f : 0.f;
+                const float in = (s < S && 2 * j < HD) ? 1.f : 0.f;
 #pragma unroll
                 for (int mi = 0; mi < NM; ++mi) {
                     const float f = in * m[mi].scale;
@@ -461,213 +460,6 @@ __global__ __launch_bounds__(64 * NT) void attn16_bwd_kernel(const float* __rest
     }
 }
 
-
-// ------------------------------------------------------------------------------------------
-// backward, KEY-SPLIT (round 5): a (dialogue, head) problem as ceil(NT / KW) workgroups of KW waves; workgroup `part` owns key
-// tiles part * KW .. part * KW + KW - 1.
-//
-// Why: the whole-problem kernel above launches B * H six-wave workgroups — 320 on 256 CUs for a 32-dialogue pass: 64 CUs
-// carry two (12 waves), 192 carry one, and the launch lasts as long as the 12-wave CUs (1.6x the average load; the same
-// shape at 640 problems, 3 against 2.5).  Everything a wave does in the backward is per KEY TILE: scores, dP, dS of all
-// queries against its 16 keys, and its keys' dK / dV, which it owns outright.  Only dQ = dS K sums over keys.  So the
-// problem splits by key tiles with NO change to a wave's work: 960 two-wave workgroups (3.75 per CU) for 320 problems, each
-// staging q, dO (all queries) and only its own 32 rows of K and V.
-//   * dK, dV: the same MFMA sequence on the same operands as the whole-problem kernel -> bit-identical;
-//   * dQ: each part computes scale * sum over ITS keys and writes a PARTIAL slab: part 0 into the q columns of d_qkv, part
-//     j >= 1 into dq_slabs[j - 1] ([T x E] each).  The consumer that reads d_qkv next — rc_bwd_kernel<2, .> (rowchain.hip: the
-//     in-proj dgrad + LayerNorm2 backward of the layer below) — adds the slabs in part order and writes the sum back for the
-//     weight-gradient launch.  No atomics: the order is fixed.
-//   * dropout keep bits: from the forward's keep words (SAVED; one dword per query tile and lane straight from memory,
-//     issued with the staging loads) or re-evaluated by Philox (one call per query tile and lane, as above).
-// A wave beyond the last key tile (NT % KW != 0: the last part) runs on clamped, zeroed operands and stores nothing.
-// ------------------------------------------------------------------------------------------
-template <int HD, int NT, int KW, bool SAVED>
-__global__ __launch_bounds__(64 * KW) void attn16_bwd_split_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
-                                                                   const float* __restrict__ lse, const float* __restrict__ d_o,
-                                                                   const uint32_t* __restrict__ keepw, float* __restrict__ d_qkv,
-                                                                   float* __restrict__ dq_slabs, long slab_stride, int S, int B, int E,
-                                                                   int H, float p, uint32_t site, const uint64_t* __restrict__ rng,
-                                                                   uint64_t add, int train) {
-    constexpr int LD = A16<HD>::LD, NTD = A16<HD>::NTD, KS = A16<HD>::KS, ROWS = 16 * NT, MAT = ROWS * LD + A16<HD>::TAIL;
-    constexpr int KROWS = 16 * KW, KMAT = KROWS * LD + A16<HD>::TAIL;
-    constexpr int NPART = (NT + KW - 1) / KW, QT = (NT + KW - 1) / KW;       // parts per problem; query tiles per wave (D, dQ)
-    constexpr int LDS_S = KROWS + 4;                     // dS image [query][local key]: rows 4 apart sit 16 banks apart
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int bh = blockIdx.x / NPART, part = blockIdx.x - bh * NPART, b = bh / H, head = bh - b * H;
-    const int kt = part * KW + w;                        // this wave's key tile (>= NT: a spare wave of the last part)
-    // K (this part's rows), LSE and D live for the whole kernel; scaled q, dO and V are dead once dV / dK are accumulated and
-    // the dS image takes their place
-    float* Ks = smem;            // [KROWS] local key rows
-    float* Ls = Ks + KMAT;       // [ROWS] log-sum-exp per query (+big for padded rows)
-    float* Ds = Ls + ROWS;       // [ROWS] D_i = sum_d dO_id O_id
-    float* Qs = Ds + ROWS;       // scaled q, all queries
-    float* Os = Qs + MAT;        // dO, all queries
-    float* Vs = Os + MAT;        // [KROWS]
-    float* SS = Qs;              // [ROWS][LDS_S] dS, over q / dO / V
-    const int ld3 = 3 * E;
-    const float scale = rsqrtf((float)HD);
-    const DropCtx dc = make_drop(rng, add, site, p, train);
-    uint32_t wdt[NT][4];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) wdt[t][0] = wdt[t][1] = wdt[t][2] = wdt[t][3] = 0xFFFFFFFFu;
-    {
-        const HeadSrc16 mq[2] = {{Qs, qkv + head * HD, ld3, scale}, {Os, d_o + head * HD, E, 1.f}};
-        const HeadSrc16 mk[2] = {{Ks, qkv + E + head * HD, ld3, 1.f}, {Vs, qkv + 2 * E + head * HD, ld3, 1.f}};
-        // D and LSE of query tiles w, w + KW, ... straight from global memory (issued with the staging loads)
-        float ov[QT][KS], dv[QT][KS], lv[QT];
-#pragma unroll
-        for (int j = 0; j < QT; ++j) {
-            const int qi = 16 * min(w + KW * j, NT - 1) + c;
-            const size_t rowo = (size_t)(min(qi, S - 1) * B + b) * E + head * HD;
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                const int d = min(4 * kk + g, HD - 1);
-                ov[j][kk] = o[rowo + d];
-                dv[j][kk] = d_o[rowo + d];
-            }
-            lv[j] = lse[(size_t)bh * S + min(qi, S - 1)];
-        }
-        uint32_t kwt[NT];
-        if (SAVED) {
-            // keep word [query group 4t + g][key column c]: nibble kt = this wave's key tile
-#pragma unroll
-            for (int t = 0; t < NT; ++t) kwt[t] = keepw[((size_t)bh * 28 + 4 * t + g) * 16 + c];
-        }
-        HeadStage<HD, NT, 2, KW> stq;
-        HeadStage<HD, KW, 2, KW> stk;
-        stq.load(mq, S, B, b, tid);
-        stk.load(mk, S, B, b, tid, KROWS * part);
-        if (!SAVED && dc.on) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                philox4((uint32_t)(bh * 28 + 4 * t + g) * 128u + (uint32_t)(16 * kt + c), dc.site, dc.o0, dc.o1, dc.k0, dc.k1, wdt[t]);
-        }
-        stq.store(mq, S, tid);
-        stk.store(mk, S, tid, KROWS * part);
-        if (SAVED) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const uint32_t nib = kwt[t] >> (4 * (kt & 7));
-#pragma unroll
-                for (int r = 0; r < 4; ++r) wdt[t][r] = ((nib >> r) & 1u) ? 0xFFFFFFFFu : 0u;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < QT; ++j) {
-            const int qt = w + KW * j, qi = 16 * min(qt, NT - 1) + c;
-            float part_ = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) part_ += (4 * kk + g < HD && qi < S) ? ov[j][kk] * dv[j][kk] : 0.f;
-            part_ += __shfl_xor(part_, 16, 64);
-            part_ += __shfl_xor(part_, 32, 64);
-            if (g == 0 && qt < NT) {
-                Ds[qi] = part_;
-                Ls[qi] = qi < S ? lv[j] : 1e30f;
-            }
-        }
-    }
-    __syncthreads();
-
-    const int kj = 16 * kt + c, kl = 16 * w + c;       // this lane's key: global position, local row
-    floatx4 ps[NT], dp[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float4 l4 = *reinterpret_cast<const float4*>(Ls + 16 * t + 4 * g);
-        ps[t] = floatx4{-l4.x, -l4.y, -l4.z, -l4.w};
-        dp[t] = floatx4{0.f, 0.f, 0.f, 0.f};
-    }
-    dot_tiles<HD, NT>(ps, Qs, Ks + kl * LD + g, c, g);      // S[query 16t+4g+reg][key kj] - LSE
-    dot_tiles<HD, NT>(dp, Os, Vs + kl * LD + g, c, g);      // dP~[query][key] = dO . V
-
-    const bool keyok = kj < S;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float4 d4 = *reinterpret_cast<const float4*>(Ds + 16 * t + 4 * g);
-        const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float pv = keyok ? __expf(ps[t][r]) : 0.f;
-            const bool keep = !dc.on || wdt[t][r] >= dc.thr;
-            const float dpk = keep ? dp[t][r] * dc.scale : 0.f;
-            ps[t][r] = keep ? pv * dc.scale : 0.f;
-            dp[t][r] = pv * (dpk - dd[r]);
-        }
-    }
-
-    // dV^T[d][key] = sum_q dO[q][d] P~[q][key];  dK^T[d][key] = sum_q (scale Q)[q][d] dS[q][key] — the whole-problem kernel's sequence
-    {
-        floatx4 av[NTD], ak[NTD];
-#pragma unroll
-        for (int dt = 0; dt < NTD; ++dt) { av[dt] = floatx4{0.f, 0.f, 0.f, 0.f}; ak[dt] = floatx4{0.f, 0.f, 0.f, 0.f}; }
-        const float* pv_ = Os + 4 * g * LD + c;
-        const float* pk_ = Qs + 4 * g * LD + c;
-        float a1[2][4][NTD], a2[2][4][NTD];
-        auto fetch = [&](int t, float (&d1)[4][NTD], float (&d2)[4][NTD]) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int dt = 0; dt < NTD; ++dt) {
-                    d1[r][dt] = pv_[(16 * t + r) * LD + 16 * dt];
-                    d2[r][dt] = pk_[(16 * t + r) * LD + 16 * dt];
-                }
-        };
-        fetch(0, a1[0], a2[0]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t + 1 < NT) fetch(t + 1, a1[(t + 1) & 1], a2[(t + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int dt = 0; dt < NTD; ++dt) {
-                    av[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t & 1][r][dt], ps[t][r], av[dt], 0, 0, 0);
-                    ak[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[t & 1][r][dt], dp[t][r], ak[dt], 0, 0, 0);
-                }
-        }
-        if (keyok) {
-            float* row = d_qkv + (size_t)(kj * B + b) * ld3 + head * HD;
-#pragma unroll
-            for (int dt = 0; dt < NTD; ++dt) {
-                store4<HD>(row + 2 * E, 16 * dt + 4 * g, av[dt], 1.f);
-                store4<HD>(row + E, 16 * dt + 4 * g, ak[dt], 1.f);
-            }
-        }
-    }
-    // dS -> LDS [query][local key], over the operands every wave has finished reading
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) SS[(16 * t + 4 * g + r) * LDS_S + kl] = dp[t][r];
-    __syncthreads();
-
-    // partial dQ^T[d][query] = scale * sum over THIS PART's keys of K[key][d] dS[query][key]; wave w: query tiles w, w + KW, ...
-    float* const dq_base = part == 0 ? d_qkv + head * HD : dq_slabs + (size_t)(part - 1) * slab_stride + head * HD;
-    const int dq_ld = part == 0 ? ld3 : E;
-#pragma unroll
-    for (int j = 0; j < QT; ++j) {
-        const int qt = min(w + KW * j, NT - 1);
-        floatx4 pq[KW];
-        const float* ss = SS + (16 * qt + c) * LDS_S + 4 * g;
-#pragma unroll
-        for (int t = 0; t < KW; ++t) {
-            const float4 q4 = *reinterpret_cast<const float4*>(ss + 16 * t);
-            pq[t] = floatx4{q4.x, q4.y, q4.z, q4.w};
-        }
-        floatx4 aq[NTD];
-#pragma unroll
-        for (int dt = 0; dt < NTD; ++dt) aq[dt] = floatx4{0.f, 0.f, 0.f, 0.f};
-        apply_tiles<HD, KW>(aq, pq, Ks, c, g);
-        const int qi = 16 * qt + c;
-        if (qi < S && w + KW * j < NT) {
-            float* row = dq_base + (size_t)(qi * B + b) * dq_ld;
-#pragma unroll
-            for (int dt = 0; dt < NTD; ++dt) store4<HD>(row, 16 * dt + 4 * g, aq[dt], scale);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -699,8 +491,7 @@ template <int HD, int NT>
 static int launch16_fwd(const float* qkv, float* o, float* lse, uint32_t* keepw, int S, int B, int E, int H, float p, uint32_t site,
                         const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
     const size_t lds = fwd_lds<HD>(NT);
-    // (the keep words are stored whenever the caller gives a buffer: the key-split backward uses them at every size, the
-    // whole-problem backward while attn16_use_keep())
+    if (!attn16_use_keep(B, H)) keepw = nullptr;
     // query tiles per workgroup: measured at hd = 10, S = 94 (tools/lab/attn_wpb.py, lab build): 320 problems 11.1 us as
     // whole workgroups, 10.1 / 9.9 / 11.5 us cut in 2 / 3 / 6; 640 problems 15.0 us whole, 16.4 / 17.9 / 21.5 us cut —
     // the cut pays while the problems do not fill the chip, then the repeated K / V staging costs more than the balance gains
@@ -729,32 +520,6 @@ static int launch16_bwd(const float* qkv, const float* o, const float* lse, cons
         GF_TRY((lds_optin<attn16_bwd_kernel<HD, NT, false>>(lds, "attention_bwd")));
         hipLaunchKernelGGL((attn16_bwd_kernel<HD, NT, false>), dim3(B * H), dim3(64 * NT), lds, st, qkv, o, lse, d_o, keepw, d_qkv, S,
                            B, E, H, p, site, rng, add, train);
-    }
-    GF_LAUNCH_CHECK();
-    return 0;
-}
-
-// key-split backward (attn16_bwd_split_kernel): LDS = local K + LSE + D + max(q | dO | local V, dS image)
-template <int HD>
-static size_t bwd_split_lds(int nt, int kw) {
-    const size_t mat = (size_t)16 * nt * A16<HD>::LD + A16<HD>::TAIL, kmat = (size_t)16 * kw * A16<HD>::LD + A16<HD>::TAIL;
-    const size_t img = (size_t)16 * nt * (16 * kw + 4), ops3 = 2 * mat + kmat;
-    return (kmat + 2 * 16 * nt + (img > ops3 ? img : ops3)) * sizeof(float);
-}
-template <int HD, int NT, int KW>
-static int launch16_bwd_split(const float* qkv, const float* o, const float* lse, const float* d_o, const uint32_t* keepw, float* d_qkv,
-                              float* dq_slabs, long slab_stride, int S, int B, int E, int H, float p, uint32_t site,
-                              const uint64_t* rng, uint64_t add, int train, hipStream_t st) {
-    const size_t lds = bwd_split_lds<HD>(NT, KW);
-    constexpr int NPART = (NT + KW - 1) / KW;
-    if (keepw != nullptr && train && p > 0.f && !mode().attn_split_philox()) {          // the forward of this pass stored its keep words
-        GF_TRY((lds_optin<attn16_bwd_split_kernel<HD, NT, KW, true>>(lds, "attention_bwd_split")));
-        hipLaunchKernelGGL((attn16_bwd_split_kernel<HD, NT, KW, true>), dim3(B * H * NPART), dim3(64 * KW), lds, st, qkv, o, lse, d_o,
-                           keepw, d_qkv, dq_slabs, slab_stride, S, B, E, H, p, site, rng, add, train);
-    } else {
-        GF_TRY((lds_optin<attn16_bwd_split_kernel<HD, NT, KW, false>>(lds, "attention_bwd_split")));
-        hipLaunchKernelGGL((attn16_bwd_split_kernel<HD, NT, KW, false>), dim3(B * H * NPART), dim3(64 * KW), lds, st, qkv, o, lse, d_o,
-                           keepw, d_qkv, dq_slabs, slab_stride, S, B, E, H, p, site, rng, add, train);
     }
     GF_LAUNCH_CHECK();
     return 0;
@@ -797,30 +562,6 @@ int launch_attn16_bwd(const float* qkv, const float* o, const float* lse, const 
     if (E / H == 60) { NT16_SWITCH3(launch16_bwd, 60, qkv, o, lse, d_o, keepw, d_qkv, S, B, E, H, p, site, rng, add, train, st) }
     if (E / H == 10) { NT16_SWITCH(launch16_bwd, 10, qkv, o, lse, d_o, keepw, d_qkv, S, B, E, H, p, site, rng, add, train, st) }
     NT16_SWITCH(launch16_bwd, 30, qkv, o, lse, d_o, keepw, d_qkv, S, B, E, H, p, site, rng, add, train, st)
-}
-
-// Key-split backward of the head_dim-10 networks (the d_model-100 stacks): partial dQ slabs, see attn16_bwd_split_kernel.
-// -> number of dQ parts (part 0 sits in d_qkv's q columns, parts 1.. in dq_slabs), 1 = not split (whole-problem kernel).
-int attn16_bwd_split_parts(int E, int H, int S) {
-    if (!(H > 0 && E % H == 0 && E / H == 10)) return 1;
-    const int nt = (S + 15) / 16;
-    return nt >= 3 ? (nt + ATTN_SPLIT_KW - 1) / ATTN_SPLIT_KW : 1;
-}
-int launch_attn16_bwd_split(const float* qkv, const float* o, const float* lse, const float* d_o, const uint32_t* keepw, float* d_qkv,
-                            float* dq_slabs, long slab_stride, int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng,
-                            uint64_t add, int train, hipStream_t st) {
-    GF_CHECK_ARG(attn16_bwd_split_parts(E, H, S) > 1 && S <= GANFFN_MAX_SEQ, "attn16_bwd_split: unsupported E=%d H=%d S=%d", E, H, S);
-    GF_CHECK_ARG(o && lse && dq_slabs && aligned16(dq_slabs) && (slab_stride & 3) == 0, "attn16_bwd_split: needs o, lse and aligned dQ slabs");
-    GF_CHECK_ARG((long)B * H * 28 * 128 < (1l << 32), "attention: B*H too large for the Philox counter");
-#define GF_SPLIT(NT) return launch16_bwd_split<10, NT, ATTN_SPLIT_KW>(qkv, o, lse, d_o, keepw, d_qkv, dq_slabs, slab_stride, S, B, E, H, p, site, rng, add, train, st);
-    switch ((S + 15) / 16) {
-        case 3: GF_SPLIT(3)
-        case 4: GF_SPLIT(4)
-        case 5: GF_SPLIT(5)
-        case 6: GF_SPLIT(6)
-        default: GF_SPLIT(7)
-    }
-#undef GF_SPLIT
 }
 
 }  // namespace ganffn

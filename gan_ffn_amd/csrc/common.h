@@ -39,10 +39,7 @@ struct Mode {
     bool n100_pad7() const { return bits & (1u << 23); }            // bit 23: padded seventh tile instead of the 4x4x1 tail
     bool outproj_nosplit() const { return bits & (1u << 24); }      // bit 24: the wide out-proj unsplit
     bool mask_float() const { return bits & (1u << 25); }           // bit 25: linear2 dgrad reads the saved activation, not the bits
-    bool attn_split_off() const { return bits & (1u << 26); }       // bit 26: whole-problem attention backward (round 4's form)
-    bool rc_split_off() const { return bits & (1u << 27); }         // bit 27: one workgroup per 16 token rows in every rowchain kernel
     bool adam_slabs_off() const { return bits & (1u << 28); }       // bit 28: tn100 slabs through the reduce launch (round 4's form)
-    bool attn_split_philox() const { return bits & (1u << 29); }    // bit 29 (lab): the key-split attention backward re-evaluates Philox
 };
 extern std::atomic<uint32_t> g_mode_word;
 inline Mode mode() { return Mode{g_mode_word.load(std::memory_order_relaxed)}; }
@@ -325,16 +322,6 @@ int launch_attn16_bwd(const float* qkv, const float* o, const float* lse, const 
                       int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
                       hipStream_t st);
 
-// key-split small-head backward (head_dim 10): the dQ of a (dialogue, head) problem leaves as attn16_bwd_split_parts partial
-// slabs — part 0 in d_qkv's q columns, parts 1.. in dq_slabs [parts - 1][T x E] — which launch_rc_ln_bwd adds in part order
-// (and writes back into d_qkv for the weight-gradient launch)
-constexpr int ATTN_SPLIT_KW = 2;            // key tiles (= waves) per workgroup
-constexpr int ATTN_SPLIT_MAX_PARTS = 4;     // ceil(7 / 2)
-int attn16_bwd_split_parts(int E, int H, int S);
-int launch_attn16_bwd_split(const float* qkv, const float* o, const float* lse, const float* d_o, const uint32_t* keepw, float* d_qkv,
-                            float* dq_slabs, long slab_stride, int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng,
-                            uint64_t add, int train, hipStream_t st);
-
 int launch_pe_dropout(const float* x, const float* pe, float* out, int S, int B, int E, float p,
                       const uint64_t* rng, uint64_t add, int train, hipStream_t st);
 int launch_dropout_bwd_inplace(float* dx, int R, int C, float p, uint32_t site, const uint64_t* rng, uint64_t add,
@@ -378,12 +365,10 @@ int launch_rc_pe_inproj_fwd(const float* x_in, const float* pe, float* out, cons
 int launch_rc_ln_inproj_fwd(const float* y, int nslab, long slab_stride, const float* x, const float* gamma, const float* beta,
                             float* out, float* xhat, float* rstd, const float* w_in, const float* b_in, float* qkv, int T,
                             float eps, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, hipStream_t st);
-// q_slabs / n_q_parts: d_qkv's q columns hold part 0 of a key-split attention backward and q_slabs [n_q_parts - 1][T x E] the
-// other parts: they are added in part order and the sum is written back into d_qkv (d_qkv is then NOT const)
-int launch_rc_ln_bwd(float* d_qkv, const float* w_in_t, const float* d_out, int nslab, long slab_stride, const float* addend,
+int launch_rc_ln_bwd(const float* d_qkv, const float* w_in_t, const float* d_out, int nslab, long slab_stride, const float* addend,
                      const float* xhat, const float* rstd, const float* gamma, float* dz, float* dy, float* gpart,
                      const float* wo_t, float* d_attn, int T, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
-                     hipStream_t st, const float* q_slabs = nullptr, int n_q_parts = 1, long q_slab_stride = 0);
+                     hipStream_t st);
 int launch_gelu_drop_fwd(const float* x, float* out, int R, int C, float p, uint32_t site, const uint64_t* rng,
                          uint64_t add, int train, hipStream_t st);
 

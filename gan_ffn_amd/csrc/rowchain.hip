@@ -46,7 +46,6 @@ namespace {
 constexpr int RE = 100;              // d_model handled here
 constexpr int RT = (RE + 15) / 16;   // 7 feature tiles of 16 over a 100-wide row
 constexpr int LDX = 116;             // LDS row stride of a 16 x 100 row tile (zero-padded to 112 columns)
-constexpr int RC_POST_WAVES = 10;    // waves per workgroup of the forward kernels with a trailing in-proj: 19 tiles, two per wave
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -133,17 +132,10 @@ struct RcFwdArgs {
     int T, B; float eps, p; uint32_t site; const uint64_t* rng; uint64_t add; int train;
 };
 
-// z = x + dropout(y); out = LayerNorm(z); optionally the next layer's in-proj on the fresh rows.
-// NW waves per workgroup (round 5): the LayerNorm stage runs on waves 0..3 exactly as before (same instruction sequence, same
-// reduction order -> the same bits); the trailing in-proj — 19 feature tiles, which the four waves used to run five deep (125
-// MFMAs = 4000 cycles at the tail of a latency chain) — is dealt over ALL NW waves, tile w + NW j to wave w: with NW = 10 two
-// tiles per wave.  Each tile is still computed by one wave in the same k order, so qkv keeps its bits too.  The extra waves
-// issue their weight loads at kernel start and meet the others at the barriers (every wave executes every barrier).
-template <int PRE, bool POST_GEMM, int NW>
-__global__ __launch_bounds__(64 * NW) void rc_fwd_kernel(RcFwdArgs a) {
-    static_assert(NW >= 4 && (POST_GEMM || NW == 4), "the LayerNorm stage needs waves 0..3; extra waves only serve the trailing GEMM");
+// z = x + dropout(y); out = LayerNorm(z); optionally the next layer's in-proj on the fresh rows
+template <int PRE, bool POST_GEMM>
+__global__ __launch_bounds__(256) void rc_fwd_kernel(RcFwdArgs a) {
     constexpr int NP = 3 * RE, PT = (NP + 15) / 16;     // in-proj: 300 output features, 19 tiles
-    constexpr int PJ = POST_GEMM ? (PT + NW - 1) / NW : 1;           // in-proj tiles per wave
     __shared__ __attribute__((aligned(16))) float red[2 * 64];
     __shared__ __attribute__((aligned(16))) float xs[POST_GEMM ? 16 * LDX : 4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4, ql = c & 3;
@@ -151,17 +143,6 @@ __global__ __launch_bounds__(64 * NW) void rc_fwd_kernel(RcFwdArgs a) {
     const bool tok = t0 + c < T;
     const size_t trow = (size_t)min(t0 + c, T - 1);
     const DropCtx dc = make_drop(a.rng, a.add, a.site, a.p, a.train);
-    // trailing GEMM operands of this wave, up front (every wave)
-    Frag<RE> wpost[PJ];
-    float4 pb[PJ];
-    if constexpr (POST_GEMM) {
-#pragma unroll
-        for (int j = 0; j < PJ; ++j) {
-            wpost[j].load(a.post_w + (size_t)min(16 * (w + NW * j) + c, NP - 1) * RE, g);
-            pb[j] = f4(a.post_b + min(16 * (w + NW * j) + 4 * g, NP - 4));
-        }
-    }
-  if (w < 4) {
 
     // this wave's feature tiles: w and w + 4 (tile 7 does not exist: wave 3 recomputes tile 6 and discards it)
     int mt[2], f0[2], f0c[2];
@@ -175,6 +156,11 @@ __global__ __launch_bounds__(64 * NW) void rc_fwd_kernel(RcFwdArgs a) {
     }
 
     // ---------------- every independent load, up front ----------------
+    Frag<RE> wpost[3];                   // trailing GEMM, tiles w, w + 4, w + 8 (all < 19)
+    if constexpr (POST_GEMM) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) wpost[j].load(a.post_w + (size_t)min(16 * (w + 4 * j) + c, NP - 1) * RE, g);
+    }
     Frag<RE> xf, wf[2];
     float4 bias[2], ysum[2];
     if constexpr (PRE == 1) {
@@ -286,38 +272,37 @@ __global__ __launch_bounds__(64 * NW) void rc_fwd_kernel(RcFwdArgs a) {
         }
     }
     if (a.rstd && w == 0 && g == 0 && tok) a.rstd[t0 + c] = rs;
-  } else if constexpr (PRE != 2) {
-    // waves 4 .. NW - 1: the two barriers of the LayerNorm statistics (token_allreduce), nothing else
-    __syncthreads();
-    __syncthreads();
-  }
 
     // ---------------- trailing GEMM: in-proj of the next layer ----------------
     if constexpr (POST_GEMM) {
+        // second tile group (w + 12, w + 16) in flight while the first one multiplies
+        Frag<RE> wpost2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wpost2[j].load(a.post_w + (size_t)min(16 * (w + 12 + 4 * j) + c, NP - 1) * RE, g);
+        float4 pb[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) pb[j] = f4(a.post_b + min(16 * (w + 4 * j) + 4 * g, NP - 4));
         __syncthreads();
         Frag<RE> af;
         af.load(xs + c * LDX, g);
-        floatx4 acc[PJ];
+        floatx4 acc[3] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+        mma<RE, 3>(acc, wpost, af);
+        floatx4 acc2[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+        mma<RE, 2>(acc2, wpost2, af);
 #pragma unroll
-        for (int j = 0; j < PJ; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-        mma<RE, PJ>(acc, wpost, af);
-#pragma unroll
-        for (int j = 0; j < PJ; ++j) {
-            const int pf = 16 * (w + NW * j) + 4 * g;        // (a tile beyond the 19: computed on a clamped copy, discarded)
-            if (tok && (w + NW * j) < PT && pf < NP)
+        for (int j = 0; j < 5; ++j) {
+            const int pf = 16 * (w + 4 * j) + 4 * g;        // (tile 19 = wave 3's fifth: beyond the matrix, discarded)
+            const floatx4 r4 = j < 3 ? acc[j] : acc2[j - 3];
+            if (tok && (w + 4 * j) < PT && pf < NP)
                 *reinterpret_cast<float4*>(a.post_out + trow * NP + pf) =
-                    make_float4(acc[j][0] + pb[j].x, acc[j][1] + pb[j].y, acc[j][2] + pb[j].z, acc[j][3] + pb[j].w);
+                    make_float4(r4[0] + pb[j].x, r4[1] + pb[j].y, r4[2] + pb[j].z, r4[3] + pb[j].w);
         }
     }
 }
 
 struct RcBwdArgs {
     // incoming gradient d = (pre_a . pre_wt^T | sum of slabs | one tensor) + addend
-    float* pre_a; const float* pre_wt;           // PRE = 2: d_qkv of the layer above [T x 3E], its in-proj weight TRANSPOSED [E x 3E]
-    // PRE = 2, key-split attention backward (attention16.hip): pre_a's q columns hold part 0 of dQ, q_slabs [n_q_parts - 1][T x E]
-    // the other parts; the kernel adds them in part order and writes the sum back into pre_a (the weight-gradient launch reads
-    // it).  n_q_parts == 1: q_slabs is any readable address (never added)
-    const float* q_slabs; int n_q_parts; long q_slab_stride;
+    const float* pre_a; const float* pre_wt;     // PRE = 2: d_qkv of the layer above [T x 3E], its in-proj weight TRANSPOSED [E x 3E]
     const float* d_out; int nslab; long slab_stride;
     const float* addend;                         // may be null
     const float* xhat; const float* rstd; const float* gamma;
@@ -328,26 +313,17 @@ struct RcBwdArgs {
 };
 
 // PRE: 0 = d_out is one tensor, 1 = d_out is nslab partial slabs, 2 = d = pre_a . pre_wt^T (K = 3E)
-// NW = 8 (PRE = 2 only, round 5): the K = 300 in-proj dgrad — 7 feature tiles x 19 k groups, which four waves ran as
-// 7 x 5 x 4 = 140 MFMAs each behind 40 operand loads per lane — is dealt over eight waves: wave w takes K quarter w & 3 (as
-// before) of feature tiles 4 (w >> 2) .. 4 (w >> 2) + 3: 80 MFMAs behind 25 loads.  The partial tiles meet in LDS in the
-// same [K quarter][tile] layout and are added in the same quarter order, so every bit is unchanged; the LayerNorm backward
-// itself stays on waves 0..3, the others only meet the barriers.
-template <int PRE, bool POST_GEMM, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void rc_bwd_kernel(RcBwdArgs a) {
-    static_assert(NW == 4 || (NW == 8 && PRE == 2 && !POST_GEMM), "8 waves: the K = 300 dgrad form only");
+template <int PRE, bool POST_GEMM>
+__global__ __launch_bounds__(256) void rc_bwd_kernel(RcBwdArgs a) {
     constexpr int K3 = 3 * RE, KQ3 = (K3 + 15) / 16, NQW = (KQ3 + 3) / 4;      // 19 k groups, <= 5 per wave
     constexpr int LDP = 112;
-    constexpr int MT = NW == 8 ? 4 : RT;      // feature tiles of the K-split product per wave
     // pp: PRE = 2: the waves' partial tiles [4][7][64] float4; afterwards (all kernels) the two 16 x 112 tiles whose column
     // sums are the LayerNorm parameter gradients
     __shared__ __attribute__((aligned(16))) float pp[PRE == 2 ? 4 * RT * 64 * 4 : 2 * 16 * LDP];
     __shared__ __attribute__((aligned(16))) float red[2 * 64];
     __shared__ __attribute__((aligned(16))) float xs[POST_GEMM ? 16 * LDX : 4];
     static_assert(4 * RT * 64 * 4 >= 2 * 16 * LDP, "pp must hold the two gradient tiles");
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4, ql = c & 3;
-    const int w = wv & 3;                      // K quarter (PRE = 2) / LayerNorm-stage wave
-    const bool lnw = wv < 4;                   // waves 4..7 (NW = 8) only run their share of the K-split product
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4, ql = c & 3;
     const int t0 = blockIdx.x * 16, T = a.T;
     const bool tok = t0 + c < T;
     const size_t trow = (size_t)min(t0 + c, T - 1);
@@ -378,71 +354,39 @@ __global__ __launch_bounds__(64 * NW) void rc_bwd_kernel(RcBwdArgs a) {
     }
     if constexpr (PRE == 2) {
         // K split over the waves: wave w takes k groups w, w + 4, ... of the 19 for ALL 7 feature tiles
-        const int m0 = NW == 8 ? 4 * (wv >> 2) : 0;          // first feature tile of this wave
-        float4 xq[NQW], wq[MT][NQW];
+        float4 xq[NQW], wq[RT][NQW];
 #pragma unroll
         for (int u = 0; u < NQW; ++u) {
             const int q = w + 4 * u, col = 16 * q + 4 * g;
             const bool ok = q < KQ3 && col < K3;
             const int colc = min(col, K3 - 4);
-            float4 tx = f4(a.pre_a + trow * K3 + colc);
-            if (u < 2) {
-                // q columns (col < E; only k groups 0..6 = u < 2 hold any): + the other parts of a key-split dQ, in part order.
-                // (The sum is written back into d_qkv behind the barrier below — with 8 waves two waves read each element.)
-                const bool isq = ok && col < RE;
-                const float* qs = a.q_slabs + trow * RE + min(col, RE - 4);
-                float4 pv[ATTN_SPLIT_MAX_PARTS - 1];
-#pragma unroll
-                for (int j = 0; j < ATTN_SPLIT_MAX_PARTS - 1; ++j) pv[j] = f4(qs + (size_t)min(j, max(a.n_q_parts - 2, 0)) * a.q_slab_stride);
-#pragma unroll
-                for (int j = 0; j < ATTN_SPLIT_MAX_PARTS - 1; ++j) {
-                    const float m = (isq && j + 1 < a.n_q_parts) ? 1.f : 0.f;
-                    tx.x += m * pv[j].x; tx.y += m * pv[j].y; tx.z += m * pv[j].z; tx.w += m * pv[j].w;
-                }
-            }
+            const float4 tx = f4(a.pre_a + trow * K3 + colc);
             xq[u] = ok ? tx : zero4();
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const float4 tw = f4(a.pre_wt + (size_t)min(16 * (m0 + m) + c, RE - 1) * K3 + colc);
+            for (int m = 0; m < RT; ++m) {
+                const float4 tw = f4(a.pre_wt + (size_t)min(16 * m + c, RE - 1) * K3 + colc);
                 wq[m][u] = ok ? tw : zero4();
             }
         }
-        __builtin_amdgcn_sched_barrier(0);   // all operand loads in flight before the first MFMA waits for one
-        floatx4 acc[MT];
+        __builtin_amdgcn_sched_barrier(0);   // all 40 operand loads in flight before the first MFMA waits for one
+        floatx4 acc[RT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < RT; ++m) acc[m] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < NQW; ++u) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[m][u].x, xq[u].x, acc[m], 0, 0, 0);
+            for (int m = 0; m < RT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[m][u].x, xq[u].x, acc[m], 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[m][u].y, xq[u].y, acc[m], 0, 0, 0);
+            for (int m = 0; m < RT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[m][u].y, xq[u].y, acc[m], 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[m][u].z, xq[u].z, acc[m], 0, 0, 0);
+            for (int m = 0; m < RT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[m][u].z, xq[u].z, acc[m], 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[m][u].w, xq[u].w, acc[m], 0, 0, 0);
+            for (int m = 0; m < RT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[m][u].w, xq[u].w, acc[m], 0, 0, 0);
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-            if (m0 + m < RT)                 // (wave-uniform: the eighth tile of the second half does not exist)
-                *reinterpret_cast<float4*>(pp + ((w * RT + m0 + m) * 64 + lane) * 4) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+        for (int m = 0; m < RT; ++m)
+            *reinterpret_cast<float4*>(pp + ((w * RT + m) * 64 + lane) * 4) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
         __syncthreads();
-        if (a.n_q_parts > 1 && lnw) {
-            // every wave has its operands in registers (its MFMAs waited for them): the summed dQ goes back into d_qkv's q
-            // columns for the weight-gradient launch; each (token, column) by the one lane of waves 0..3 that holds it
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int col = 16 * (w + 4 * u) + 4 * g;
-                if (col < RE && tok) *reinterpret_cast<float4*>(a.pre_a + trow * K3 + col) = xq[u];
-            }
-        }
-        if constexpr (NW == 8) {
-            if (!lnw) {                      // waves 4..7 are done; they meet the remaining barriers of the LayerNorm stage
-                __syncthreads();             // (pp reuse)
-                __syncthreads();             // (row statistics)
-                return;
-            }
-        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -599,7 +543,7 @@ int launch_rc_outproj_ln_fwd(const float* attn_o, const float* wo, const float* 
     RcFwdArgs a{};
     a.pre_a = attn_o; a.pre_w = wo; a.pre_b = bo; a.x = x; a.gamma = gamma; a.beta = beta; a.out = out; a.xhat = xhat; a.rstd = rstd;
     a.T = T; a.eps = eps; a.p = p; a.site = site; a.rng = rng; a.add = add; a.train = train;
-    hipLaunchKernelGGL((rc_fwd_kernel<1, false, 4>), dim3(rc_blocks(T)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((rc_fwd_kernel<1, false>), dim3(rc_blocks(T)), dim3(256), 0, st, a);
     GF_LAUNCH_CHECK();
     return 0;
 }
@@ -617,9 +561,8 @@ int launch_rc_ln_inproj_fwd(const float* y, int nslab, long slab_stride, const f
     a.y = y; a.nslab = nslab; a.slab_stride = slab_stride; a.x = x; a.gamma = gamma; a.beta = beta; a.out = out; a.xhat = xhat;
     a.rstd = rstd; a.post_w = w_in; a.post_b = b_in; a.post_out = qkv;
     a.T = T; a.eps = eps; a.p = p; a.site = site; a.rng = rng; a.add = add; a.train = train;
-    if (w_in && mode().rc_split_off()) hipLaunchKernelGGL((rc_fwd_kernel<0, true, 4>), dim3(rc_blocks(T)), dim3(256), 0, st, a);
-    else if (w_in) hipLaunchKernelGGL((rc_fwd_kernel<0, true, RC_POST_WAVES>), dim3(rc_blocks(T)), dim3(64 * RC_POST_WAVES), 0, st, a);
-    else hipLaunchKernelGGL((rc_fwd_kernel<0, false, 4>), dim3(rc_blocks(T)), dim3(256), 0, st, a);
+    if (w_in) hipLaunchKernelGGL((rc_fwd_kernel<0, true>), dim3(rc_blocks(T)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((rc_fwd_kernel<0, false>), dim3(rc_blocks(T)), dim3(256), 0, st, a);
     GF_LAUNCH_CHECK();
     return 0;
 }
@@ -633,8 +576,7 @@ int launch_rc_pe_inproj_fwd(const float* x_in, const float* pe, float* out, cons
     RcFwdArgs a{};
     a.y = pe; a.x = x_in; a.out = out; a.post_w = w_in; a.post_b = b_in; a.post_out = qkv;
     a.T = T; a.B = B; a.p = p; a.site = SITE_PE; a.rng = rng; a.add = add; a.train = train;
-    if (mode().rc_split_off()) hipLaunchKernelGGL((rc_fwd_kernel<2, true, 4>), dim3(rc_blocks(T)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((rc_fwd_kernel<2, true, RC_POST_WAVES>), dim3(rc_blocks(T)), dim3(64 * RC_POST_WAVES), 0, st, a);
+    hipLaunchKernelGGL((rc_fwd_kernel<2, true>), dim3(rc_blocks(T)), dim3(256), 0, st, a);
     GF_LAUNCH_CHECK();
     return 0;
 }
@@ -643,12 +585,10 @@ int launch_rc_pe_inproj_fwd(const float* x_in, const float* pe, float* out, cons
 // [E x 3E]) when d_qkv is given, else the nslab slabs of d_out; + addend.  Outgoing: dz, dy = dz * dropout multiplier, the
 // per-workgroup partial sums of the LayerNorm parameter gradients (gpart: rc_blocks(T) * 2 * E floats), and with wo_t
 // (out-proj weight transposed) d_attn = dy . wo_t^T.
-int launch_rc_ln_bwd(float* d_qkv, const float* w_in_t, const float* d_out, int nslab, long slab_stride, const float* addend,
+int launch_rc_ln_bwd(const float* d_qkv, const float* w_in_t, const float* d_out, int nslab, long slab_stride, const float* addend,
                      const float* xhat, const float* rstd, const float* gamma, float* dz, float* dy, float* gpart,
                      const float* wo_t, float* d_attn, int T, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
-                     hipStream_t st, const float* q_slabs, int n_q_parts, long q_slab_stride) {
-    GF_CHECK_ARG(n_q_parts >= 1 && n_q_parts <= ATTN_SPLIT_MAX_PARTS && (n_q_parts == 1 || (d_qkv && q_slabs && aligned16(q_slabs) && (q_slab_stride & 3) == 0)),
-                 "rc_ln_bwd: bad dQ slabs (parts=%d)", n_q_parts);
+                     hipStream_t st) {
     GF_CHECK_ARG((d_qkv || d_out) && xhat && rstd && gamma && dz && T > 0, "rc_ln_bwd: bad arguments");
     GF_CHECK_ARG(!d_qkv || (w_in_t && aligned16(d_qkv) && aligned16(w_in_t)), "rc_ln_bwd: in-proj dgrad needs the transposed weight");
     GF_CHECK_ARG(!wo_t || (d_attn && dy && aligned16(wo_t) && aligned16(d_attn)), "rc_ln_bwd: out-proj dgrad needs dy and an output");
@@ -658,12 +598,10 @@ int launch_rc_ln_bwd(float* d_qkv, const float* w_in_t, const float* d_out, int 
     a.pre_a = d_qkv; a.pre_wt = w_in_t; a.d_out = d_out; a.nslab = nslab; a.slab_stride = slab_stride; a.addend = addend;
     a.xhat = xhat; a.rstd = rstd; a.gamma = gamma; a.dz = dz; a.dy = dy; a.gpart = gpart; a.post_wt = wo_t; a.post_out = d_attn;
     a.T = T; a.p = p; a.site = site; a.rng = rng; a.add = add; a.train = train;
-    a.q_slabs = n_q_parts > 1 ? q_slabs : d_qkv; a.n_q_parts = n_q_parts; a.q_slab_stride = n_q_parts > 1 ? q_slab_stride : 0;
     const dim3 grid(rc_blocks(T)), blk(256);
     if (d_qkv) {
         if (wo_t) hipLaunchKernelGGL((rc_bwd_kernel<2, true>), grid, blk, 0, st, a);
-        else if (mode().rc_split_off()) hipLaunchKernelGGL((rc_bwd_kernel<2, false>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((rc_bwd_kernel<2, false, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((rc_bwd_kernel<2, false>), grid, blk, 0, st, a);
     } else if (nslab > 1) {
         if (wo_t) hipLaunchKernelGGL((rc_bwd_kernel<1, true>), grid, blk, 0, st, a);
         else hipLaunchKernelGGL((rc_bwd_kernel<1, false>), grid, blk, 0, st, a);

@@ -356,16 +356,6 @@ int ganffn_attention_fwd_keep(const float* qkv, float* o, float* lse, uint32_t* 
 int ganffn_attention_bwd_keep(const float* qkv, const float* o, const float* lse, const float* d_o,
                               const uint32_t* keep, float* d_qkv, int S, int B, int E, int H, float p, uint32_t site,
                               const uint64_t* rng, uint64_t rng_offset_add, void* stream);
-/* Key-split form of the backward (head_dim 10, S > 32: the d_model-100 networks' attention core behind model.py:1210,1276,
- * 1307,1340,1377), as ganffn_encoder_bwd launches it for every layer but the bottom one of its range: a (dialogue, head)
- * problem runs as *n_parts workgroups of two key tiles each.  dK and dV come out complete and bit-identical to
- * ganffn_attention_bwd_keep; dQ comes out as *n_parts PARTIAL slabs — part 0 in d_qkv's q columns, part j >= 1 at
- * dq_slabs + (j - 1) * slab_stride ([T x E], q layout) — whose sum in part order is dQ (the rowchain kernel that consumes
- * d_qkv adds them).  keep may be NULL (Philox re-evaluated). */
-int ganffn_attention_bwd_split(const float* qkv, const float* o, const float* lse, const float* d_o,
-                               const uint32_t* keep, float* d_qkv, float* dq_slabs, int64_t slab_stride, int* n_parts,
-                               int S, int B, int E, int H, float p, uint32_t site, const uint64_t* rng,
-                               uint64_t rng_offset_add, void* stream);
 /* z = x + drop(y); xhat = (z-mean)*rstd; out = xhat*w + b   (norm1/norm2 of the encoder layer) */
 int ganffn_add_dropout_layernorm_fwd(const float* x, const float* y, const float* w, const float* b,
                                      float* out, float* xhat, float* rstd, int T, int E, float eps,
@@ -408,7 +398,12 @@ int ganffn_ffn_k100_hook(int which, const float* a, const float* w, const float*
                          const float* h_saved, int T, float p, uint32_t site, const uint64_t* rng, uint64_t rng_offset_add,
                          int train, void* stream);
 
-/* A/B measurement hook (process-wide), a bit mask; 0 = the default path.
+/* A/B measurement hook (process-wide), a bit mask; 0 = the default path.  It is the library's ONLY mutable process state besides
+ * the per-(kernel, device) "LDS opt-in done" masks: one 32-bit word held in a relaxed atomic (csrc/common.h `Mode`); every entry
+ * point takes one snapshot of it per call, so a setter racing with a launch makes that launch take one path or the other, never
+ * a mixture.  Bits 8..23 are lab knobs (forced tile / chunk counts), the others select an older or alternative launch
+ * sequence that stays parity-tested. */
+/*
  *   bit 0: run the d_model-100 feed-forward block as the fused kernel of ffn.hip instead of two GEMMs (measured slower);
  *   bit 1: run the token-local chains around the LayerNorms of a d_model-100 layer (out-proj + LN1, LN2 + next in-proj and
  *          their backward mirrors, csrc/rowchain.hip) as separate GEMM + LayerNorm launches;
@@ -431,6 +426,7 @@ int ganffn_ffn_k100_hook(int which, const float* a, const float* w, const float*
  *   bit 25: the linear2 dgrad takes its ReLU / dropout pattern from the saved hidden activation instead of the 1-bit copy that
  *           linear1's epilogue leaves beside it in the saved block (same predicate, same bits; 24.6 MB less to read per layer
  *           at the headline size).
+ *   bit 28: ganffn_encoder_bwd_parts_supported() answers 0: weight gradients always go through the reduce launch (same bits).
  * Every combination is parity-tested; results agree to rounding.  The switch must not change between a forward pass and
  * the backward pass that consumes its saved block. */
 int ganffn_debug_set_ffn_mode(int bits);

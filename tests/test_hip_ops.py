@@ -210,30 +210,8 @@ def test_attention_fwd_bwd(lib, S, B, E, H, p):
     assert torch.equal(od2, od) and torch.equal(dq2, dq)
     if E // H <= 32:
         assert torch.equal(lse2, lse)
-        if p > 0:
-            assert int((keep != 0).sum()) > 0        # the forward did store its keep words
-    if E // H == 10 and S > 32:
-        # the key-split backward the encoder stack runs for every layer but the bottom one (round 5): a (dialogue, head) problem as
-        # ceil(tiles / 2) two-wave workgroups.  dK / dV: the same MFMA sequence -> the SAME BITS as the whole-problem kernel;
-        # dQ: partial slabs whose sum in part order is dQ (another summation order over the key tiles: equal to rounding)
-        for kp in (keep, None):                  # forward's keep words / Philox re-evaluated: identical bits
-            dq3 = torch.full_like(dq, float("nan"))
-            slabs = torch.full((3, S, B, E), float("nan"), device="cuda")
-            n = C.c_int(0)
-            lib.call("ganffn_attention_bwd_split", ptr(qd), ptr(od2), ptr(lse2), ptr(dod), ptr(kp) if kp is not None else None, ptr(dq3),
-                     ptr(slabs), C.c_int64(S * B * E), C.byref(n), S, B, E, H, C.c_float(p), C.c_uint32(site), ptr(rng), C.c_uint64(add), stream())
-            assert n.value == ((S + 15) // 16 + 1) // 2 and 2 <= n.value <= 4
-            assert torch.equal(dq3[..., E:], dq[..., E:])                      # dK, dV bit-identical
-            total = dq3[..., :E].clone()
-            for j in range(n.value - 1):
-                total = total + slabs[j]                                         # fixed order: part 0, 1, 2, ...
-            assert not torch.isnan(total).any()
-            assert rel_err(total, q64.grad[..., :E]) < 5e-5
-            assert float((total - dq[..., :E]).abs().max()) <= 2e-5 * float(dq[..., :E].abs().max())
-            if kp is keep:
-                first = (dq3.clone(), slabs[:n.value - 1].clone())
-            else:
-                assert torch.equal(dq3, first[0]) and torch.equal(slabs[:n.value - 1], first[1])
+        if p > 0 and B * H <= 384:
+            assert int((keep != 0).sum()) > 0        # the forward did store its keep words (small launches only: see attn16_use_keep)
 
 
 @pytest.mark.parametrize("T,E", [(3008, 100), (3008, 512), (14, 100), (5, 512), (331, 100)])
