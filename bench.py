@@ -82,8 +82,8 @@ def wgrad_groups(S, B, config="iemocap"):
             (2, [(m, n, T1) for _ in range(8) for (m, n) in e512])]
 
 
-TRAFFIC_FILE = "profiles/r04_wgrad_traffic.json"
-GEMM_TRAFFIC_FILE = "profiles/r04_gemm_traffic.json"
+TRAFFIC_FILE = "profiles/r05_wgrad_traffic.json"
+GEMM_TRAFFIC_FILE = "profiles/r05_gemm_traffic.json"
 
 
 def wgrad_algorithmic_bytes(S, B, config="iemocap"):
@@ -310,7 +310,7 @@ def time_attention(S, B, reps=3):
     return _time_mix(calls, reps)
 
 
-IN_STEP_FILE = "profiles/r04_bench_streams1_by_launch_shape.txt"
+IN_STEP_FILE = "profiles/r05_bench_streams1_by_launch_shape.txt"
 
 
 def profile_is_current(rel_path):
@@ -417,7 +417,7 @@ def build_workload(config, dev):
     return engine.build_networks(device=dev, seed=3407)       # random init of the reference architecture
 
 
-DRNN_IN_STEP_FILE = "profiles/r04_drnn_by_launch_shape.txt"
+DRNN_IN_STEP_FILE = "profiles/r05_drnn_by_launch_shape.txt"
 
 
 def time_skinny_kernel(B, reps=20):

@@ -12,9 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import roofline_model as RM  # noqa: E402
 
-BENCH = os.path.join(ROOT, "profiles", "r04_bench_default.json")
-SUMMARY = os.path.join(ROOT, "profiles", "r04_bench_streams1_by_launch_shape.txt")
-needs_profiles = pytest.mark.skipif(not (os.path.exists(BENCH) and os.path.exists(SUMMARY)), reason="round-4 profiles not committed yet")
+BENCH = os.path.join(ROOT, "profiles", "r05_bench_default.json")
+SUMMARY = os.path.join(ROOT, "profiles", "r05_bench_streams1_by_launch_shape.txt")
+needs_profiles = pytest.mark.skipif(not (os.path.exists(BENCH) and os.path.exists(SUMMARY)), reason="round-5 profiles not committed yet")
 
 
 def load_line():
@@ -70,9 +70,13 @@ def test_bench_line_fractions_follow_the_committed_profile():
     assert line["roofline"]["family"] == dominant
     assert abs(line["roofline"]["frac"] - fams[dominant]["frac"]) < 1e-9
     assert abs(line["roofline"]["achieved"] / line["roofline"]["peak"] - line["roofline"]["frac"]) < 2e-3
-    # ... and roofline_worst the one with the LOWEST in-step fraction
-    worst = min(fams.values(), key=lambda f: f["in_step_frac"])["family"]
-    assert line["roofline_worst"]["family"] == worst
+    # ... and roofline_worst the one with the LOWEST in-step fraction AMONG THE FAMILIES ON THE SAME ROOF (a fraction of the MFMA
+    # peak and a fraction of the HBM peak are not comparable: ADVICE r4); the HBM-bound families have roofline_worst_hbm
+    for bound, key in (("mfma", "roofline_worst"), ("hbm", "roofline_worst_hbm")):
+        cands = [f for f in fams.values() if f["bound"] == bound]
+        if cands:
+            assert line[key]["family"] == min(cands, key=lambda f: f["in_step_frac"])["family"]
+            assert line[key]["bound"] == bound
     # the profile the line quotes was taken on the kernel sources the line was produced with
     assert line["profile"]["file"].endswith(os.path.basename(SUMMARY))
     # below peak, as it must be
@@ -81,6 +85,13 @@ def test_bench_line_fractions_follow_the_committed_profile():
     step = line["config"]["step_frac_of_fp32_mfma_peak"]
     assert 0.3 < step < 1.0
     assert abs(step - 954.3e6 * 94 * 32 / (line["ms_per_step"] * 1e-3) / RM.FP32_MFMA_PEAK) < 5e-3
+    # the EXECUTED fraction leaves out the frozen discriminators' weight gradients (6 passes the reference computes and drops)
+    frozen = 6 * (8 * 2.0 * (100 * 2048 * 2 + 100 * 100 + 300 * 100) + 2.0 * (100 * 64 + 64 * 16 + 16))
+    ex = line["config"]["step_frac_executed"]
+    assert abs(ex - (954.3e6 - frozen) * 94 * 32 / (line["ms_per_step"] * 1e-3) / RM.FP32_MFMA_PEAK) < 5e-3 and ex < step
+    # the median of device-synchronised iterations is reported beside the headline, and is the slower of the two
+    assert line["config"]["synchronised_iterations"] >= 20
+    assert line["config"]["median_ms_per_step_synchronised"] >= 0.98 * line["ms_per_step"]
 
 
 @needs_profiles
@@ -89,5 +100,5 @@ def test_committed_profiles_were_taken_on_the_kernel_code_in_the_tree():
     CODE (comments and whitespace stripped) — a kernel change without a fresh profile fails here, and bench.py would flag the
     in-step fields as stale"""
     assert RM.summary_sha(SUMMARY) == RM.csrc_sha16()
-    drnn = os.path.join(ROOT, "profiles", "r04_drnn_by_launch_shape.txt")
+    drnn = os.path.join(ROOT, "profiles", "r05_drnn_by_launch_shape.txt")
     assert RM.summary_sha(drnn) == RM.csrc_sha16()
