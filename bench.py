@@ -790,17 +790,25 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     heartbeat("rank %d of %d up (pid %d)" % (rank, world, os.getpid()), rank, every_rank=True)
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the hot path has no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # backend: nccl = RCCL over xGMI, one GPU per rank (the product).  GANFFN_DIST_BACKEND=gloo is a REHEARSAL mode for a one-GPU
+    # box: the ranks share the visible GPU(s) and reduce over gloo (RCCL refuses two ranks on one device) — it exercises the
+    # launcher and every world > 1 line of this file end to end, and says so in the line (`dist_backend`); never a measurement
+    backend = os.environ.get("GANFFN_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     pg = None
     force_dist = os.environ.get("GANFFN_FORCE_DIST", "0") == "1"   # exercise the RCCL path on a single GPU
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
-        heartbeat("rank %d: process group up (RCCL, %d ranks)" % (rank, dist.get_world_size()), rank, every_rank=True)
+        heartbeat("rank %d: process group up (%s, %d ranks)" % (rank, "RCCL" if backend == "nccl" else backend, dist.get_world_size()), rank, every_rank=True)
 
     from gan_ffn_amd import _lib, engine, ops
     if args.config == "drnn":
@@ -889,7 +897,8 @@ def main():
     value = total_utts * args.steps / dt
     if pg is not None:
         import torch.distributed as dist
-    dist_info = {"rccl_ranks": dist.get_world_size() if pg is not None else 0,          # ranks RCCL really connected (0: no process group)
+    dist_info = {"rccl_ranks": dist.get_world_size() if pg is not None else 0,          # ranks the process group really connected (0: none)
+                 "dist_backend": (backend if pg is not None else None),                 # "nccl" = RCCL; anything else is a rehearsal, not a measurement
                  "dp_mode": engine.dp_mode() if pg is not None else None,
                  "communicators": len(getattr(eng, "pgs", [None])) if pg is not None else 0,
                  "launcher_rung": os.environ.get("GANFFN_BENCH_RUNG"),

@@ -76,10 +76,6 @@ SIGNATURES = {
     "ganffn_gemm_nn": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ganffn_gemm_tn_acc": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ganffn_ffn_linear1_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _U32, _P, _U64, _I, _P]),
-    "ganffn_ffn_pack_floats": (_L, [_I]),
-    "ganffn_ffn_fused_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U32, _P, _U64, _I, _P]),
-    "ganffn_ffn_fused_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
-    "ganffn_ffn3_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _U32, _P, _U64, _I, _I, C.POINTER(C.c_int), _P]),
     "ganffn_gemm_tn_grouped_workspace_floats": (_L, []),
     "ganffn_gemm_tn_grouped": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "ganffn_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _U32, _P, _U64, _P]),

@@ -110,7 +110,7 @@ static int check_cfg(const ganffn_enc_cfg* c) {
 // DESIGN.md section 6.
 std::atomic<uint32_t> g_mode_word{0};
 GF_LAB_ONLY(extern unsigned long long* g_n100_stamps; extern unsigned long long* g_wres_stamps;)
-constexpr int MAX_SPLITS = 16;  // partial-output slabs: fused FFN (16 F splits) / split-K GEMMs (<= 8)
+constexpr int MAX_SPLITS = 16;  // partial-output slabs: K chunks of gemm_n100 (<= 16) / split-K GEMMs (<= 8)
 
 static int64_t a4(int64_t n) { return (n + 3) & ~int64_t(3); }
 
@@ -137,15 +137,13 @@ static int inproj_dgrad_splits(int T, int E) {
 static int64_t enc_ws_floats(const ganffn_enc_cfg* c) {
     const int64_t T = (int64_t)c->S * c->B, TE = T * c->E, TF = T * c->F;
     // L x (dh | dyA dyB d_qkv(3)) | dz2 dz1 d_attn | tmp slabs | L x 2 LayerNorm partial-sum blocks
-    // + L packed FFN weight blocks (fused feed-forward kernel, d_model 100)
-    const int64_t pack = ffn_fused_supported(c->E, c->F) ? (int64_t)c->L * ffn_pack_floats(c->F) : 0;
     // + the partial-slab workspace of the grouped weight-gradient launch (narrow groups split the token range)
     // + L transposed {in-proj, out-proj} weight blocks (rowchain backward, d_model 100)
     const int64_t rcw = rc_supported(c->E) ? (int64_t)c->L * rc_pack_floats() + 8 : 0;
-    const int64_t bwd = (int64_t)c->L * (TF + 5 * TE) + (3 + MAX_SPLITS) * TE + (int64_t)c->L * 2 * ln_part_floats(c) + pack +
+    const int64_t bwd = (int64_t)c->L * (TF + 5 * TE) + (3 + MAX_SPLITS) * TE + (int64_t)c->L * 2 * ln_part_floats(c) +
                         gemm_tn_grouped_part_floats() + 8 + rcw;
     const SavedOff s = saved_off(c);
-    const int64_t fwd_nosave = 2 * TE + s.per_layer + MAX_SPLITS * TE + pack;   // X ping-pong + one layer's saved set + tmp slabs + packs
+    const int64_t fwd_nosave = 2 * TE + s.per_layer + MAX_SPLITS * TE;          // X ping-pong + one layer's saved set + tmp slabs
     return (bwd > fwd_nosave ? bwd : fwd_nosave) + 64;
 }
 
@@ -208,11 +206,6 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
         tmp = workspace + 2 * TE + so.per_layer;
         Xcur = workspace;
     }
-    // d_model 100: the feed-forward block runs as ONE fused kernel per layer on weights packed in MFMA fragment order
-    const bool fused = ffn_fused_supported(E, F) && md.ffn_fused();
-    float* pack = tmp + (int64_t)MAX_SPLITS * TE;
-    const int64_t PK = fused ? ffn_pack_floats(F) : 0;
-    if (fused) GF_TRY(launch_ffn_pack(params, lo.total, lo.w1, lo.w2, pack, L, F, 0, st));
     // d_model 100: out-proj + residual + dropout + LN1 is one kernel, and LN2 carries the NEXT layer's in-proj (rowchain.hip);
     // the positional encoding + dropout at the head of the stack carries layer 0's
     const bool rc = rc_supported(E) && !md.rc_off();
@@ -257,14 +250,7 @@ extern "C" int ganffn_encoder_fwd(const ganffn_enc_cfg* c, const float* x_in, co
         }
         // FFN: h = drop(relu(x1 W1^T + b1)); y = h W2^T + b2
         int splits = 1;
-        if (md.ffn3() && ffn3_supported(E, F) && (T <= 4096 || md.ffn3_wide())) {
-            GF_TRY(launch_ffn3_fwd(sv + so.x1, P + lo.w1, P + lo.b1, P + lo.w2, P + lo.b2, saved ? sv + so.h : nullptr, tmp, TE, T,
-                                   c->p_enc, site + 2, rng, add, train, MAX_SPLITS, &splits, st));
-        } else if (fused) {
-            // one kernel; the hidden tile feeds linear2 from registers; h is streamed out only when backward needs it
-            GF_TRY(launch_ffn_fused_fwd(sv + so.x1, pack + (int64_t)l * PK, P + lo.b1, P + lo.b2, saved ? sv + so.h : nullptr,
-                                        tmp, TE, T, E, F, c->p_enc, site + 2, rng, add, train, &splits, st));
-        } else {
+        {
             EpiArgs e1;
             e1.bias = P + lo.b1; e1.p = c->p_enc; e1.site = site + 2; e1.rng = rng; e1.rng_add = add; e1.train = train;
             if (saved) e1.mask_out = reinterpret_cast<uint16_t*>(sv + so.hmask);     // the pattern the linear2 dgrad will ask for
@@ -368,13 +354,8 @@ static int encoder_bwd_impl(const ganffn_enc_cfg* c, int layer_lo, int layer_hi,
     float* tmp = d_attn + TE;         // [MAX_SPLITS][T x E] partial slabs of dh W1
     float* lnp0 = tmp + (int64_t)MAX_SPLITS * TE;   // [L][2] LayerNorm partial-sum blocks
     const int64_t LNP = ln_part_floats(c);
-    float* pack = lnp0 + (int64_t)c->L * 2 * LNP;    // packed FFN weights of the layers of this range (backward orientation)
-    const bool fused = ffn_fused_supported(E, F) && md.ffn_fused();
-    const int64_t PK = fused ? ffn_pack_floats(F) : 0;
-    float* tnp = pack + (ffn_fused_supported(E, F) ? (int64_t)c->L * ffn_pack_floats(F) : 0);   // grouped-wgrad partial slabs
+    float* tnp = lnp0 + (int64_t)c->L * 2 * LNP;     // grouped-wgrad partial slabs
     tnp = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(tnp) + 15) & ~(uintptr_t)15);
-    if (fused)
-        GF_TRY(launch_ffn_pack(params + (int64_t)layer_lo * lo.total, lo.total, lo.w1, lo.w2, pack, layer_hi - layer_lo, F, 1, st));
     const bool rc = rc_supported(E) && !md.rc_off();
     float* rcw = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(tnp + gemm_tn_grouped_part_floats()) + 15) & ~(uintptr_t)15);
     const int64_t RCW = rc_pack_floats();              // per layer: in_w^T [E x 3E] | out_w^T [E x E]
@@ -423,21 +404,16 @@ static int encoder_bwd_impl(const ganffn_enc_cfg* c, int layer_lo, int layer_hi,
         if (G) tn[ntn++] = TnDesc{dyA, E, sv + so.h, F, G + lo.w2, F, G + lo.b2, E, F, T};
         const float mscale = (pdrop > 0.f) ? 1.0f / (1.0f - pdrop) : 1.0f;
         int splits = 1;
-        if (fused) {
-            // dh = (dy W2) * [h > 0] / (1-p) and d x1 = dh W1 in one kernel (dh streamed out for the wgrad below)
-            GF_TRY(launch_ffn_fused_bwd(dyA, pack + (int64_t)(l - layer_lo) * PK, sv + so.h, dh, tmp, TE, T, E, F, mscale, &splits, st));
-        } else {
+        {
             EpiArgs em;
             em.aux_in = sv + so.h;
             em.mscale = mscale;
-            // the forward's two-GEMM path left the pattern as bits (the one-kernel forwards, debug bits 0 / 7, do not)
-            const bool fwd_was_ffn3 = md.ffn3() && ffn3_supported(E, F) && (T <= 4096 || md.ffn3_wide());
-            if (!fwd_was_ffn3 && !md.mask_float()) em.mask_in = reinterpret_cast<const uint16_t*>(sv + so.hmask);
+            if (!md.mask_float()) em.mask_in = reinterpret_cast<const uint16_t*>(sv + so.hmask);     // linear1's epilogue left the pattern as bits
             GF_TRY(launch_gemm_nn(dyA, E, P + lo.w2, F, dh, F, T, F, E, EPI_MASK_POS, em, st));
         }
         // linear1 wgrad: gW1[F,E] += dh^T x1 ; gb1 += colsum(dh)
         if (G) tn[ntn++] = TnDesc{dh, F, sv + so.x1, E, G + lo.w1, E, G + lo.b1, F, E, T};
-        if (!fused) {
+        {
             // d x1 = dh W1 (split-K slabs) + dz2, consumed directly by the LN1 backward
             if (n100_supported(E, F) && !md.n100_off()) {
                 splits = MAX_SPLITS;
@@ -743,33 +719,6 @@ extern "C" int ganffn_debug_set_ffn_mode(int bits) {
     g_mode_word.store((uint32_t)bits, std::memory_order_relaxed);
     return 0;
 }
-extern "C" int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h,
-                                    float* slabs, float* pack_ws, int T, int E, int F, float p, uint32_t site,
-                                    const uint64_t* rng, uint64_t add, int train, void* stream) {
-    GF_CHECK_ARG(w1 && w2 && pack_ws && ffn_fused_supported(E, F), "ffn_fused_fwd: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    GF_TRY(launch_ffn_pack_ptrs(w1, w2, 0, pack_ws, 1, F, 0, st));       // w1 / w2 are separate tensors here
-    int splits = 0;
-    GF_TRY(launch_ffn_fused_fwd(x, pack_ws, b1, b2, h, slabs, (long)T * E, T, E, F, p, site, rng, add, train, &splits, st));
-    return -1000 - splits;   // negative "code" carries the slab count back to the test harness (see ganffn.h)
-}
-extern "C" int ganffn_ffn_fused_bwd(const float* dy, const float* w1, const float* w2, const float* h, float* dh, float* slabs,
-                                    float* pack_ws, int T, int E, int F, float mscale, void* stream) {
-    GF_CHECK_ARG(w1 && w2 && pack_ws && ffn_fused_supported(E, F), "ffn_fused_bwd: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    GF_TRY(launch_ffn_pack_ptrs(w1, w2, 0, pack_ws, 1, F, 1, st));
-    int splits = 0;
-    GF_TRY(launch_ffn_fused_bwd(dy, pack_ws, h, dh, slabs, (long)T * E, T, E, F, mscale, &splits, st));
-    return -1000 - splits;
-}
-extern "C" int ganffn_ffn3_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h, float* slabs,
-                               int64_t slab_stride, int T, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train,
-                               int max_slabs, int* n_slabs, void* stream) {
-    GF_CHECK_ARG(n_slabs && max_slabs >= 1 && max_slabs <= MAX_SPLITS, "ffn3_fwd: max_slabs=%d out of [1,%d]", max_slabs, MAX_SPLITS);
-    return launch_ffn3_fwd(x, w1, b1, w2, b2, h, slabs, (long)slab_stride, T, p, site, rng, add, train, max_slabs, n_slabs,
-                           (hipStream_t)stream);
-}
-extern "C" int64_t ganffn_ffn_pack_floats(int F) { return ffn_pack_floats(F); }
 extern "C" int64_t ganffn_gemm_tn_grouped_workspace_floats(void) { return gemm_tn_grouped_part_floats(); }
 extern "C" int ganffn_gemm_tn_grouped(int n, const float* const* At, const float* const* Bm, float* const* C, float* const* colsum,
                                       const int* M, const int* N, const int* K, float* workspace, int64_t workspace_floats,

@@ -24,18 +24,17 @@ namespace ganffn {
 // point / launcher takes ONE snapshot (`const Mode md = mode();`) and decides from it.
 struct Mode {
     uint32_t bits;
-    bool ffn_fused() const { return bits & 1u; }                    // bit 0: ffn.hip's fused feed-forward kernel
+    // (bits 0, 7 and 22 selected the fused feed-forward kernels ffn.hip / ffn3.hip until round 5: measured slower in the step three
+    //  times over, removed from the product — history + DESIGN.md section 3; the bits are reserved and ignored)
     bool rc_off() const { return bits & 2u; }                       // bit 1: separate GEMM + LayerNorm launches instead of rowchain.hip
     bool n100_off() const { return bits & 4u; }                     // bit 2: generic tiles instead of gemm_n100.hip
     bool tn100_off() const { return bits & 8u; }                    // bit 3: generic tiles instead of gemm_tn100.hip
     bool tn100_in_kernel_sum() const { return bits & 16u; }         // bit 4: last-arriver slab sum (measured slower)
     bool dhead_off() const { return bits & 32u; }                   // bit 5: discriminator head as separate launches
     bool pe_off() const { return bits & 64u; }                      // bit 6: positional encoding and layer 0's in-proj as two launches
-    bool ffn3() const { return bits & 128u; }                       // bit 7: ffn3.hip's one-kernel feed-forward forward
     int n100_force_splits() const { return (int)((bits >> 8) & 0xFFu); }     // bits 8..15 (lab): K-chunk count of gemm_n100
     int tn100_force_splits() const { return (int)((bits >> 16) & 0xFu); }    // bits 16..19 (lab): token-chunk count of tn100
     int n100_force_kw() const { const int k = (int)((bits >> 20) & 3u); return k == 3 ? 2 : k; }   // bits 20..21 (lab)
-    bool ffn3_wide() const { return bits & (1u << 22); }            // bit 22: ffn3 also at T > 4096
     bool n100_pad7() const { return bits & (1u << 23); }            // bit 23: padded seventh tile instead of the 4x4x1 tail
     bool outproj_nosplit() const { return bits & (1u << 24); }      // bit 24: the wide out-proj unsplit
     bool mask_float() const { return bits & (1u << 25); }           // bit 25: linear2 dgrad reads the saved activation, not the bits
@@ -253,29 +252,6 @@ int launch_gemm_nn(const float* A, int lda, const float* Bm, int ldb, float* C, 
 long gemm_tn_part_floats(int M, int N, int K);
 int launch_gemm_tn_acc(const float* At, int lda, const float* Bm, int ldb, float* C, int ldc, float* colsum,
                        int M, int N, int K, hipStream_t st, float* part_ws = nullptr, long part_floats = 0);
-
-// fused feed-forward block (ffn.hip), d_model = 100 only.  `packed` = this layer's linear1 / linear2 weights in MFMA
-// fragment order (launch_ffn_pack: forward or backward orientation, ffn_pack_floats(F) floats per layer).
-bool ffn_fused_supported(int E, int F);
-int ffn_fused_splits(int T, int F);
-long ffn_pack_floats(int F);
-int launch_ffn_pack(const float* params, long layer_stride, long off_w1, long off_w2, float* packed, int L, int F, int bwd,
-                    hipStream_t st);
-int launch_ffn_pack_ptrs(const float* w1, const float* w2, long layer_stride, float* packed, int L, int F, int bwd,
-                         hipStream_t st);
-int launch_ffn_fused_fwd(const float* x, const float* packed, const float* b1, const float* b2, float* h, float* slabs,
-                         long slab_stride, int T, int E, int F, float p, uint32_t site, const uint64_t* rng, uint64_t add,
-                         int train, int* splits_out, hipStream_t st);
-int launch_ffn_fused_bwd(const float* dy, const float* packed, const float* h, float* dh, float* slabs, long slab_stride, int T,
-                         int E, int F, float mscale, int* splits_out, hipStream_t st);
-
-// feed-forward block of the d_model-100 networks as one forward kernel (ffn3.hip): 64 tokens x one hidden chunk per
-// workgroup, the hidden tile goes from product 1 to product 2 in registers; partial y per hidden chunk in slabs
-bool ffn3_supported(int E, int F);
-int ffn3_chunks(int T, int max_slabs);
-int launch_ffn3_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h, float* slabs,
-                    long slab_stride, int T, float p, uint32_t site, const uint64_t* rng, uint64_t add, int train, int max_slabs,
-                    int* splits_out, hipStream_t st);
 
 // grouped wgrad: n independent TN problems in one launch
 struct TnDesc {

@@ -308,26 +308,6 @@ int ganffn_gemm_tn_acc(const float* At, const float* Bm, float* C, float* colsum
 int ganffn_ffn_linear1_fwd(const float* x, const float* w1, const float* b1, float* h, int T, int E, int F,
                            float p, uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, int train,
                            void* stream);
-/* Fused feed-forward block for d_model = 100 (ffn.hip): linear1 + ReLU + dropout + linear2 in one kernel, and its
- * dgrad chain (torch TransformerEncoderLayer._ff_block behind model.py:1210).  The kernels read the two weights from a
- * copy packed in MFMA fragment order; these hooks pack w1 [F x E] / w2 [E x F] into pack_ws (ganffn_ffn_pack_floats(F)
- * floats, 16-byte aligned) first, which is what ganffn_encoder_fwd / _bwd do once per pass for all layers.  The output is
- * returned as partial slabs slabs[s][T x E], s < nslab, to be summed by the caller (the LayerNorm kernels do it on the
- * fly).  Test hooks: on success these two return -(1000 + nslab). */
-int64_t ganffn_ffn_pack_floats(int F);
-int ganffn_ffn_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
-                         float* h /* [T x F] or NULL */, float* slabs /* [16][T x E] */, float* pack_ws, int T, int E,
-                         int F, float p, uint32_t site, const uint64_t* rng, uint64_t rng_offset_add, int train,
-                         void* stream);
-int ganffn_ffn_fused_bwd(const float* dy, const float* w1, const float* w2, const float* h, float* dh,
-                         float* slabs, float* pack_ws, int T, int E, int F, float mscale, void* stream);
-/* The same block (d_model = 100, F = 2048 only) as ffn3.hip's forward kernel, straight from the row-major weights: 64 tokens
- * x one hidden chunk per workgroup, weight tiles shared through LDS, the hidden tile passed from linear1 to linear2 in
- * registers.  h [T x 2048] (or NULL when no backward follows) receives dropout(relu(x W1^T + b1)); the output is returned
- * as *n_slabs (<= max_slabs <= 16) partial slabs slabs[s][slab_stride], b2 added in slab 0. */
-int ganffn_ffn3_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h,
-                    float* slabs, int64_t slab_stride, int T, float p, uint32_t site, const uint64_t* rng,
-                    uint64_t rng_offset_add, int train, int max_slabs, int* n_slabs, void* stream);
 /* n (<= 40) independent problems C_i[M_i x N_i] += At_i[K_i x M_i]^T B_i[K_i x N_i] (+ column sums) in ONE launch: the
  * deferred weight-gradient GEMMs of all encoder layers of a backward pass (dense leading dimensions).  workspace
  * (ganffn_gemm_tn_grouped_workspace_floats() floats, or NULL): lets a group with few output tiles split the token range
@@ -404,7 +384,8 @@ int ganffn_ffn_k100_hook(int which, const float* a, const float* w, const float*
  * a mixture.  Bits 8..23 are lab knobs (forced tile / chunk counts), the others select an older or alternative launch
  * sequence that stays parity-tested. */
 /*
- *   bit 0: run the d_model-100 feed-forward block as the fused kernel of ffn.hip instead of two GEMMs (measured slower);
+ *   bits 0, 7, 22: reserved, ignored (until round 5 they selected the fused feed-forward kernels ffn.hip / ffn3.hip: measured
+ *          slower in the step three times over and removed from the product; the kernels are in the history);
  *   bit 1: run the token-local chains around the LayerNorms of a d_model-100 layer (out-proj + LN1, LN2 + next in-proj and
  *          their backward mirrors, csrc/rowchain.hip) as separate GEMM + LayerNorm launches;
  *   bit 2: run the [T x 2048] x [2048 x 100] products on the generic 64 x 64 tiles instead of csrc/gemm_n100.hip;
@@ -415,8 +396,6 @@ int ganffn_ffn_k100_hook(int which, const float* a, const float* w, const float*
  *   bit 5: run the discriminator head as separate GELU / GEMM / tail launches instead of csrc/disc_head.hip;
  *   bit 6: run the head of a d_model-100 encoder stack (positional encoding + dropout, layer 0's in-proj) as two launches
  *          instead of one (csrc/rowchain.hip);
- *   bit 7: run the FORWARD feed-forward block of a d_model-100 layer as csrc/ffn3.hip's single kernel (ganffn_ffn3_fwd) instead
- *          of two GEMMs, at up to 4096 tokens; with bit 22 also above (measured: faster alone, slower in the step);
  *   bits 8..15: forced K-chunk count of csrc/gemm_n100.hip (0 = choose; clamped to the caller's slab capacity);
  *   bits 16..19: forced token-chunk count of csrc/gemm_tn100.hip (0 = choose; clamped to 8 and to the workspace);
  *   bits 20..21: csrc/gemm_n100.hip with 4 (value 1) or 8 (value 2) waves per workgroup (0 = choose);

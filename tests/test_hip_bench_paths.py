@@ -124,3 +124,24 @@ def test_launcher_second_rung_runs_on_one_stream_and_one_communicator():
         assert r.returncode == 0, r.stderr[-3000:]
         c = _last_json(r.stdout)["config"]
         assert c["dp_mode"] == dp and c["communicators"] == comms and c["streams"] == streams and c["rccl_ranks"] == 1, c
+
+
+def test_two_rank_rehearsal_through_the_launcher():
+    """every world > 1 line of bench.py end to end on a one-GPU box: `python bench.py --gpus 2` (no WORLD_SIZE) spawns two
+    ranks that SHARE the GPU and reduce over gloo (GANFFN_DIST_BACKEND=gloo; RCCL refuses two ranks on one device) — the
+    launcher, the rank-0 relay, the slab broadcast, the pre-roll's collective stop flag, the in-line all-reduce on three
+    streams, MAX-over-ranks timing and the per-rank spread.  A rehearsal of the plumbing, not a measurement (the line says
+    dist_backend = gloo)."""
+    env = dict(os.environ, GANFFN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "GANFFN_DP_MODE", "GANFFN_FORCE_DIST"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--seq", "20", "--no-cpu-baseline", "--step-only"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["launcher"]["spawned_ranks"] == 2 and c["launcher"]["rung"] == "inline-3streams"
+    assert c["rccl_ranks"] == 2 and c["dist_backend"] == "gloo" and c["dp_mode"] == "inline" and c["streams"] == 3
+    lo, hi = c["ms_per_step_min_max_over_ranks"]
+    assert 0 < lo <= hi <= d["ms_per_step"] + 1e-3          # the line's time is the MAX over the ranks
+    assert "[rank 1]" in r.stderr                             # the second rank really ran (its stderr is relayed)

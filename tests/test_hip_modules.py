@@ -192,28 +192,22 @@ def test_cpu_tensor_fails_loudly():
         m(torch.zeros(4, 2, 100))
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 6, 8, 32, 46, 64, 128, 128 | 1 << 22, 1 << 23, 1 << 25, 1 << 24 | 1 << 25])
-def test_fused_ffn_modes_agree_with_fixture(mode):
-    """the encoder's FFN runs as two GEMMs (bit 0 clear, the default) or as the fused kernel (bit 0 set); the token-local
-    chains around the LayerNorms of a d_model-100 layer run as single kernels (rowchain.hip; bit 1 clear, the default) or
-    as separate GEMM + LayerNorm launches (bit 1 set); the [T x 2048] x [2048 x 100] products run on the 112-wide
-    16x16x4 kernel (gemm_n100.hip; bit 2 clear, the default) or on the generic 64 x 64 tiles (bit 2 set); likewise the
-    grouped weight gradients (gemm_tn100.hip, bit 3) and the one-kernel discriminator head (disc_head.hip, bit 5): the
-    combinations tested — including everything on the older launch sequences (46) — all match the reference; so does the
-    forward feed-forward block as ffn3.hip's single kernel (bit 7; with bit 22 also above 4096 tokens — 128 tokens per
-    workgroup), and so do the 100-wide products with their last four rows on a padded seventh MFMA tile (bit 23) instead
-    of v_mfma_f32_4x4x1; the linear2 dgrad taking its ReLU / dropout pattern from the saved activation (bit 25) instead of the
-    1-bit copy beside it, and the 512-wide out-proj unsplit (bit 24; these two also on the 512-wide generator)"""
+@pytest.mark.parametrize("mode", [0, 2, 4, 6, 8, 32, 46, 64, 1 << 23, 1 << 25, 1 << 24 | 1 << 25, 1 << 28])
+def test_older_launch_sequences_agree_with_fixture(mode):
+    """ganffn_debug_set_ffn_mode keeps the launch sequences that newer kernels replaced selectable, and every one of them
+    stays pinned to the reference fixture and to the oracle in train mode: the token-local chains around the LayerNorms of a
+    d_model-100 layer as separate GEMM + LayerNorm launches (bit 1) instead of rowchain.hip; the [T x 2048] x [2048 x 100]
+    products on the generic 64 x 64 tiles (bit 2) instead of gemm_n100.hip; likewise the grouped weight gradients (bit 3,
+    gemm_tn100.hip), the discriminator head (bit 5, disc_head.hip) and the head of the stack (bit 6); everything at once (46);
+    the 100-wide products with their last four rows on a padded seventh MFMA tile (bit 23) instead of v_mfma_f32_4x4x1; the
+    linear2 dgrad taking its ReLU / dropout pattern from the saved activation (bit 25) instead of the 1-bit copy beside it, and
+    the 512-wide out-proj unsplit (bit 24; these two also on the 512-wide generator); weight gradients always through the
+    reduce launch (bit 28).  (Bits 0, 7 and 22 selected the fused feed-forward kernels until round 5; they are reserved.)"""
     from gan_ffn_amd import _lib
     lib = _lib.load()
     lib.ganffn_debug_set_ffn_mode(mode)
     try:
-        # ffn3.hip adds linear1's k-steps in another order than gemm_wres: OTHER hidden units land on the far side of the ReLU
-        # kink than in the default path (all of them within rounding of zero: the kink audit), and at 330 tokens one of them
-        # moves a dx row by 5 % and layer 3's out-proj gradient by 1 % of their scales against the reference's own fp32 run.
-        # For these modes the output is held to the fixture and the gradients to the fp64 oracle on the HIP ReLU pattern
-        # (strict), not to the fixture's kink-tolerant bounds
-        test_module_matches_reference_fixture(("TextGenerator", 100), (110, 3), fixture_grads=not (mode & 128))
+        test_module_matches_reference_fixture(("TextGenerator", 100), (110, 3))
         test_train_mode_matches_oracle_with_same_masks("AcousticDiscriminator", 100, 94, 4)
         if mode & (3 << 24):
             test_module_matches_reference_fixture(("VisualGenerator", 512), (110, 3))

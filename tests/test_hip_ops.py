@@ -357,93 +357,6 @@ def _n100_case(lib, T, K, kmajor, cap):
     assert torch.equal(slabs2[:n.value], slabs[:n.value])
 
 
-@pytest.mark.parametrize("T", [3008, 6016, 14, 130, 33, 4097])
-@pytest.mark.parametrize("p", [0.0, 0.1])
-def test_ffn_fused_fwd_bwd(lib, T, p):
-    """fused linear1+ReLU+dropout+linear2 (and its dgrad chain) vs fp64 torch with the same Philox mask"""
-    E, F = 100, 2048
-    g = torch.Generator().manual_seed(T + int(p * 10))
-    x = torch.randn(T, E, generator=g)
-    w1, b1 = torch.randn(F, E, generator=g) / 10, torch.randn(F, generator=g) / 10
-    w2, b2 = torch.randn(E, F, generator=g) / 45, torch.randn(E, generator=g) / 10
-    dy = torch.randn(T, E, generator=g)
-    seed, off, add, site = 31337, 2, 9, 22
-    keep = torch.from_numpy(philox.keep_mask(T, F, p, site, seed, off + add)).double() / (1 - p)
-    x64 = x.double().requires_grad_(True)
-    h_ref = torch.relu(x64 @ w1.double().T + b1.double()) * keep
-    y_ref = h_ref @ w2.double().T + b2.double()
-    rng = torch.tensor([seed, off], dtype=torch.int64, device="cuda")
-    xd, w1d, b1d, w2d, b2d, dyd = dev(x), dev(w1), dev(b1), dev(w2), dev(b2), dev(dy)
-    h = torch.full((T, F), float("nan"), device="cuda")
-    slabs = torch.full((16, T, E), float("nan"), device="cuda")
-    pack = torch.full((int(lib.load().ganffn_ffn_pack_floats(F)),), float("nan"), device="cuda")
-    rc = lib.load().ganffn_ffn_fused_fwd(ptr(xd), ptr(w1d), ptr(b1d), ptr(w2d), ptr(b2d), ptr(h), ptr(slabs), ptr(pack), T, E, F,
-                                         C.c_float(p), C.c_uint32(site), ptr(rng), C.c_uint64(add), 1, stream())
-    assert rc <= -1001, (rc, lib.load().ganffn_last_error())
-    ns = -rc - 1000
-    y = slabs[:ns].sum(0)
-    assert rel_err(h, h_ref.detach()) < 5e-6
-    assert rel_err(y, y_ref.detach()) < 2e-5
-    # backward dgrad chain
-    # the backward's contract is "mask by the SAVED hidden activations": take the pattern from the forward's own output
-    # (one of the ~10^7 hidden units may sit within fp32 rounding of zero, where fp32 and fp64 disagree about relu)
-    pattern = (h > 0).double().cpu()
-    assert float((pattern != (h_ref.detach() > 0).double()).double().mean()) < 1e-6
-    dh_ref = (dy.double() @ w2.double()) * pattern / (1 - p)
-    dx_ref = dh_ref @ w1.double()
-    dh = torch.full((T, F), float("nan"), device="cuda")
-    slabs.fill_(float("nan"))
-    rc = lib.load().ganffn_ffn_fused_bwd(ptr(dyd), ptr(w1d), ptr(w2d), ptr(h), ptr(dh), ptr(slabs), ptr(pack), T, E, F,
-                                         C.c_float(1.0 / (1.0 - p)), stream())
-    assert rc <= -1001, (rc, lib.load().ganffn_last_error())
-    dx = slabs[:-rc - 1000].sum(0)
-    assert rel_err(dh, dh_ref) < 2e-5
-    assert rel_err(dx, dx_ref) < 3e-5
-
-
-@pytest.mark.parametrize("T", [3008, 6016, 14, 130, 33, 4097, 64, 1])
-@pytest.mark.parametrize("p,save", [(0.0, True), (0.1, True), (0.1, False)])
-def test_ffn3_fwd(lib, T, p, save):
-    """ffn3.hip: linear1 + ReLU + dropout + linear2 of the d_model-100 layer in one kernel (the hidden tile never leaves
-    the registers between the two products) vs fp64 torch with the same Philox mask; ragged token counts; the hidden
-    tensor is written only when asked for; nothing is written beyond the slabs reported; bit-reproducible"""
-    E, F = 100, 2048
-    g = torch.Generator().manual_seed(T + int(p * 10))
-    x = torch.randn(T, E, generator=g)
-    w1, b1 = torch.randn(F, E, generator=g) / 10, torch.randn(F, generator=g) / 10
-    w2, b2 = torch.randn(E, F, generator=g) / 45, torch.randn(E, generator=g) / 10
-    seed, off, add, site = 31337, 2, 9, 22
-    keep = torch.from_numpy(philox.keep_mask(T, F, p, site, seed, off + add)).double() / (1 - p)
-    h_ref = torch.relu(x.double() @ w1.double().T + b1.double()) * keep
-    y_ref = h_ref @ w2.double().T + b2.double()
-    rng = torch.tensor([seed, off], dtype=torch.int64, device="cuda")
-    xd, w1d, b1d, w2d, b2d = dev(x), dev(w1), dev(b1), dev(w2), dev(b2)
-    h = torch.full((T, F), float("nan"), device="cuda")
-    cap = 16
-    slabs = torch.full((cap, T, E), float("nan"), device="cuda")
-    n = C.c_int(0)
-    args = lambda hh, sl: (ptr(xd), ptr(w1d), ptr(b1d), ptr(w2d), ptr(b2d), ptr(hh) if hh is not None else None, ptr(sl),
-                           C.c_int64(T * E), T, C.c_float(p), C.c_uint32(site), ptr(rng), C.c_uint64(add), 1, cap, C.byref(n), stream())
-    lib.call("ganffn_ffn3_fwd", *args(h if save else None, slabs))
-    assert 1 <= n.value <= 8
-    y = slabs[:n.value].sum(0)
-    assert bool(torch.isfinite(y).all())
-    assert rel_err(y, y_ref) < 2e-5
-    assert bool(torch.isnan(slabs[n.value:]).all())
-    if save:
-        assert rel_err(h, h_ref) < 5e-6
-        # the dropout pattern is the contract's, element for element
-        assert float((((h != 0).cpu() != (h_ref != 0))).double().mean()) < 1e-6
-    else:
-        assert bool(torch.isnan(h).all())
-    slabs2 = torch.full_like(slabs, float("nan"))
-    h2 = torch.full_like(h, float("nan"))
-    lib.call("ganffn_ffn3_fwd", *args(h2 if save else None, slabs2))
-    assert torch.equal(slabs2[:n.value], slabs[:n.value])
-    if save:
-        assert torch.equal(h2, h)
-
-
 @pytest.mark.parametrize("mode_bits", [0, 8, 2 << 16, 5 << 16, 8 << 16, 9 << 16, 1 << 23, 1 << 23 | 3 << 16])
 @pytest.mark.parametrize("K", [6016, 3008, 333, 40])
 def test_gemm_tn_grouped_d100_group(lib, K, mode_bits):
