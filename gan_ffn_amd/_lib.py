@@ -16,6 +16,11 @@ class EncCfg(C.Structure):
                 ("train", C.c_int32)]
 
 
+class LstmCfg(C.Structure):
+    """ganffn_lstm_cfg"""
+    _fields_ = [("S", C.c_int32), ("B", C.c_int32), ("In", C.c_int32), ("H", C.c_int32)]
+
+
 class HeadCfg(C.Structure):
     _fields_ = [("T", C.c_int32), ("E", C.c_int32), ("D1", C.c_int32), ("D2", C.c_int32), ("kind", C.c_int32),
                 ("p", C.c_float), ("train", C.c_int32)]
@@ -64,6 +69,10 @@ SIGNATURES = {
     "ganffn_bce2_fwd": (_I, [_P, _F, _F, _I, _I, _I, _F, _P, _I, _P]),
     "ganffn_bce2_bwd": (_I, [_P, _F, _F, _I, _I, _I, _F, _P, _P]),
     "ganffn_adam_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P]),
+    "ganffn_lstm_saved_floats": (_L, [C.POINTER(LstmCfg)]),
+    "ganffn_lstm_workspace_floats": (_L, [C.POINTER(LstmCfg)]),
+    "ganffn_lstm_layer_fwd": (_I, [C.POINTER(LstmCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ganffn_lstm_layer_bwd": (_I, [C.POINTER(LstmCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ganffn_adam_step_parts": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P, _L, _I, _L, _L, _L, _P]),
     "ganffn_encoder_bwd_parts_supported": (_I, [_PE]),
     "ganffn_encoder_bwd_parts_covered": (_L, [_I, _I]),

@@ -253,6 +253,23 @@ long gemm_tn_part_floats(int M, int N, int K);
 int launch_gemm_tn_acc(const float* At, int lda, const float* Bm, int ldb, float* C, int ldc, float* colsum,
                        int M, int N, int K, hipStream_t st, float* part_ws = nullptr, long part_floats = 0);
 
+// skinny products (dialogue_rnn.hip): M <= 32 rows of A (dialogues) against a weight matrix, up to 8 problems per launch — one
+// link of a recurrence's launch chain (DialogueRNN cells, lstm.hip's recurrent products)
+struct SkinnyProb {
+    const float* A; int lda;      // [M x K]
+    const float* W; int ldw;      // NT: [N x K];  NN: [K x N]
+    const float* Cin; int ldcin;  // optional addend [M x N]
+    const float* Cin2;            // optional second addend [M x N], leading dimension ldc (may be C itself: in-place +=)
+    const float* bias;            // optional [N]
+    float* C; int ldc;            // [M x N]
+    int M, N, K;
+};
+struct SkinnyGroup {
+    SkinnyProb p[8];
+};
+// nn = false: C = A W^T (+ Cin + Cin2 + bias), W [N x K];  nn = true: C = A W (+ Cin + Cin2), W [K x N]
+int launch_skinny(const SkinnyGroup& grp, int nprob, bool nn, hipStream_t st);
+
 // grouped wgrad: n independent TN problems in one launch
 struct TnDesc {
     const float* At; int lda;

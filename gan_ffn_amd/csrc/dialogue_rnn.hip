@@ -40,18 +40,7 @@ enum : uint32_t { SITE_DRNN_G = 8, SITE_DRNN_P = 9, SITE_DRNN_E = 10 };   // + 4
 // ------------------------------------------------------------------------------------------
 // skinny products: M <= 32 rows of A (dialogues) against a weight matrix
 // ------------------------------------------------------------------------------------------
-struct SkinnyProb {
-    const float* A; int lda;      // [M x K]
-    const float* W; int ldw;      // NT: [N x K];  NN: [K x N]
-    const float* Cin; int ldcin;  // optional addend [M x N]
-    const float* Cin2;            // optional second addend [M x N], leading dimension ldc (may be C itself: in-place +=)
-    const float* bias;            // optional [N]
-    float* C; int ldc;            // [M x N]
-    int M, N, K;
-};
-struct SkinnyGroup {
-    SkinnyProb p[8];      // a step's products of both cells (2 each) in both directions
-};
+// (SkinnyProb / SkinnyGroup: common.h — lstm.hip runs its recurrent products through the same kernels)
 
 // NT: C[b][n] = sum_k A[b][k] W[n][k] (+ Cin[b][n] + bias[n]).  Workgroup = 16 weight rows x 32 dialogues, NW waves split K
 // (4 for the K = 500 products of the forward step, 12 for the K = 1500 ones of the backward step: 125 -> 128 k each).
@@ -223,7 +212,7 @@ __global__ __launch_bounds__(512) void skinny_nn_kernel(SkinnyGroup grp) {
     }
 }
 
-static int launch_skinny(const SkinnyGroup& grp, int nprob, bool nn, hipStream_t st) {
+int launch_skinny(const SkinnyGroup& grp, int nprob, bool nn, hipStream_t st) {
     int maxN = 0, maxK = 0;
     for (int i = 0; i < nprob; ++i) {
         const SkinnyProb& q = grp.p[i];

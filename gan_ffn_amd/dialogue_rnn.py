@@ -250,8 +250,10 @@ class MELDLSTMModel(nn.Module):
     """MELD classifier (/root/reference/model.py:520-562, train_MELD.py:147-151): 4-layer
     bidirectional LSTM over the utterance features, masked general2 attention of every step over the sequence,
     hardswish(emotions + hardswish(attended)), class log-probabilities.  `linear` and `dropout` serve the att2=False
-    branch / exist on the reference object.  The LSTM is the device library's (MIOpen on the MI355X); the attention is
-    the batched general2 kernel used by BiModel."""
+    branch / exist on the reference object.  On the GPU the LSTM recurrence runs on the build's own kernels (csrc/lstm.hip
+    through ops.lstm_forward: hoisted input products, one skinny MFMA product + one gate launch per step for both directions,
+    deferred weight gradients) with `self.lstm`'s parameters — round 5; until then MIOpen's; the attention is the batched
+    general2 kernel used by BiModel."""
 
     def __init__(self, D_m, D_e, D_h, n_classes=7, dropout=0.5):
         super().__init__()
@@ -263,7 +265,12 @@ class MELDLSTMModel(nn.Module):
         self.smax_fc = nn.Linear(D_h, n_classes)
 
     def forward(self, U, qmask, umask, visuf=None, att2=True):
-        emotions, _ = self.lstm(U)
+        if U.is_cuda:
+            # the recurrence on the HIP kernels (csrc/lstm.hip), with self.lstm's own parameters (same state_dict keys)
+            from . import ops
+            emotions = ops.lstm_forward(U, self.lstm, self.training)
+        else:
+            emotions, _ = self.lstm(U)      # CPU tensors: stock torch (the fixtures' CPU check; the product path is the GPU one)
         alpha, alpha_f, alpha_b = [], [], []
         if att2:
             att, a = self.matchatt.general2_all_queries(emotions, umask)

@@ -577,3 +577,81 @@ def dialogue_rnn_run(cells, Us, qmasks, training):
         al = torch.cat(a_parts[z], 0) if len(a_parts[z]) > 1 else a_parts[z][0]
         res.append((e, [al[:, t, :t] for t in range(1, S)]))
     return res
+
+
+# ----------------------------------------------------------------------------------------------
+# N4: bidirectional LSTM (include/ganffn.h "N4"; csrc/lstm.hip) — the recurrence of nn.LSTM inside MELDLSTMModel
+# (/root/reference/model.py:520-562, train_MELD.py:147-151)
+# ----------------------------------------------------------------------------------------------
+SITE_LSTM = 64          # + layer: the dropout nn.LSTM(dropout=p) applies to the output of every layer but the last
+
+
+class LstmLayerFn(torch.autograd.Function):
+    """one bidirectional LSTM layer: x (S, B, In) -> (S, B, 2H) = [h forward | h reverse]; torch's parameters
+    weight_ih [4H x In], weight_hh [4H x H], bias_ih, bias_hh [4H] per direction (gate order i, f, g, o).  The kernels take at
+    most 32 dialogues per call: bigger batches run in chunks (dialogues are independent)."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        _need_gpu(x, *params)
+        x = _f32c(x)
+        p = [_f32c(t.detach()) for t in params]          # w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1
+        S, B, In = x.shape
+        H = p[1].shape[1]
+        out = torch.empty(S, B, 2 * H, device=x.device, dtype=torch.float32)
+        chunks = []
+        for b0 in range(0, B, 32):
+            b1 = min(B, b0 + 32)
+            cfg = _lib.LstmCfg(S, b1 - b0, In, H)
+            n_saved = int(_lib.load().ganffn_lstm_saved_floats(C.byref(cfg)))
+            n_ws = int(_lib.load().ganffn_lstm_workspace_floats(C.byref(cfg)))
+            xc = x if (b0, b1) == (0, B) else x[:, b0:b1].contiguous()
+            oc = out if (b0, b1) == (0, B) else torch.empty(S, b1 - b0, 2 * H, device=x.device, dtype=torch.float32)
+            saved = torch.empty(n_saved, device=x.device, dtype=torch.float32)
+            ws = torch.empty(n_ws, device=x.device, dtype=torch.float32)
+            _lib.call("ganffn_lstm_layer_fwd", C.byref(cfg), _ptr(xc), _ptr_array([p[0], p[4]]), _ptr_array([p[1], p[5]]),
+                      _ptr_array([p[2], p[6]]), _ptr_array([p[3], p[7]]), _ptr(oc), _ptr(saved), _ptr(ws), _stream())
+            if oc is not out:
+                out[:, b0:b1] = oc
+            chunks.append((b0, b1, xc, oc, saved))
+        ctx.chunks, ctx.p, ctx.shape = chunks, p, (S, B, In, H)
+        ctx.need_x = x.requires_grad if hasattr(x, "requires_grad") else False
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        S, B, In, H = ctx.shape
+        p = ctx.p
+        d_out = _f32c(d_out)
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty(S, B, In, device=d_out.device, dtype=torch.float32) if need_dx else None
+        grads = [torch.zeros_like(t) if ctx.needs_input_grad[1 + i] else None for i, t in enumerate(p)]
+        for (b0, b1, xc, oc, saved) in ctx.chunks:
+            cfg = _lib.LstmCfg(S, b1 - b0, In, H)
+            n_ws = int(_lib.load().ganffn_lstm_workspace_floats(C.byref(cfg)))
+            ws = torch.empty(n_ws, device=d_out.device, dtype=torch.float32)
+            dc = d_out if (b0, b1) == (0, B) else d_out[:, b0:b1].contiguous()
+            dxc = None
+            if need_dx:
+                dxc = dx if (b0, b1) == (0, B) else torch.empty(S, b1 - b0, In, device=d_out.device, dtype=torch.float32)
+            _lib.call("ganffn_lstm_layer_bwd", C.byref(cfg), _ptr(dc), _ptr(xc), _ptr(oc), _ptr_array([p[0], p[4]]), _ptr_array([p[1], p[5]]),
+                      _ptr(dxc), _ptr_array([grads[0], grads[4]]), _ptr_array([grads[1], grads[5]]), _ptr_array([grads[2], grads[6]]),
+                      _ptr_array([grads[3], grads[7]]), _ptr(saved), _ptr(ws), _stream())
+            if need_dx and dxc is not dx:
+                dx[:, b0:b1] = dxc
+        return (dx, *grads)
+
+
+def lstm_forward(x, lstm, training):
+    """nn.LSTM(..., bidirectional=True, dropout=p).forward(x)[0] for a padded (S, B, In) CUDA batch, on the HIP kernels, with the
+    module's own parameters (state_dict keys unchanged: lstm.weight_ih_l{k}[_reverse], ...).  Inter-layer dropout (every layer but
+    the last, train mode only) follows the Philox contract (site SITE_LSTM + layer)."""
+    assert lstm.bidirectional and not lstm.batch_first and lstm.proj_size == 0 and lstm.bias, "lstm_forward: the MELDLSTMModel configuration only"
+    h = x
+    for l in range(lstm.num_layers):
+        names = ["weight_ih_l%d", "weight_hh_l%d", "bias_ih_l%d", "bias_hh_l%d"]
+        params = [getattr(lstm, n % l) for n in names] + [getattr(lstm, (n % l) + "_reverse") for n in names]
+        h = LstmLayerFn.apply(h, *params)
+        if l + 1 < lstm.num_layers and lstm.dropout > 0.0:
+            h = DropoutFn.apply(h, float(lstm.dropout), training, SITE_LSTM + l)
+    return h

@@ -368,6 +368,28 @@ int ganffn_gemm_hook(int mode, int epi, const float* A, const float* W, const fl
                      int64_t slab_stride, int M, int N, int K, float p, uint32_t site, const uint64_t* rng,
                      uint64_t rng_offset_add, int train, int max_slabs, int* n_slabs, void* stream);
 
+/* ---- N4: one bidirectional LSTM layer (csrc/lstm.hip) -----------------------------------------------------------------
+ * Replaces the recurrence of `nn.LSTM(input_size, hidden_size, num_layers = 4, bidirectional = True, dropout = p)` inside
+ * MELDLSTMModel (/root/reference/model.py:520-562; built at /root/reference/train_MELD.py:147-151 with D_m = 600, D_e = 300),
+ * one layer per call (the caller applies the inter-layer dropout and chains four calls).  x [S x B x In] padded, no mask (the
+ * reference hands nn.LSTM the padded batch: model.py:546); out [S x B x 2H] = [h forward | h reverse]; torch's gate order
+ * i, f, g, o: w_ih[d] [4H x In], w_hh[d] [4H x H], b_ih[d], b_hh[d] [4H], d = 0 forward, 1 reverse.  B <= 32 per call.
+ * saved (ganffn_lstm_saved_floats): activated gates and cell states of every step, read by the backward;
+ * workspace (ganffn_lstm_workspace_floats) is scratch.  The backward ACCUMULATES (+=) into gw_* / gb_* (any of them, or an
+ * array, may be NULL) and writes dx [S x B x In] (NULL: not wanted).  Deterministic: no atomics. */
+typedef struct ganffn_lstm_cfg {
+    int32_t S, B, In, H;
+} ganffn_lstm_cfg;
+int64_t ganffn_lstm_saved_floats(const ganffn_lstm_cfg* cfg);
+int64_t ganffn_lstm_workspace_floats(const ganffn_lstm_cfg* cfg);
+int ganffn_lstm_layer_fwd(const ganffn_lstm_cfg* cfg, const float* x, const float* const* w_ih, const float* const* w_hh,
+                          const float* const* b_ih, const float* const* b_hh, float* out, float* saved, float* workspace,
+                          void* stream);
+int ganffn_lstm_layer_bwd(const ganffn_lstm_cfg* cfg, const float* d_out, const float* x, const float* out,
+                          const float* const* w_ih, const float* const* w_hh, float* dx, float* const* gw_ih,
+                          float* const* gw_hh, float* const* gb_ih, float* const* gb_hh, const float* saved,
+                          float* workspace, void* stream);
+
 /* Measurement hook: the K = 100 -> 2048 products of the d_model-100 feed-forward block (csrc/gemm.hip gemm_wres_kernel) with the
  * arguments ganffn_encoder_fwd / _bwd give them (linear1 / linear2 of nn.TransformerEncoderLayer, call sites model.py:1210,1307).
  * which 0: out[T x 2048] = dropout_p(relu(a[T x 100] w[2048 x 100]^T + bias)); hmask != NULL: also the 1-bit [out > 0] pattern

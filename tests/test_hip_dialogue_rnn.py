@@ -133,7 +133,10 @@ def test_hip_recurrence_at_configuration_5_size_matches_reference_fixture():
 
 
 def test_meld_lstm_model_on_gpu_matches_reference_fixture():
-    """N4 on the device: MIOpen LSTM + the HIP general2 kernel (D = 600) against the reference's fixture"""
+    """N4 on the device: the build's own LSTM recurrence (csrc/lstm.hip, since round 5; MIOpen's until then) + the HIP general2
+    kernel (D = 600) against the REFERENCE's MELDLSTMModel fixture (/root/reference/model.py:520-562): log-probabilities,
+    attention weights, dU and the sampled LSTM / attention / head gradients — in eval mode (as the fixture was made) and in train
+    mode with dropout 0 (the same arithmetic through the train-mode code path)"""
     import test_dialogue_rnn_cpu as T
-    # MIOpen's RNN backward exists only in training mode: dropout 0 + train() is the same arithmetic as eval()
+    T.check_meld(T._meld_model().cuda().eval(), "cuda")
     T.check_meld(T._meld_model(dropout=0.0).cuda().train(), "cuda")
