@@ -708,6 +708,136 @@ def launch(args, argv, cmd=None):
     return 1
 
 
+def supervise(args, argv, cmd=None, coord_dir=None):
+    """One rank of an EXTERNAL launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: how the
+    driver starts N > 1) — the same watchdog and fallback ladder as launch(), per rank.  The process torchrun started makes NO
+    GPU call: it is a supervisor that runs the real rank as a child process, so that a hung collective can be answered by
+    ending that child and starting a FRESH one on the next rung.  The N supervisors of a launch (same node: nnodes = 1) agree
+    through files in one directory (named after torchrun's agent pid, which all of them share as their parent, and the master
+    port): rank 0 publishes a fresh rendezvous port per rung (the agent's own store on MASTER_PORT cannot host a second
+    rendezvous), any supervisor whose child dies or goes silent marks the rung failed, every supervisor that sees the mark ends
+    its child and moves on; rank 0's JSON line ends the launch."""
+    import subprocess
+    import threading
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    silence = float(os.environ.get("GANFFN_LAUNCH_SILENCE_S", "300"))
+    total_cap = float(os.environ.get("GANFFN_LAUNCH_RUNG_S", "1500"))
+    D = coord_dir or os.path.join("/tmp", "ganffn_bench_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+    os.makedirs(D, exist_ok=True)
+    ladder = LADDER
+    if os.environ.get("GANFFN_LAUNCH_RUNGS"):
+        ladder = [LADDER[int(i)] for i in os.environ["GANFFN_LAUNCH_RUNGS"].split(",")]
+    if os.environ.get("GANFFN_DP_MODE"):
+        ladder = [("as-asked", {}, None)]
+    tried = []
+
+    def wait_file(path, timeout):
+        t_end = time.time() + timeout
+        while time.time() < t_end:
+            if os.path.exists(path):
+                return True
+            time.sleep(0.1)
+        return False
+
+    for k, (name, rung_env, streams) in enumerate(ladder):
+        pf = os.path.join(D, "rung%d.port" % k)
+        if rank == 0:
+            with open(pf + ".tmp", "w") as f:
+                f.write(str(_free_port()))
+            os.replace(pf + ".tmp", pf)
+        if not wait_file(pf, 120):
+            print("[bench supervisor %d] rung %r: no port from rank 0" % (rank, name), file=sys.stderr, flush=True)
+            return 1
+        port = int(open(pf).read())
+        e = dict(os.environ)
+        e.update(rung_env)
+        e.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GANFFN_BENCH_CHILD="1", GANFFN_BENCH_RUNG=name,
+                 GANFFN_BENCH_FALLBACK_FROM=",".join(tried), GANFFN_BENCH_SUPERVISED="1",
+                 HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        for v in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
+            e.pop(v, None)          # the child rendezvouses through its own store on the fresh port, not through the agent's
+        rung_cmd = (cmd if cmd is not None else [sys.executable, os.path.abspath(__file__)]) + _child_argv(argv, streams)
+        if rank == 0:
+            print("[bench supervisor] rung %r: %d ranks, port %d%s" % (name, world, port, ", after " + ",".join(tried) if tried else ""),
+                  file=sys.stderr, flush=True)
+        proc = subprocess.Popen(rung_cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True, cwd=ROOT)
+        last, lines = [time.time()], []
+
+        def pump(stream, keep):
+            for line in stream:
+                last[0] = time.time()
+                if keep is not None and line.startswith("{"):
+                    keep.append(line.strip())
+                else:
+                    sys.stderr.write(line if rank == 0 else "[rank %d] %s" % (rank, line))
+                    sys.stderr.flush()
+        ths = [threading.Thread(target=pump, args=(proc.stdout, lines if rank == 0 else None), daemon=True),
+               threading.Thread(target=pump, args=(proc.stderr, None), daemon=True)]
+        for t_ in ths:
+            t_.start()
+        fail, done = os.path.join(D, "rung%d.fail" % k), os.path.join(D, "rung%d.done" % k)
+        t0, why, outcome, t_exit = time.time(), None, None, None
+        while outcome is None:
+            rc = proc.poll()
+            if rc == 0 and t_exit is None:
+                t_exit = time.time()
+            if os.path.exists(done):
+                outcome = "done"
+            elif os.path.exists(fail):
+                outcome = "failed"
+            elif rc is not None and rc != 0:
+                why, outcome = "rank %d exited with %d" % (rank, rc), "failed"
+            elif rc == 0 and rank == 0:
+                for t_ in ths:
+                    t_.join(timeout=5)
+                if lines:
+                    outcome = "done"
+                else:
+                    why, outcome = "rank 0 printed no JSON line", "failed"
+            elif rc == 0 and rank != 0 and time.time() - t_exit > 120.0:
+                outcome = "done"              # this rank's worker finished cleanly; rank 0 will have had its line
+            elif rc is None and time.time() - last[0] > silence:
+                why, outcome = "rank %d silent for %.0f s" % (rank, silence), "failed"
+            elif time.time() - t0 > total_cap:
+                why, outcome = "rung exceeded %.0f s" % total_cap, "failed"
+            else:
+                time.sleep(0.25)
+        if outcome == "failed":
+            if why is not None and not os.path.exists(fail):
+                try:
+                    with open(fail + ".%d" % rank, "w") as f:
+                        f.write(why)
+                    os.replace(fail + ".%d" % rank, fail)
+                except OSError:
+                    pass
+            _end_children([proc])
+            if rank == 0:
+                print("[bench supervisor] rung %r failed: %s" % (name, why or open(fail).read()), file=sys.stderr, flush=True)
+            tried.append(name)
+            continue
+        # done
+        if rank == 0:
+            open(done, "w").write("ok")
+            d = None
+            try:
+                d = json.loads(lines[-1])
+                d.setdefault("config", {})
+                d["config"]["launcher"] = {"spawned_ranks": world, "rung": name, "fallback_from": tried or None,
+                                           "how": "each rank of the external launcher supervises its own worker process (watchdog + ladder)"}
+                print(json.dumps(d), flush=True)
+            except Exception:
+                print(lines[-1], flush=True)
+        else:
+            t_end = time.time() + 30.0            # rank 0 has its line: a straggler in teardown is given 30 s, then ended
+            while proc.poll() is None and time.time() < t_end:
+                time.sleep(0.2)
+        _end_children([proc], grace=3.0)
+        return 0
+    if rank == 0:
+        print("[bench supervisor] every rung failed: %s" % tried, file=sys.stderr, flush=True)
+    return 1
+
+
 def heartbeat(msg, rank=0, every_rank=False):
     """progress line for the launcher's watchdog (stderr; any rank's output counts as a sign of life)"""
     if rank == 0 or every_rank:
@@ -782,6 +912,10 @@ def main():
     if args.launcher == "spawn" or (args.launcher == "auto" and args.gpus > 1 and not is_child):
         if not is_child:
             sys.exit(launch(args, sys.argv[1:]))
+    # started by an EXTERNAL launcher with several ranks (torch.distributed.run: how the driver runs N > 1): this process
+    # becomes its rank's supervisor — same watchdog, same ladder, agreed between the ranks through files (supervise())
+    if args.launcher != "none" and os.environ.get("GANFFN_BENCH_CHILD") != "1" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        sys.exit(supervise(args, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -145,3 +145,22 @@ def test_two_rank_rehearsal_through_the_launcher():
     lo, hi = c["ms_per_step_min_max_over_ranks"]
     assert 0 < lo <= hi <= d["ms_per_step"] + 1e-3          # the line's time is the MAX over the ranks
     assert "[rank 1]" in r.stderr                             # the second rank really ran (its stderr is relayed)
+
+
+def test_two_rank_rehearsal_under_torch_distributed_run():
+    """the way the DRIVER starts N > 1: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.  Every rank
+    torchrun starts becomes a supervisor that makes no GPU call and runs the real rank as its child (bench.supervise): the
+    watchdog and the fallback ladder work here too.  Two ranks sharing the GPU over gloo (rehearsal backend); ONE JSON line, from
+    rank 0, saying how it was launched."""
+    env = dict(os.environ, GANFFN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "GANFFN_DP_MODE", "GANFFN_FORCE_DIST"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "4", "--seq", "20", "--no-cpu-baseline", "--step-only"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["rccl_ranks"] == 2 and c["dist_backend"] == "gloo"
+    assert c["launcher"]["rung"] == "inline-3streams" and c["launcher"]["spawned_ranks"] == 2 and "supervises" in c["launcher"]["how"]
