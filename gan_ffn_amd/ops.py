@@ -538,17 +538,45 @@ _CHECK_QMASK = __import__("os").environ.get("GANFFN_CHECK_QMASK", "0") == "1"
 
 
 def dialogue_rnn_supported(cell, U, qmask):
-    """the configuration the HIP recurrence implements: general attention, no listener, two parties, dims % 4,
+    """the configurations the HIP recurrence implements: general attention (the trained configuration) or simple attention
+    (DialogueRNNCell's constructor default; run as general attention with a constant query: _drnn_cell_args), no listener, two parties, dims % 4,
     D_g = D_p <= 512 (the attention kernels keep one state column per thread), on a GPU.
     PRECONDITION (not tested here: the test would be a device->host sync in front of ~760 latency-sized launches): every
     qmask row is one-hot or all zero, as the reference's loaders produce (dataloader.py:41-50) — the gate kernels use
     (argmax, value at argmax) only.  GANFFN_CHECK_QMASK=1 verifies it on every call."""
-    ok = (U.is_cuda and not cell.listener_state and getattr(cell.attention, "att_type", None) == "general"
+    simple = type(cell.attention).__name__ == "SimpleAttention"          # softmax over time of a learned scalar score (model.py:117-131)
+    ok = (U.is_cuda and not cell.listener_state and (getattr(cell.attention, "att_type", None) == "general" or simple)
           and qmask.size(2) == 2 and cell.D_g == cell.D_p and cell.D_g <= 512 and cell.D_m % 4 == 0 and cell.D_g % 4 == 0
           and cell.D_e % 4 == 0 and U.size(0) <= 112)
     if ok and _CHECK_QMASK:
         ok = bool((((qmask == 0) | (qmask == 1)).all() & (qmask.sum(2) <= 1).all()).item())
     return ok
+
+
+def _drnn_cell_args(cell, U):
+    """(U, the 13 parameter tensors) the recurrence kernels take for one DialogueRNNCell.
+    general attention (model.py:160-166): as they are.
+    simple attention (model.py:117-131): alpha = softmax_s(w . g_s) is general attention with the CONSTANT query w (general:
+    alpha = softmax_s(q_t . g_s), q_t = W_att U_t).  A constant cannot come out of W_att U_t, so the utterance features get one
+    more column that is always 1 (and three zero columns: the kernels want widths in multiples of 4), the input-side weights of
+    the global and party cells get matching zero columns, and the attention weight becomes [0 | w^T | 0]: q_t = w for every t.
+    All of it is torch.cat on the way in, so autograd carries dU and d(w) back out; the recurrence itself is the same HIP launch
+    chain.  (The scalar score has no bias in the reference; a bias would cancel in the softmax anyway.)"""
+    sd = dict(cell.named_parameters())
+    if type(cell.attention).__name__ != "SimpleAttention":
+        return U, [sd[k] for k in DRNN_KEYS]
+    S, B, Dm = U.shape
+    H = cell.D_g
+    Ux = torch.cat([U, U.new_ones(S, B, 1), U.new_zeros(S, B, 3)], 2)
+
+    def pad_ih(W):
+        return torch.cat([W[:, :Dm], W.new_zeros(W.size(0), 4), W[:, Dm:]], 1)
+    w = sd["attention.scalar.weight"]                                   # [1 x D_g]
+    att = torch.cat([w.new_zeros(H, Dm), w.t(), w.new_zeros(H, 3)], 1)  # [D_g x (D_m + 4)]
+    params = []
+    for k in DRNN_KEYS[:-1]:
+        params.append(pad_ih(sd[k]) if k in ("g_cell.weight_ih", "p_cell.weight_ih") else sd[k])
+    return Ux, params + [att]
 
 
 def dialogue_rnn_run(cells, Us, qmasks, training):
@@ -564,8 +592,8 @@ def dialogue_rnn_run(cells, Us, qmasks, training):
             qm = qmasks[z][:, b0:b1]
             spk = torch.argmax(qm, 2)
             mval = qm.gather(2, spk.unsqueeze(2)).squeeze(2)
-            sd = dict(cells[z].named_parameters())
-            args += [Us[z][:, b0:b1].contiguous(), spk, mval] + [sd[k] for k in DRNN_KEYS]
+            Ux, params = _drnn_cell_args(cells[z], Us[z][:, b0:b1])
+            args += [Ux.contiguous(), spk, mval] + params
         meta = {"p": float(cells[0].dropout.p), "train": bool(training)}
         out = DialogueRNNFn.apply(meta, *args)
         for z in range(ndir):

@@ -254,7 +254,8 @@ def artifacts():
 
 
 DRNN_CASES = {"general": dict(context_attention="general", listener_state=False),
-              "simple_listener": dict(context_attention="simple", listener_state=True)}
+              "simple_listener": dict(context_attention="simple", listener_state=True),
+              "simple": dict(context_attention="simple", listener_state=False)}       # (round 5: DialogueRNNCell's default attention)
 DRNN_DIMS = dict(D_m=100, D_g=500, D_p=500, D_e=100, D_h=100, n_classes=6, D_a=100, dropout_rec=0.1, dropout=0.6)
 DRNN_LENS = [7, 4, 6]
 

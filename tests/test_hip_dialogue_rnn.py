@@ -90,9 +90,11 @@ def test_general2_attention_kernel_vs_fp64_torch(S, B, D):
     assert float((alpha.cpu() * (1 - mask).unsqueeze(1)).abs().max()) == 0.0          # masked steps: exactly zero weight
 
 
-@pytest.mark.parametrize("tag", ["general", "simple_listener"])
+@pytest.mark.parametrize("tag", ["general", "simple_listener", "simple"])
 def test_bimodel_on_gpu_matches_reference_fixture(tag):
-    """the same reference fixture as tests/test_dialogue_rnn_cpu.py, with the head on the GPU (HIP general2 kernel)"""
+    """the same reference fixture as tests/test_dialogue_rnn_cpu.py, with the head on the GPU (HIP general2 kernel).  "general"
+    and (round 5) "simple" — the scalar-score attention of model.py:117-131, run as general attention with a constant query —
+    go through the HIP recurrence; listener state is the one variant left on torch ops (not the trained configuration)"""
     import test_dialogue_rnn_cpu as T
     import formula as F_
     from util import golden
@@ -104,13 +106,19 @@ def test_bimodel_on_gpu_matches_reference_fixture(tag):
     m = m.cuda()
     U, qmask, umask = T.inputs()
     Ut = torch.from_numpy(U).cuda().requires_grad_(True)
+    from gan_ffn_amd import ops
+    assert ops.dialogue_rnn_supported(m.dialog_rnn_f.dialogue_cell, Ut, torch.from_numpy(qmask).cuda()) == (tag != "simple_listener")
     lp, alpha, alpha_f, alpha_b = m(Ut, torch.from_numpy(qmask).cuda(), torch.from_numpy(umask).cuda())
     T.close(lp.detach().cpu().numpy(), g["%s/log_prob" % tag], 5e-5, "log_prob")
     T.close(torch.stack(alpha, 0).detach().cpu().numpy(), g["%s/alpha" % tag], 5e-5, "alpha")
     gy = torch.from_numpy(F_.formula_input("drnn.grad", lp.shape[0], lp.shape[1], lp.shape[2])) - 0.5
     (lp * gy.cuda()).sum().backward()
     T.close(Ut.grad.cpu().numpy(), g["%s/dU" % tag], 2e-4, "dU")
-    for k in ("matchatt.transform.weight", "matchatt.transform.bias", "linear.weight", "dialog_rnn_f.dialogue_cell.g_cell.weight_ih"):
+    keys = ("matchatt.transform.weight", "matchatt.transform.bias", "linear.weight", "dialog_rnn_f.dialogue_cell.g_cell.weight_ih")
+    if tag == "simple":     # the scalar-score weight gets its gradient through the constant-query column; the padded input weights theirs
+        keys += ("dialog_rnn_f.dialogue_cell.attention.scalar.weight", "dialog_rnn_r.dialogue_cell.attention.scalar.weight",
+                 "dialog_rnn_r.dialogue_cell.p_cell.weight_ih", "dialog_rnn_f.dialogue_cell.e_cell.weight_hh")
+    for k in keys:
         p = dict(m.named_parameters())[k]
         got = p.grad.cpu().numpy() if p.grad.numel() <= 4096 else p.grad.cpu().reshape(-1)[F_.sample_indices(p.grad.numel())].numpy()
         T.close(got, g["%s/grad/%s" % (tag, k)], 5e-4, "grad " + k)
