@@ -125,8 +125,12 @@ def test_module_matches_reference_fixture(case, shape, fixture_grads=True):
     assert all(p.grad is None for k, p in sd.items() if k.startswith("encoder_layer."))
 
 
+# (3, 32) and (5, 32): T = 96 and 160 tokens, T % 64 == 32 — the token counts of real variable-length IEMOCAP batches at B = 32 with an odd
+# S, at which the wave holding rows 32..63 of the last 64-row tile of the linear2 dgrad lies wholly past the matrix; its 1-bit-pattern
+# read is clamped onto the last row tile (it read one tile past the pattern, the last field of the exactly-sized saved block)
 @pytest.mark.parametrize("cls_name,din,S,B", [("TextGenerator", 100, 23, 3), ("VisualGenerator", 512, 38, 2),
-                                              ("AcousticDiscriminator", 100, 94, 4), ("VisualDiscriminator", 512, 17, 2)])
+                                              ("AcousticDiscriminator", 100, 94, 4), ("VisualDiscriminator", 512, 17, 2),
+                                              ("TextDiscriminator", 100, 3, 32), ("VisualGenerator", 512, 5, 32)])
 def test_train_mode_matches_oracle_with_same_masks(cls_name, din, S, B):
     """dropout ON: same (seed, offset) -> identical Philox masks in kernel and oracle."""
     from gan_ffn_amd import ops
