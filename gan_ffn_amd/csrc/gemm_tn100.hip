@@ -102,16 +102,34 @@ __global__ __launch_bounds__(256) void tn100_kernel(W100Group grp) {
     const int ldsv##J = UT + rv##J * LDV + cv##J;
     GF_W_VIDX(0) GF_W_VIDX(1)
     float4 qu0, qu1, qu2, qu3, qv0, qv1;
-    // rows (tokens) beyond kend are clamped onto the last valid token and zeroed when they go to LDS (wave-uniform tail test)
+    // Global loads.  A FULL tile (all 32 token rows below kend — every tile but possibly the last) is read through a uniform
+    // base pointer (scalar ALU) + loop-invariant 32-bit lane offsets: no vector ALU work per tile.  fp32 MFMAs execute on
+    // the SIMD's vector ALU, so every VALU instruction in this loop is paid for in MFMA time (round 5 counters,
+    // profiles/r05_wgrad_pmc.json: 3.05 VALU instructions per MFMA, MFMA pipe 57 % busy, before this form).  Rows beyond kend
+    // (the tail tile only) are clamped onto the last valid token and zeroed when they go to LDS (wave-uniform tail test).
+    const uint32_t lou0 = (uint32_t)ru0 * (uint32_t)ldu + offu0, lou1 = (uint32_t)ru1 * (uint32_t)ldu + offu1,
+                   lou2 = (uint32_t)ru2 * (uint32_t)ldu + offu2, lou3 = (uint32_t)ru3 * (uint32_t)ldu + offu3;
+    const uint32_t lov0 = (uint32_t)rv0 * (uint32_t)ldv + offv0, lov1 = (uint32_t)rv1 * (uint32_t)ldv + offv1;
 #define GF_W_GLOAD(TT)                                                                                \
     {                                                                                                 \
         const int k0 = kbeg + min((TT), nt - 1) * WBK, kl = kend - 1;                                 \
-        qu0 = *reinterpret_cast<const float4*>(Ug + (size_t)min(k0 + ru0, kl) * ldu + offu0);         \
-        qu1 = *reinterpret_cast<const float4*>(Ug + (size_t)min(k0 + ru1, kl) * ldu + offu1);         \
-        qu2 = *reinterpret_cast<const float4*>(Ug + (size_t)min(k0 + ru2, kl) * ldu + offu2);         \
-        qu3 = *reinterpret_cast<const float4*>(Ug + (size_t)min(k0 + ru3, kl) * ldu + offu3);         \
-        qv0 = *reinterpret_cast<const float4*>(Vg + (size_t)min(k0 + rv0, kl) * ldv + offv0);         \
-        qv1 = *reinterpret_cast<const float4*>(Vg + (size_t)min(k0 + rv1, kl) * ldv + offv1);         \
+        if (k0 + WBK <= kend) {                             /* wave-uniform */                          \
+            const float* const ub = Ug + (size_t)k0 * ldu;                                            \
+            const float* const vb = Vg + (size_t)k0 * ldv;                                            \
+            qu0 = *reinterpret_cast<const float4*>(ub + lou0);                                        \
+            qu1 = *reinterpret_cast<const float4*>(ub + lou1);                                        \
+            qu2 = *reinterpret_cast<const float4*>(ub + lou2);                                        \
+            qu3 = *reinterpret_cast<const float4*>(ub + lou3);                                        \
+            qv0 = *reinterpret_cast<const float4*>(vb + lov0);                                        \
+            qv1 = *reinterpret_cast<const float4*>(vb + lov1);                                        \
+        } else {                                                                                      \
+            qu0 = *reinterpret_cast<const float4*>(Ug + (size_t)min(k0 + ru0, kl) * ldu + offu0);     \
+            qu1 = *reinterpret_cast<const float4*>(Ug + (size_t)min(k0 + ru1, kl) * ldu + offu1);     \
+            qu2 = *reinterpret_cast<const float4*>(Ug + (size_t)min(k0 + ru2, kl) * ldu + offu2);     \
+            qu3 = *reinterpret_cast<const float4*>(Ug + (size_t)min(k0 + ru3, kl) * ldu + offu3);     \
+            qv0 = *reinterpret_cast<const float4*>(Vg + (size_t)min(k0 + rv0, kl) * ldv + offv0);     \
+            qv1 = *reinterpret_cast<const float4*>(Vg + (size_t)min(k0 + rv1, kl) * ldv + offv1);     \
+        }                                                                                             \
     }
 #define GF_W_MASK(Q, ROW) { const float f_ = (ROW) < kv ? 1.f : 0.f; Q.x *= f_; Q.y *= f_; Q.z *= f_; Q.w *= f_; }
 #define GF_W_SSTORE(BUF, TT)                                                                          \
@@ -127,12 +145,20 @@ __global__ __launch_bounds__(256) void tn100_kernel(W100Group grp) {
         *reinterpret_cast<float4*>(sdst + ldsv1) = qv1;                                               \
     }
 
+    // The accumulators are updated IN PLACE by MFMAs written as inline assembly: with the builtin, hipcc let the destination
+    // of an MFMA differ from its accumulator input and restored the assignment with 88 v_accvgpr_read / write / mov per K
+    // tile (for 56 MFMAs).  Hazards the compiler no longer sees: an accumulator is touched again 7 MFMAs (>= 200 cycles)
+    // later — far beyond any MFMA -> MFMA wait-state requirement; the A / B operands come straight from ds_read (s_waitcnt is
+    // still inserted for inline-assembly operands), never from a VALU instruction right before; the epilogue's first VALU
+    // read of an accumulator comes after the explicit s_nop block below.
     floatx4 acc[WT7];
 #pragma unroll
     for (int m = 0; m < WT7; ++m) acc[m] = floatx4{0.f, 0.f, 0.f, 0.f};
     // bias gradient = column sums of dY over the tokens.  side 0: dY = U (its 100 columns): wave 0 of the tile-0 workgroup
     // sums the A operand values it reads; side 1: dY = V: every wave sums the B operand values of its 16 columns.
-    const bool cs_u = q.colsum != nullptr && q.side == 0 && tile == 0 && wave == 0;
+    // (wave-uniform by construction; readfirstlane tells the compiler, which otherwise runs the sums of the one wave that
+    //  owns them under an exec mask in EVERY wave: 32 dead VALU instructions per K tile)
+    const bool cs_u = __builtin_amdgcn_readfirstlane((int)(q.colsum != nullptr && q.side == 0 && tile == 0 && wave == 0)) != 0;
     const bool cs_v = q.colsum != nullptr && q.side == 1;
     float csu[WT7], csv = 0.f;
 #pragma unroll
@@ -149,46 +175,69 @@ __global__ __launch_bounds__(256) void tn100_kernel(W100Group grp) {
     }
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
-        GF_W_GLOAD(t + 1)
-        __builtin_amdgcn_sched_barrier(0);       // the next tile's loads stay ahead of this tile's MFMAs
-        const float* s = smem + (t & 1) * STAGE;
-        const float* sv = s + UT + wave * 16 + c;
-        const float* su = s + c;
-        // 8 k-steps of 4 tokens: at the j-th MFMA of a half, lane group g takes token 16 half + 4 g + j (rows of the lane groups
-        // 4 apart: conflict-free ds_read_b32 with the 116 / 68 row strides)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float av[4][WT7], bv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kr = 16 * half + 4 * g + j;
-                bv[j] = sv[kr * LDV];
-#pragma unroll
-                for (int m = 0; m < WT7; ++m) av[j][m] = (TAIL4 && m == WT7 - 1) ? s[kr * LDU + 96 + (c & 3)] : su[kr * LDU + 16 * m];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int m = 0; m < WT7; ++m) {
-                    if (TAIL4 && m == WT7 - 1) acc[m] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j][m], bv[j], acc[m], 0, 0, 0);
-                    else acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][m], bv[j], acc[m], 0, 0, 0);
-                }
-            if (cs_v) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) csv += bv[j];
-            }
-            if (cs_u) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int m = 0; m < WT7; ++m) csu[m] += av[j][m];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < nt) GF_W_SSTORE((t + 1) & 1, t + 1)
-        __syncthreads();
+    // 8 k-steps of 4 tokens per tile: at the j-th MFMA of a half, lane group g takes token 16 half + 4 g + j (rows of the lane
+    // groups 4 apart: conflict-free ds_read_b32 with the 116 / 68 row strides).  The stage is a compile-time constant of the
+    // step (the loop is unrolled by two): every LDS address is one loop-invariant VGPR + an immediate offset.
+    const float* const sv_lane = smem + UT + wave * 16 + c + 4 * g * LDV;
+    const float* const su_lane = smem + c + 4 * g * LDU;
+    const float* const s4_lane = smem + 96 + (c & 3) + 4 * g * LDU;
+    // LDS reads run one group of 2 k-steps (16 dwords per lane) AHEAD of the MFMAs: the reads of group i + 1 are issued before
+    // the 14 MFMAs of group i, so only the first group of a tile waits for LDS (k order unchanged: 0 1 | 2 3 | 16 17 | 18 19 + 4 g)
+#define GF_W_LOADG(A, B, BUF, GI)                                                                     \
+    {                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+            const int kr = 16 * ((GI) >> 1) + 2 * ((GI) & 1) + j;                                     \
+            B[j] = sv_lane[(BUF) * STAGE + kr * LDV];                                                 \
+            _Pragma("unroll") for (int m = 0; m < WT7; ++m)                                           \
+                A[j][m] = (TAIL4 && m == WT7 - 1) ? s4_lane[(BUF) * STAGE + kr * LDU] : su_lane[(BUF) * STAGE + kr * LDU + 16 * m]; \
+        }                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
     }
+#define GF_W_MFMAG(A, B)                                                                              \
+    {                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
+            _Pragma("unroll") for (int m = 0; m < WT7; ++m) {                                         \
+                if (TAIL4 && m == WT7 - 1) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(A[j][m]), "v"(B[j])); \
+                else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(A[j][m]), "v"(B[j])); \
+            }                                                                                         \
+        if (cs_v) { csv += B[0]; csv += B[1]; }                                                       \
+        if (cs_u) {                                                                                   \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                             \
+                _Pragma("unroll") for (int m = 0; m < WT7; ++m) csu[m] += A[j][m];                    \
+        }                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+#define GF_W_COMPUTE(BUF)                                                                             \
+    {                                                                                                 \
+        float a0[2][WT7], b0[2], a1[2][WT7], b1[2];                                                   \
+        GF_W_LOADG(a0, b0, BUF, 0)                                                                    \
+        GF_W_LOADG(a1, b1, BUF, 1)                                                                    \
+        GF_W_MFMAG(a0, b0)                                                                            \
+        GF_W_LOADG(a0, b0, BUF, 2)                                                                    \
+        GF_W_MFMAG(a1, b1)                                                                            \
+        GF_W_LOADG(a1, b1, BUF, 3)                                                                    \
+        GF_W_MFMAG(a0, b0)                                                                            \
+        GF_W_MFMAG(a1, b1)                                                                            \
+    }
+#define GF_W_STEP(BUF, TT)                                                                            \
+    {                                                                                                 \
+        GF_W_GLOAD((TT) + 1)                                                                          \
+        __builtin_amdgcn_sched_barrier(0);       /* the next tile's loads stay ahead of this tile's MFMAs */ \
+        GF_W_COMPUTE(BUF)                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if ((TT) + 1 < nt) GF_W_SSTORE((BUF) ^ 1, (TT) + 1)                                           \
+        __syncthreads();                                                                              \
+    }
+    for (int t = 0; t < nt; t += 2) {
+        GF_W_STEP(0, t)
+        if (t + 1 < nt) GF_W_STEP(1, t + 1)
+    }
+    // (inline-assembly MFMAs: the wait states before a VALU / store instruction reads an accumulator are ours to provide)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#undef GF_W_STEP
+#undef GF_W_COMPUTE
+#undef GF_W_LOADG
+#undef GF_W_MFMAG
 #undef GF_W_GLOAD
 #undef GF_W_SSTORE
 #undef GF_W_MASK
