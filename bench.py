@@ -119,6 +119,19 @@ def committed_traffic(S, B, which=None):
     return None
 
 
+def _ramp(one_iteration, seconds=0.5):
+    """replay the launch mix until `seconds` of wall time have passed: the shader clock idles at ~100 MHz and takes ~0.4 s of
+    load to reach its sustained 2.39 GHz (tools/lab/clock_wgrad.py, profiles/r05_ab_logs.txt section 9); a three-replay
+    measurement taken cold reads ~10 % slow (weight-gradient family 541 against 485 us per launch).  The training step runs
+    with the clock up (bench pre-roll), so its kernels are priced in that state too."""
+    t0 = time.time()
+    one_iteration()
+    torch.cuda.synchronize()
+    while time.time() - t0 < seconds:
+        one_iteration()
+        torch.cuda.synchronize()
+
+
 def time_dominant_kernel(S, B, reps=3, config="iemocap"):
     """Live HIP-event timing, on the stream the kernel is launched on (torch's current stream), of one iteration's
     launches of the dominant kernel (see wgrad_groups), replayed back to back in isolation.
@@ -153,7 +166,7 @@ def time_dominant_kernel(S, B, reps=3, config="iemocap"):
         for cnt, a, _ in calls:
             for _i in range(cnt):
                 _lib.call("ganffn_gemm_tn_grouped", a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], ops._ptr(ws), nws, st)
-    one_iteration()
+    _ramp(one_iteration)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
@@ -214,7 +227,7 @@ def time_n100_kernel(S, B, reps=3):
             for _ in range(cnt):
                 _lib.call("ganffn_gemm_n100", ops._ptr(A), ops._ptr(W), km, ops._ptr(b), ops._ptr(slabs), C.c_int64(T * 100), T, K, 16,
                           C.byref(n), st)
-    one_iteration()
+    _ramp(one_iteration)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
@@ -234,7 +247,7 @@ def _time_mix(calls, reps=3):
         for cnt, fn, _ in calls:
             for _i in range(cnt):
                 fn()
-    one_iteration()
+    _ramp(one_iteration)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
