@@ -34,6 +34,38 @@ namespace ganffn {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+// buffer loads / stores: a 128-bit descriptor in scalar registers + a 32-bit byte offset per lane + a scalar byte offset —
+// no 64-bit per-lane address arithmetic (fp32 MFMAs share the vector ALU: every VALU instruction next to them costs MFMA time)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load_f4(__amdgpu_buffer_rsrc_t rs, uint32_t voff_bytes, uint32_t soff_bytes) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff_bytes, (int)soff_bytes, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+// Four single instructions hipcc will not leave alone: written in C++, `x & sext(bit)` and `min(x, 1) << i | y` come back
+// as v_and + v_cmp_ne + v_cndmask chains (instcombine's canonical select form) — 3-4 instructions where one or two do.
+__device__ __forceinline__ uint32_t v_bit_to_mask(uint32_t word, int bit) {            // 0 or 0xFFFFFFFF
+    uint32_t r;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(word), "n"(bit));
+    return r;
+}
+__device__ __forceinline__ uint32_t v_and_keep(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_and_b32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t v_nonzero_bit_or(uint32_t x, int bit, uint32_t acc) {   // acc | ((x != 0) << bit)
+    uint32_t t, r;
+    asm("v_min_u32 %0, 1, %1" : "=v"(t) : "v"(x));
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(t), "n"(bit), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ void buf_store_u32(__amdgpu_buffer_rsrc_t rs, uint32_t voff_bytes, uint32_t soff_bytes, uint32_t v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, rs, (int)voff_bytes, (int)soff_bytes, 0);
+}
+
 // BK in {16, 32, 64}; K-contiguous LDS row stride BK + 4 = 4 * odd  (20, 36, 68)
 
 enum { MODE_NT = 0, MODE_NN = 1, MODE_TN = 2 };
@@ -369,6 +401,56 @@ __device__ __forceinline__ void gemm_apply_store_full(const GemmArgs& g, const f
                                                       const int mbase, const int nbase, const int r, const int h,
                                                       const DropCtx& dc, const uint32_t keep) {
     constexpr bool HAS_AUX = epi_has_aux<EPI>();
+    if constexpr (EPI == EPI_RELU_DROP || EPI == EPI_MASK_POS) {
+        // Round 5, the two epilogues of the K = 100 kernel written for their instruction count (the tile loop of linear1 carried
+        // 168 vector instructions per 50 MFMAs before Philox, the dgrad 157: profiles/r05_ffn_k100_pmc.json, 8.4 / 5.9 per MFMA):
+        //  * stores through a buffer descriptor: lane offset loop-invariant, the row (mbase + dr) * ldc in the SCALAR offset — no
+        //    64-bit address per store;
+        //  * a keep / pattern bit becomes an all-ones / all-zeros word (one bit-field extract) ANDed onto the product: the dropped
+        //    value is +0 exactly as `x * 0.f` of a non-negative x (linear1) resp. the `? :` (dgrad) gave — same bits;
+        //  * the ReLU pattern bit of register i is min(bits(v), 1) << i: v >= +0 always, so v > 0 <=> its bits are not 0;
+        //  * eval mode (dc.on == 0, wave-uniform) skips the dropout arithmetic instead of multiplying by 1.
+        if (EPI == EPI_MASK_POS && g.ea.mask_in == nullptr) {
+            // (saved-activation form of the mask, lab bit 25 only: the general code below)
+        } else {
+            const __amdgpu_buffer_rsrc_t rc = buf_rsrc(g.C, 0xFFFFFFFFu);
+            const uint32_t vo = (uint32_t)(4 * h * g.ldc + nbase + r) * 4u;     // lane part; rows: scalar
+            const uint32_t ldcb = (uint32_t)g.ldc * 4u;
+            // (mbase is wave-uniform but derives from the wave id: say so, or every store becomes a readfirstlane loop)
+            const uint32_t mb = (uint32_t)__builtin_amdgcn_readfirstlane(mbase);
+            uint32_t pos = 0;
+            if constexpr (EPI == EPI_RELU_DROP) {
+                const uint32_t sbits = __float_as_uint(dc.scale);
+                if (dc.on) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int dr = (i & 3) + 8 * (i >> 2);
+                        const uint32_t vb = v_and_keep(__float_as_uint(fmaxf(acc[i] + bias, 0.f) * __uint_as_float(sbits)), v_bit_to_mask(keep, i));
+                        pos = v_nonzero_bit_or(vb, i, pos);
+                        buf_store_u32(rc, vo, (mb + dr) * ldcb, vb);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int dr = (i & 3) + 8 * (i >> 2);
+                        const uint32_t vb = __float_as_uint(fmaxf(acc[i] + bias, 0.f));
+                        pos = v_nonzero_bit_or(vb, i, pos);
+                        buf_store_u32(rc, vo, (mb + dr) * ldcb, vb);
+                    }
+                }
+                if (g.ea.mask_out != nullptr)
+                    g.ea.mask_out[((size_t)(mbase >> 5) * g.N + nbase + r) * 2 + h] = (uint16_t)pos;
+            } else {
+                const uint32_t mword = __float_as_uint(aux[0]);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int dr = (i & 3) + 8 * (i >> 2);
+                    buf_store_u32(rc, vo, (mb + dr) * ldcb, v_and_keep(__float_as_uint(acc[i] * g.ea.mscale), v_bit_to_mask(mword, i)));
+                }
+            }
+            return;
+        }
+    }
     float* const cp = g.C + (size_t)(mbase + 4 * h) * g.ldc + nbase + r;
     float* const up = (EPI == EPI_DROP_GELU) ? g.ea.aux_out + (size_t)(mbase + 4 * h) * g.ldc + nbase + r : nullptr;
     const bool bitmask = EPI == EPI_MASK_POS && g.ea.mask_in != nullptr;                  // uniform
