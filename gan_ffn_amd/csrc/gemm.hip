@@ -852,8 +852,17 @@ __global__ __launch_bounds__(256) void gemm_wres_kernel(GemmArgs g, int mtiles, 
     const int ti##J = min(tid + J * 256, TOTALV - 1); /* clamped duplicates rewrite the last vector */   \
     const int trow##J = ti##J / KV, tcol##J = 4 * (ti##J - trow##J * KV), soff##J = trow##J * LD + tcol##J;
     GF_REP7(GF_WRES_IDX)
-#define GF_WRES_GLOAD1(J) ta##J = *reinterpret_cast<const float4*>(g.A + (size_t)min(mrow0 + trow##J, g.M - 1) * g.lda + tcol##J);
-#define GF_WRES_GLOAD(MT) { const int mrow0 = (MT) * BM; GF_REP7(GF_WRES_GLOAD1) }
+    // token-tile loads through a buffer descriptor (round 5): the lane's offset inside a tile is loop-invariant, the tile's first
+    // row is one 32-bit add, and rows past M are out of the descriptor's range — the hardware returns zeros for them (they feed
+    // output rows that are never stored) instead of a per-lane min() + 64-bit address per load
+    const __amdgpu_buffer_rsrc_t rsA = buf_rsrc(g.A, (uint32_t)(((size_t)(g.M - 1) * g.lda + KC) * sizeof(float)));
+    // (the tile's first row is added to the LANE offset, one v_add per load: the range check covers the lane offset only, a
+    //  scalar offset would slip past it)
+    const uint32_t ldab = (uint32_t)g.lda * 4u;
+#define GF_WRES_VOFF(J) const uint32_t tvo##J = ((uint32_t)trow##J * (uint32_t)g.lda + (uint32_t)tcol##J) * 4u;
+    GF_REP7(GF_WRES_VOFF)
+#define GF_WRES_GLOAD1(J) ta##J = buf_load_f4(rsA, tvo##J + so_, 0u);
+#define GF_WRES_GLOAD(MT) { const uint32_t so_ = (uint32_t)((MT) * BM) * ldab; GF_REP7(GF_WRES_GLOAD1) }
 #define GF_WRES_SSTORE1(J) *reinterpret_cast<float4*>(sdst + soff##J) = ta##J;
 #define GF_WRES_SSTORE(BUF) { float* const sdst = smem + (BUF) * (BM * LD); GF_REP7(GF_WRES_SSTORE1) }
 
@@ -870,48 +879,60 @@ __global__ __launch_bounds__(256) void gemm_wres_kernel(GemmArgs g, int mtiles, 
     GF_WRES_GLOAD(mt)
     GF_WRES_SSTORE(0)
     __syncthreads();
-    int buf = 0;
     GF_LAB_ONLY(if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();)
 
-    // One tile's 4 * G8 MFMAs with their LDS fragment reads.
+    // One tile's 4 * G8 MFMAs with their LDS fragment reads.  (Round 5 also wrote them as inline assembly accumulating in place in
+    // ordinary vector registers, to save the 16 v_accvgpr_read of the epilogue: wrong results on the GPU although the emitted
+    // sequence reads like hipcc's own — not pursued for 16 instructions per tile; the builtin stays.)
+#define GF_WRES_MFMA1(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, ACC, 0, 0, 0);
 #define GF_WRES_MFMA(ACC, BUF)                                                                              \
     {                                                                                                       \
         const float* arow = smem + (BUF) * (BM * LD) + (wm * 32 + r) * LD;                                  \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = 0.f;                                        \
         _Pragma("unroll") for (int gq = 0; gq < G8F; ++gq) {                                                \
             const float4 q = *reinterpret_cast<const float4*>(arow + min(8 * gq + 4 * h, KC - 4));          \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.x, wf[gq][0], ACC, 0, 0, 0);                        \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.y, wf[gq][1], ACC, 0, 0, 0);                        \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.z, wf[gq][2], ACC, 0, 0, 0);                        \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(q.w, wf[gq][3], ACC, 0, 0, 0);                        \
+            if (gq == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) ACC[i_] = 0.f; GF_WRES_MFMA1(ACC, q.x, wf[gq][0]) } \
+            else GF_WRES_MFMA1(ACC, q.x, wf[gq][0])                                                          \
+            GF_WRES_MFMA1(ACC, q.y, wf[gq][1])                                                               \
+            GF_WRES_MFMA1(ACC, q.z, wf[gq][2])                                                               \
+            GF_WRES_MFMA1(ACC, q.w, wf[gq][3])                                                               \
         }                                                                                                   \
         if constexpr (TAIL2) {                                                                              \
             const float4 q = *reinterpret_cast<const float4*>(arow + KC - 4);                               \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? q.y : q.x, wtail[0], ACC, 0, 0, 0);               \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? q.w : q.z, wtail[1], ACC, 0, 0, 0);               \
+            GF_WRES_MFMA1(ACC, h ? q.y : q.x, wtail[0])                                                      \
+            GF_WRES_MFMA1(ACC, h ? q.w : q.z, wtail[1])                                                      \
         }                                                                                                   \
     }
-#pragma unroll 1
-    for (; mt < mtiles; mt += wg_per_panel, buf ^= 1) {
-        const int mbase = mt * BM + wm * 32;
-        const int mload = min(mt + wg_per_panel, mtiles - 1);   // unconditional (clamped): no load under a branch
-        GF_WRES_GLOAD(mload)
-        float aux[1][1][16];
-        gemm_load_aux<EPI, 1, 1>(g, aux, mbase, nbase, 0, r, h);
-        __builtin_amdgcn_sched_barrier(0);
-        uint32_t keep[1][1];
-        gemm_keep_bits<EPI, 1, 1>(g, dc, keep, mbase, nbase, r, h);
-        floatx16 acc[1][1];
-        GF_WRES_MFMA(acc[0][0], buf)
-        __builtin_amdgcn_sched_barrier(0);
-        GF_WRES_SSTORE(buf ^ 1)
-        if (mbase + 32 <= g.M && nbase + 32 <= g.N) {           // wave-uniform
-            gemm_apply_store_full<EPI>(g, acc[0][0], aux[0][0], bias, mbase, nbase, r, h, dc, keep[0][0]);
-        } else {
-            gemm_apply_store<EPI, 1, 1>(g, acc, aux, mbase, nbase, 0, r, h, dc, keep);
-        }
-        __syncthreads();
+    // one tile from LDS stage BUF (a compile-time constant: the loop below is unrolled by two)
+#define GF_WRES_TILE(BUF)                                                                                   \
+    {                                                                                                       \
+        const int mbase = mt * BM + wm * 32;                                                                \
+        const int mload = min(mt + wg_per_panel, mtiles - 1);   /* unconditional (clamped): no load under a branch */ \
+        GF_WRES_GLOAD(mload)                                                                                \
+        float aux[1][1][16];                                                                                \
+        gemm_load_aux<EPI, 1, 1>(g, aux, mbase, nbase, 0, r, h);                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        uint32_t keep[1][1];                                                                                \
+        gemm_keep_bits<EPI, 1, 1>(g, dc, keep, mbase, nbase, r, h);                                         \
+        floatx16 acc[1][1];                                                                                 \
+        GF_WRES_MFMA(acc[0][0], BUF)                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        GF_WRES_SSTORE((BUF) ^ 1)                                                                           \
+        if (mbase + 32 <= g.M && nbase + 32 <= g.N) {           /* wave-uniform */                          \
+            gemm_apply_store_full<EPI>(g, acc[0][0], aux[0][0], bias, mbase, nbase, r, h, dc, keep[0][0]);  \
+        } else {                                                                                            \
+            gemm_apply_store<EPI, 1, 1>(g, acc, aux, mbase, nbase, 0, r, h, dc, keep);                      \
+        }                                                                                                   \
+        __syncthreads();                                                                                    \
     }
+#pragma unroll 1
+    for (; mt < mtiles; mt += wg_per_panel) {
+        GF_WRES_TILE(0)
+        mt += wg_per_panel;
+        if (mt >= mtiles) break;
+        GF_WRES_TILE(1)
+    }
+#undef GF_WRES_TILE
+#undef GF_WRES_MFMA1
     GF_LAB_ONLY(if (stamp) { stamp[2] = __builtin_amdgcn_s_memtime(); stamp[3] = (unsigned long long)((mtiles - j0 + wg_per_panel - 1) / wg_per_panel); })
 #undef GF_WRES_MFMA
 #undef GF_WRES_GLOAD
@@ -919,6 +940,7 @@ __global__ __launch_bounds__(256) void gemm_wres_kernel(GemmArgs g, int mtiles, 
 #undef GF_WRES_GLOAD1
 #undef GF_WRES_SSTORE1
 #undef GF_WRES_IDX
+#undef GF_WRES_VOFF
 #undef GF_REP7
 }
 
@@ -937,6 +959,9 @@ static int launch_wres(const GemmArgs& g, hipStream_t st) {
         int per_cu = 0, cus = 0;
         GF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_wres_kernel<MODE, EPI, KC>, 256, lds));
         GF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid));
+        // (two per CU at most: with the accumulator in ordinary registers three would fit, and three measured slower in
+        //  round 3 — fewer tiles per workgroup to amortise the weight fragments and the first load)
+        if (per_cu > 2) per_cu = 2;
         res = per_cu * cus > 0 ? per_cu * cus : 512;
     }
     int per = res / panels;
@@ -1046,7 +1071,8 @@ static int launch_pick(const GemmArgs& g, int splits, hipStream_t st) {
     // straight-line K loop the 4-wave 64x64x16 block is the fastest or within 2 % of the fastest of every block /
     // wave-tile shape tried (64x64x32, 128x64, 64x128, 128x128 with 2, 4, 8 or 16 waves), so it is the only one used.
     if constexpr (MODE != MODE_TN)
-        if (g.K == 100 && g.N >= 1024 && splits == 1 && (g.lda & 3) == 0 && ((MODE == MODE_NT) ? (g.ldb & 3) == 0 : true))
+        if (g.K == 100 && g.N >= 1024 && splits == 1 && (g.lda & 3) == 0 && ((MODE == MODE_NT) ? (g.ldb & 3) == 0 : true) &&
+            (size_t)g.M * g.lda * 4 < (size_t(1) << 31) && (size_t)g.M * g.ldc * 4 < (size_t(1) << 31))   // 32-bit buffer offsets
             return launch_wres<MODE, EPI>(g, st);
     if (g.K <= 128) return launch_cfg<MODE, 64, 64, 16, EPI, 2, 2, 1>(g, splits, st);
     // (64 x 128 tiles for the N = 2048, K = 512 products: 5-9 % faster in isolation, round 2; in the 3-stream step 35.9 against
