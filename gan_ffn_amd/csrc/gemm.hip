@@ -399,9 +399,9 @@ __device__ __forceinline__ void gemm_apply_store(const GemmArgs& g, floatx16 (&a
 template <int EPI>
 __device__ __forceinline__ void gemm_apply_store_full(const GemmArgs& g, const floatx16& acc, const float (&aux)[16], const float bias,
                                                       const int mbase, const int nbase, const int r, const int h,
-                                                      const DropCtx& dc, const uint32_t keep) {
+                                                      const DropCtx& dc, const uint32_t keep, const uint32_t slab_bytes = 0u) {
     constexpr bool HAS_AUX = epi_has_aux<EPI>();
-    if constexpr (EPI == EPI_RELU_DROP || EPI == EPI_MASK_POS) {
+    if constexpr (EPI == EPI_RELU_DROP || EPI == EPI_MASK_POS || EPI == EPI_NONE) {
         // Round 5, the two epilogues of the K = 100 kernel written for their instruction count (the tile loop of linear1 carried
         // 168 vector instructions per 50 MFMAs before Philox, the dgrad 157: profiles/r05_ffn_k100_pmc.json, 8.4 / 5.9 per MFMA):
         //  * stores through a buffer descriptor: lane offset loop-invariant, the row (mbase + dr) * ldc in the SCALAR offset — no
@@ -419,7 +419,13 @@ __device__ __forceinline__ void gemm_apply_store_full(const GemmArgs& g, const f
             // (mbase is wave-uniform but derives from the wave id: say so, or every store becomes a readfirstlane loop)
             const uint32_t mb = (uint32_t)__builtin_amdgcn_readfirstlane(mbase);
             uint32_t pos = 0;
-            if constexpr (EPI == EPI_RELU_DROP) {
+            if constexpr (EPI == EPI_NONE) {        // bias (+ residual) and the store; slab_bytes: the split-K slab of this workgroup
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int dr = (i & 3) + 8 * (i >> 2);
+                    buf_store_u32(rc, vo, slab_bytes + (mb + dr) * ldcb, __float_as_uint((acc[i] + bias) + aux[i]));
+                }
+            } else if constexpr (EPI == EPI_RELU_DROP) {
                 const uint32_t sbits = __float_as_uint(dc.scale);
                 if (dc.on) {
 #pragma unroll
@@ -492,6 +498,19 @@ __device__ __forceinline__ void gemm_store_epilogue(const GemmArgs& g, floatx16 
                                                     const uint32_t (&keep)[TM][TN]) {
     float aux[TM][TN][16];
     gemm_load_aux<EPI, TM, TN>(g, aux, mbase, nbase, bz, r, h);
+    if constexpr (TM == 1 && TN == 1 && (EPI == EPI_NONE || EPI == EPI_RELU_DROP || EPI == EPI_MASK_POS)) {
+        // a wave tile that lies wholly inside the matrix (every tile of the hot shapes: M = 3008 = 47 x 64, N a multiple of 64):
+        // the straight-line epilogue of the weight-resident kernel — buffer stores with scalar row offsets, no per-element
+        // bounds test, the lean dropout / pattern arithmetic — instead of the general one (round 5).  Same values.
+        const size_t span = ((size_t)(gridDim.z - 1) * (size_t)g.slab_stride + (size_t)g.M * (size_t)g.ldc) * sizeof(float);
+        if (mbase + 32 <= g.M && nbase + 32 <= g.N && span < (size_t(1) << 31) && (EPI == EPI_NONE || bz == 0)) {   // wave-uniform
+            float bias = 0.f;
+            if (g.ea.bias != nullptr && bz == 0) bias = g.ea.bias[nbase + r];
+            const uint32_t slab_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)((size_t)bz * (size_t)g.slab_stride * sizeof(float)));
+            gemm_apply_store_full<EPI>(g, acc[0][0], aux[0][0], bias, mbase, nbase, r, h, dc, keep[0][0], slab_bytes);
+            return;
+        }
+    }
     gemm_apply_store<EPI, TM, TN>(g, acc, aux, mbase, nbase, bz, r, h, dc, keep);
 }
 
