@@ -36,6 +36,12 @@ constexpr int LDWK = 116;          // K-major weight tile [32][116]: rows 4 apar
 // K-contiguous LDS tile [rows][32]: 16-byte slot s of row r at slot s ^ ((r / 2) % 8) (gemm.hip kc_off<32>)
 __device__ __forceinline__ int sw32(int row, int slot) { return row * NBK + 4 * (slot ^ ((row >> 1) & 7)); }
 
+__device__ __forceinline__ float4 n100_ldb(__amdgpu_buffer_rsrc_t rs, uint32_t voff_bytes, uint32_t soff_bytes) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff_bytes, (int)soff_bytes, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 struct N100Args {
     const float* A; int lda;       // activations [T x K]
     const float* W; int ldw;       // NT: [100 x K] rows of K;  NN: [K x 100] rows of 100
@@ -91,16 +97,22 @@ __global__ __launch_bounds__(256 * KW) void gemm_n100_kernel(N100Args a) {
     // two register sets (A: even tiles, B: odd tiles): the loads of tile t + 2 are issued at step t, so a tile has two
     // steps (~3600 MFMA cycles) to arrive — with one step of cover a lone workgroup on a CU was load-latency-bound
     float4 qaA0, qaA1, qwA0, qwA1, qwA2, qwA3, qaB0, qaB1, qwB0, qwB1, qwB2, qwB3;
+    // (every offset below is clamped into its operand: unbounded descriptors; the launcher refuses operands of 4 GiB or more)
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, -1, 0x00020000);
 #define GF_N100_GLOAD(R, TT)                                                                                        \
     {                                                                                                               \
         const int k0 = kbeg + min((TT), nt - 1) * NBK; /* (a prefetch beyond the last tile re-reads it: never consumed) */ \
-        const float* Ak = a.A + k0;                                                                                 \
-        const float* Wk = WKMAJOR ? a.W + (size_t)k0 * a.ldw : a.W + k0;                                            \
-        qa##R##0 = *reinterpret_cast<const float4*>(Ak + offa0);                                                    \
-        qw##R##0 = *reinterpret_cast<const float4*>(Wk + offw0); qw##R##1 = *reinterpret_cast<const float4*>(Wk + offw1); \
+        /* buffer loads (round 5): descriptor in scalar registers + loop-invariant 32-bit byte offset per lane + the tile's    */ \
+        /* scalar byte offset — no vector ALU address arithmetic per tile.  (With 64-bit per-lane addresses hipcc computed     */ \
+        /* each address into the destination registers of the load it feeds and waited for the PREVIOUS register set's loads   */ \
+        /* at the top of every step: s_waitcnt vmcnt(0) — the two-step prefetch never had two steps.)                          */ \
+        const uint32_t sofa = (uint32_t)k0 * 4u, sofw = WKMAJOR ? (uint32_t)k0 * (uint32_t)a.ldw * 4u : (uint32_t)k0 * 4u;  \
+        qa##R##0 = n100_ldb(rsA, 4u * offa0, sofa);                                                                 \
+        qw##R##0 = n100_ldb(rsW, 4u * offw0, sofw); qw##R##1 = n100_ldb(rsW, 4u * offw1, sofw);                     \
         if constexpr (KW == 1) {        /* 256 threads: 2 activation and 4 weight vectors each; 512 threads: 1 and 2 */ \
-            qa##R##1 = *reinterpret_cast<const float4*>(Ak + offa1);                                                \
-            qw##R##2 = *reinterpret_cast<const float4*>(Wk + offw2); qw##R##3 = *reinterpret_cast<const float4*>(Wk + offw3); \
+            qa##R##1 = n100_ldb(rsA, 4u * offa1, sofa);                                                             \
+            qw##R##2 = n100_ldb(rsW, 4u * offw2, sofw); qw##R##3 = n100_ldb(rsW, 4u * offw3, sofw);                 \
         }                                                                                                           \
     }
 #define GF_N100_SSTORE(R, BUF)                                                                                      \
@@ -291,6 +303,9 @@ int launch_gemm_n100(const float* A, int lda, const float* W, int ldw, int w_kma
     GF_CHECK_ARG(A && W && C && splits_io && T > 0 && n100_supported(NE, K), "gemm_n100: bad arguments (K=%d)", K);
     GF_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(C) && (lda & 3) == 0 && (ldw & 3) == 0 && (slab_stride & 3) == 0 &&
                      (!bias || aligned16(bias)), "gemm_n100: operands must be 16-byte aligned");
+    GF_CHECK_ARG((unsigned long long)T * (unsigned long long)lda * 4ull < (1ull << 32) &&
+                     (unsigned long long)(w_kmajor ? K : NE) * (unsigned long long)ldw * 4ull < (1ull << 32),
+                 "gemm_n100: an operand of 4 GiB or more is not supported");
     const int ksteps = K / NBK;
     int s = n100_splits(T, K, *splits_io < 1 ? 1 : *splits_io, w_kmajor);
     const int per = (ksteps + s - 1) / s;
