@@ -66,6 +66,19 @@ def test_gemm_nn(lib, M, N, K):
     assert rel_err(Cd, ref) < 2e-6 * max(1, K ** 0.5)
 
 
+def test_gemm_refuses_an_operand_of_4_gib(lib):
+    """the K loops read their operands through buffer descriptors with 32-bit byte offsets (csrc/gemm.hip `fits32`): an operand
+    of 4 GiB or more must be refused with a message, not wrap around (the path's matrices are 1-50 MB)"""
+    from gan_ffn_amd._lib import GanffnError
+    M = K = 32768                                   # M * K * 4 bytes = 4 GiB exactly
+    A = torch.empty(M, K, device="cuda")            # never read
+    W, b, Cd = torch.zeros(4, K, device="cuda"), torch.zeros(4, device="cuda"), torch.zeros(M, 4, device="cuda")
+    with pytest.raises(GanffnError, match="4 GiB"):
+        lib.call("ganffn_gemm_nt", ptr(A), ptr(W), ptr(b), ptr(Cd), M, 4, K, stream())
+    del A
+    torch.cuda.empty_cache()
+
+
 def test_weight_resident_short_k_kernel_gives_the_generic_kernels_bits(lib):
     """K = 100, N >= 1024 runs on the persistent weight-resident kernel (gemm_wres_kernel); the same rows through the
     generic kernel (N < 1024) must give identical bits — both use the same k order inside the MFMA chain"""
