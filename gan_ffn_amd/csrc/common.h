@@ -153,8 +153,12 @@ __device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, u
         asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p1), "=s"(cy1) : "s"(M1), "v"(c2));
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        const uint32_t n0 = hi1 ^ c1 ^ k0;
-        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        // hi ^ c ^ k in ONE instruction: gfx950's v_bitop3_b32 with the truth table of a 3-input xor (0x96); hipcc emits two
+        // v_xor_b32 (gfx9 has no v_xor3) — 40 instead of 20 per call, and every one of them is paid in MFMA time in the GEMM
+        // epilogues.  The round key is wave-uniform (make_drop reads it through scalar loads): the one scalar operand allowed.
+        uint32_t n0, n2;
+        asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n0) : "v"(hi1), "v"(c1), "s"(k0));
+        asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n2) : "v"(hi0), "v"(c3), "s"(k1));
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
