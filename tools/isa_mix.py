@@ -26,7 +26,7 @@ def demangle(names):
 def listing(path):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
-        subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950:xnack-", "--cuda-device-only", "-S", "-o", out, os.path.basename(path)],
+        subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950:xnack-", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "--cuda-device-only", "-S", "-o", out, os.path.basename(path)],
                        cwd=os.path.dirname(path), check=True, stderr=subprocess.DEVNULL)
         return open(out).read()
 
