@@ -39,6 +39,10 @@ def csrc_sha16():
             h.update(n.encode())
             h.update(_code_only(open(os.path.join(d, n)).read()).encode())
     h.update(_code_only(open(os.path.join(root, "include", "ganffn.h")).read()).encode())
+    # the compiler flags decide the code as much as the sources do (round 5: -amdgpu-mfma-vgpr-form): the Makefile's CXXFLAGS line
+    for line in open(os.path.join(d, "Makefile")):
+        if line.startswith("CXXFLAGS"):
+            h.update(line.strip().encode())
     return h.hexdigest()[:16]
 
 
