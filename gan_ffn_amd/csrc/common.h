@@ -142,6 +142,8 @@ __device__ __forceinline__ DropCtx make_drop(const uint64_t* rng, uint64_t add, 
     return d;
 }
 
+// k0 / k1 (the seed halves) MUST be wave-uniform: they are scalar operands of the round's xor (every caller takes them from
+// make_drop, which reads the generator state through scalar loads); the counter words c0..c3 are per lane.
 __device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                         uint32_t k1, uint32_t (&out)[4]) {
     // one v_mad_u64_u32 per 32x32->64 product (hipcc would emit v_mul_hi_u32 + v_mul_lo_u32, both quarter-rate)
