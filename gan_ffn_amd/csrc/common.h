@@ -94,6 +94,25 @@ static inline int lds_optin(size_t lds, const char* what) {
 }
 
 // ---------------------------------------------------------------------------------------
+// buffer loads / stores: a 128-bit descriptor in scalar registers + a 32-bit byte offset per lane + a scalar byte offset —
+// no 64-bit per-lane address arithmetic (fp32 MFMAs share the vector ALU: every VALU instruction next to them costs MFMA time,
+// and hipcc's 64-bit address temporaries alias load destinations and bring low s_waitcnt vmcnt to the top of K-loop steps:
+// DESIGN.md section 0d rows 2c / 2d).  The hardware range check covers the LANE offset only (not the scalar one); callers
+// that pass bytes = 0xFFFFFFFF clamp their offsets into the operand themselves, and the launchers refuse operands >= 4 GiB.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load_f4(__amdgpu_buffer_rsrc_t rs, uint32_t voff_bytes, uint32_t soff_bytes) {
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+    const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff_bytes, (int)soff_bytes, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void buf_store_u32(__amdgpu_buffer_rsrc_t rs, uint32_t voff_bytes, uint32_t soff_bytes, uint32_t v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, rs, (int)voff_bytes, (int)soff_bytes, 0);
+}
+
+// ---------------------------------------------------------------------------------------
 // dropout sites (mirror of oracle/ganffn_oracle.py SITE_*)
 // ---------------------------------------------------------------------------------------
 enum : uint32_t {

@@ -34,16 +34,6 @@ namespace ganffn {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-// buffer loads / stores: a 128-bit descriptor in scalar registers + a 32-bit byte offset per lane + a scalar byte offset —
-// no 64-bit per-lane address arithmetic (fp32 MFMAs share the vector ALU: every VALU instruction next to them costs MFMA time)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 buf_load_f4(__amdgpu_buffer_rsrc_t rs, uint32_t voff_bytes, uint32_t soff_bytes) {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff_bytes, (int)soff_bytes, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
 // Four single instructions hipcc will not leave alone: written in C++, `x & sext(bit)` and `min(x, 1) << i | y` come back
 // as v_and + v_cmp_ne + v_cndmask chains (instcombine's canonical select form) — 3-4 instructions where one or two do.
 __device__ __forceinline__ uint32_t v_bit_to_mask(uint32_t word, int bit) {            // 0 or 0xFFFFFFFF
@@ -61,9 +51,6 @@ __device__ __forceinline__ uint32_t v_nonzero_bit_or(uint32_t x, int bit, uint32
     asm("v_min_u32 %0, 1, %1" : "=v"(t) : "v"(x));
     asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(t), "n"(bit), "v"(acc));
     return r;
-}
-__device__ __forceinline__ void buf_store_u32(__amdgpu_buffer_rsrc_t rs, uint32_t voff_bytes, uint32_t soff_bytes, uint32_t v) {
-    __builtin_amdgcn_raw_buffer_store_b32(v, rs, (int)voff_bytes, (int)soff_bytes, 0);
 }
 
 // BK in {16, 32, 64}; K-contiguous LDS row stride BK + 4 = 4 * odd  (20, 36, 68)

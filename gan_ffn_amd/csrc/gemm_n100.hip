@@ -36,12 +36,6 @@ constexpr int LDWK = 116;          // K-major weight tile [32][116]: rows 4 apar
 // K-contiguous LDS tile [rows][32]: 16-byte slot s of row r at slot s ^ ((r / 2) % 8) (gemm.hip kc_off<32>)
 __device__ __forceinline__ int sw32(int row, int slot) { return row * NBK + 4 * (slot ^ ((row >> 1) & 7)); }
 
-__device__ __forceinline__ float4 n100_ldb(__amdgpu_buffer_rsrc_t rs, uint32_t voff_bytes, uint32_t soff_bytes) {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff_bytes, (int)soff_bytes, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
 struct N100Args {
     const float* A; int lda;       // activations [T x K]
     const float* W; int ldw;       // NT: [100 x K] rows of K;  NN: [K x 100] rows of 100
@@ -98,8 +92,8 @@ __global__ __launch_bounds__(256 * KW) void gemm_n100_kernel(N100Args a) {
     // steps (~3600 MFMA cycles) to arrive — with one step of cover a lone workgroup on a CU was load-latency-bound
     float4 qaA0, qaA1, qwA0, qwA1, qwA2, qwA3, qaB0, qaB1, qwB0, qwB1, qwB2, qwB3;
     // (every offset below is clamped into its operand: unbounded descriptors; the launcher refuses operands of 4 GiB or more)
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = buf_rsrc(a.A, 0xFFFFFFFFu);
+    const __amdgpu_buffer_rsrc_t rsW = buf_rsrc(a.W, 0xFFFFFFFFu);
 #define GF_N100_GLOAD(R, TT)                                                                                        \
     {                                                                                                               \
         const int k0 = kbeg + min((TT), nt - 1) * NBK; /* (a prefetch beyond the last tile re-reads it: never consumed) */ \
@@ -108,11 +102,11 @@ __global__ __launch_bounds__(256 * KW) void gemm_n100_kernel(N100Args a) {
         /* each address into the destination registers of the load it feeds and waited for the PREVIOUS register set's loads   */ \
         /* at the top of every step: s_waitcnt vmcnt(0) — the two-step prefetch never had two steps.)                          */ \
         const uint32_t sofa = (uint32_t)k0 * 4u, sofw = WKMAJOR ? (uint32_t)k0 * (uint32_t)a.ldw * 4u : (uint32_t)k0 * 4u;  \
-        qa##R##0 = n100_ldb(rsA, 4u * offa0, sofa);                                                                 \
-        qw##R##0 = n100_ldb(rsW, 4u * offw0, sofw); qw##R##1 = n100_ldb(rsW, 4u * offw1, sofw);                     \
+        qa##R##0 = buf_load_f4(rsA, 4u * offa0, sofa);                                                                 \
+        qw##R##0 = buf_load_f4(rsW, 4u * offw0, sofw); qw##R##1 = buf_load_f4(rsW, 4u * offw1, sofw);                     \
         if constexpr (KW == 1) {        /* 256 threads: 2 activation and 4 weight vectors each; 512 threads: 1 and 2 */ \
-            qa##R##1 = n100_ldb(rsA, 4u * offa1, sofa);                                                             \
-            qw##R##2 = n100_ldb(rsW, 4u * offw2, sofw); qw##R##3 = n100_ldb(rsW, 4u * offw3, sofw);                 \
+            qa##R##1 = buf_load_f4(rsA, 4u * offa1, sofa);                                                             \
+            qw##R##2 = buf_load_f4(rsW, 4u * offw2, sofw); qw##R##3 = buf_load_f4(rsW, 4u * offw3, sofw);                 \
         }                                                                                                           \
     }
 #define GF_N100_SSTORE(R, BUF)                                                                                      \

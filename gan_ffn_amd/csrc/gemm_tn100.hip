@@ -40,12 +40,6 @@ constexpr int WE = 100, WT7 = 7, WBK = 32, WBN = 64;
 constexpr int LDU = 116, LDV = 68;            // = 4 (mod 8): ds_read_b32 of rows g and g + 1 (4 k apart... see above) conflict-free
 constexpr int WMAXP = 40, WMAXSPLIT = 8;
 
-__device__ __forceinline__ float4 tn100_ldb(__amdgpu_buffer_rsrc_t rs, uint32_t voff_bytes, uint32_t soff_bytes) {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff_bytes, (int)soff_bytes, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
 struct W100Problem {
     const float* U; const float* V;            // U: [K x 100] (the 100-wide operand), V: [K x Nn]
     float* C; float* colsum;                   // gradient [M x N] (ldc) and bias gradient [M] (or null)
@@ -118,19 +112,19 @@ __global__ __launch_bounds__(256) void tn100_kernel(W100Group grp) {
     const uint32_t lov0 = (uint32_t)rv0 * (uint32_t)ldv + offv0, lov1 = (uint32_t)rv1 * (uint32_t)ldv + offv1;
     // (buffer descriptors: the tile's token offset goes into the SCALAR offset of the load — no per-lane 64-bit pointer to advance;
     //  unbounded: a full tile lies inside the operands by construction; operands of 4 GiB or more are refused by the launcher)
-    const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ug), 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vg), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsU = buf_rsrc(Ug, 0xFFFFFFFFu);
+    const __amdgpu_buffer_rsrc_t rsV = buf_rsrc(Vg, 0xFFFFFFFFu);
 #define GF_W_GLOAD(TT)                                                                                \
     {                                                                                                 \
         const int k0 = kbeg + min((TT), nt - 1) * WBK, kl = kend - 1;                                 \
         if (k0 + WBK <= kend) {                             /* wave-uniform */                          \
             const uint32_t su_ = (uint32_t)k0 * (uint32_t)ldu * 4u, sv_ = (uint32_t)k0 * (uint32_t)ldv * 4u;   /* scalar */ \
-            qu0 = tn100_ldb(rsU, 4u * lou0, su_);                                                     \
-            qu1 = tn100_ldb(rsU, 4u * lou1, su_);                                                     \
-            qu2 = tn100_ldb(rsU, 4u * lou2, su_);                                                     \
-            qu3 = tn100_ldb(rsU, 4u * lou3, su_);                                                     \
-            qv0 = tn100_ldb(rsV, 4u * lov0, sv_);                                                     \
-            qv1 = tn100_ldb(rsV, 4u * lov1, sv_);                                                     \
+            qu0 = buf_load_f4(rsU, 4u * lou0, su_);                                                     \
+            qu1 = buf_load_f4(rsU, 4u * lou1, su_);                                                     \
+            qu2 = buf_load_f4(rsU, 4u * lou2, su_);                                                     \
+            qu3 = buf_load_f4(rsU, 4u * lou3, su_);                                                     \
+            qv0 = buf_load_f4(rsV, 4u * lov0, sv_);                                                     \
+            qv1 = buf_load_f4(rsV, 4u * lov1, sv_);                                                     \
         } else {                                                                                      \
             qu0 = *reinterpret_cast<const float4*>(Ug + (size_t)min(k0 + ru0, kl) * ldu + offu0);     \
             qu1 = *reinterpret_cast<const float4*>(Ug + (size_t)min(k0 + ru1, kl) * ldu + offu1);     \
